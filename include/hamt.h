@@ -1,0 +1,201 @@
+/*
+ * hamt.h -- C ABI of libhamt_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the HAMT
+ * history-aware multimodal transformer forward/backward.
+ *
+ * The reference (cshizhe/VLN-HAMT) is pure Python: its "interface" for this path is the torch.nn
+ * class surface of pretrain_src/model/{vilmodel,pretrain_cmt}.py.  That surface is re-declared in
+ * the vln-hamt_amd/model package; every forward there lowers to the entry points below through ctypes
+ * (vln-hamt_amd/_lib.py).  Each entry point names the reference op group it replaces
+ * (file:line relative to /root/reference; IDs A1..A24 are SURVEY.md section 8a).
+ *
+ * Conventions
+ *  - plain C: raw device pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *  - return 0 on success, negative hamt_status otherwise; hamt_last_error() gives the text
+ *    (thread-local).  No C++ exception crosses the boundary.
+ *  - asynchronous on the given stream; no allocation, no synchronisation, no global mutable state:
+ *    every scratch buffer is passed in by the caller (hipGraph-capture safe).
+ *  - row-major tensors; "ld*" are leading dimensions in ELEMENTS; every row must start 16-byte
+ *    aligned (ld * sizeof(elem) % 16 == 0).
+ *  - dropout is counter based: mask(idx) = hash(rng[0] (seed), rng[1] (epoch), call_id, idx) with
+ *    `rng` a DEVICE pointer to two uint64 (so a captured graph draws fresh masks every replay when
+ *    the epoch word is bumped) and call_id a host value unique per call site; backward replays the
+ *    mask from the same triple, nothing is stored.
+ */
+#ifndef HAMT_H
+#define HAMT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAMT_ABI_VERSION 1
+
+typedef enum { HAMT_OK = 0, HAMT_ERR_ARG = -1, HAMT_ERR_UNSUPPORTED = -2, HAMT_ERR_LAUNCH = -3 } hamt_status;
+typedef enum { HAMT_F32 = 0, HAMT_BF16 = 1 } hamt_dtype;
+/* arithmetic of the contraction: bf16 MFMA operands with fp32 accumulate, or exact fp32 MFMA */
+typedef enum { HAMT_PREC_BF16 = 0, HAMT_PREC_F32 = 1 } hamt_prec;
+
+int hamt_version(void);
+/* copies the calling thread's last error text into buf (NUL terminated); returns its length */
+int hamt_last_error(char* buf, size_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue( A[M,K] * B[K,N] )            (all nn.Linear calls of A2-A5, A7, A10, A11,
+ * A15-A20 forward; their dgrad dX = dY*W and wgrad dW = dY^T*X backward)
+ *   a_kmajor = 0: A stored [M][K] (K contiguous)      1: A stored [K][M] (M contiguous)
+ *   b_kmajor = 0: B stored [N][K] (nn.Linear weight)  1: B stored [K][N]
+ *   forward  y = x W^T      : a_kmajor 0, b_kmajor 0      (vilmodel.py:97-99, 140, 169, 182 ...)
+ *   dgrad    dx = dy W      : a_kmajor 0, b_kmajor 1
+ *   wgrad    dW = dy^T x    : a_kmajor 1, b_kmajor 1
+ * epilogue flags (applied in this order): v = alpha*acc; +bias[n]; store pre-activation to aux
+ * (HAMT_EPI_SAVE_PRE); GELU(erf) or ReLU; multiply by gelu'(aux[m,n]) / relu'(aux[m,n])
+ * (HAMT_EPI_MUL_DGELU / _DRELU: fused activation backward for dgrad); C += v (HAMT_EPI_ACCUM).
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  HAMT_EPI_BIAS = 1, HAMT_EPI_GELU = 2, HAMT_EPI_RELU = 4, HAMT_EPI_ACCUM = 8,
+  HAMT_EPI_MUL_DGELU = 16, HAMT_EPI_MUL_DRELU = 32, HAMT_EPI_SAVE_PRE = 64
+};
+typedef struct {
+  int M, N, K;
+  int lda, ldb, ldc, ldaux;
+  int a_kmajor, b_kmajor;
+  int dtype_a, dtype_b, dtype_c, dtype_aux; /* hamt_dtype */
+  int prec;                                 /* hamt_prec  */
+  int epilogue;                             /* HAMT_EPI_* */
+  float alpha;
+} hamt_gemm_desc;
+int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+              void* aux, void* stream);
+
+/* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
+int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate,
+                float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * attn_small: multi-head softmax attention for short sequences (A2 core vilmodel.py:101-126,
+ * A7 core vilmodel.py:327-348): S = Q K^T * scale + mask[b, key]; P = softmax(S); P = dropout(P);
+ * O = P V, heads split/merged by pointer arithmetic (head h = columns [h*64, h*64+64)).
+ * Q rows (b*Sq + i) at q + row*ldq, K/V rows (b*Sk + j); mask is the reference's additive
+ * (1-m)*-10000 row, fp32 [B, Sk] (may be NULL).  d_head must be 64.  lse[B,heads,Sq] (fp32) is
+ * saved for backward.  Backward recomputes P (flash style) and needs delta = rowsum(dO*O)
+ * computed by hamt_attn_small_bwd itself into `delta` ([B,heads,Sq] fp32 scratch).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int B, heads, Sq, Sk, d_head;
+  int ldq, ldk, ldv, ldo;
+  int dtype_qkv, dtype_o; /* hamt_dtype */
+  float scale, p_drop;
+  uint32_t call_id;
+} hamt_attn_desc;
+int hamt_attn_small_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v,
+                        const float* add_mask, void* o, float* lse, const uint64_t* rng, void* stream);
+/* dq/dk/dv have the layout (ld, dtype) of q/k/v; do has the layout of o */
+int hamt_attn_small_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v,
+                        const float* add_mask, const void* o, const void* d_o, const float* lse,
+                        float* delta, void* dq, void* dk, void* dv, const uint64_t* rng, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ln: y = dropout_post( LayerNorm( dropout_pre(x) + residual ) )      fp32 statistics
+ *   BertSelfOutput / BertOutput (A3/A5, vilmodel.py:139-143, 181-185): p_pre = p, residual, p_post = 0
+ *   BertEmbeddings / Image / History embeddings (A1, A10, A11):        p_pre = 0, p_post = p
+ *   prediction heads (pretrain_cmt.py:13-71): LN followed by Dropout:  p_post = p
+ * z (the pre-LN sum) is written for backward (may alias x).  y16 (bf16 copy of y) optional.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int M, H;
+  float eps, p_pre, p_post;
+  uint32_t call_id;
+} hamt_ln_desc;
+int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
+                const float* beta, float* z, float* y, void* y16, float* mean, float* rstd,
+                const uint64_t* rng, void* stream);
+/* dz = d(pre-LN sum) (also the residual gradient); dx = dropout_pre-masked dz (NULL when p_pre == 0:
+ * then dx == dz); dgamma/dbeta are ACCUMULATED (+=).  ws: >= 2*256*H floats. */
+int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+                const float* rstd, const float* gamma, float* dz, float* dx, float* dgamma,
+                float* dbeta, float* ws, const uint64_t* rng, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gather/scatter family (embedding lookups A1/A10/A11, boolean-mask compaction A15/A19
+ * pretrain_cmt.py:161-165, SPREL anchor gather A18 pretrain_cmt.py:211-214, cat/slice A9/A12)
+ *   gather_rows:  out[r, col0:col0+W] = (base ? base[r, col0:col0+W] : 0) + src[idx[r], :W]   idx int64, r < R
+ *   scatter_add:  dst[idx[r], :W] += src[r, col0:col0+W]   (atomic; duplicate indices allowed)
+ * idx == NULL means identity (row copy between strided buffers); out may alias base.
+ * ---------------------------------------------------------------------------------------------- */
+int hamt_gather_rows(int R, int W, const float* src, int ld_src, const int64_t* idx, const float* base,
+                     int ld_base, float* out, int ld_out, int col0, void* stream);
+int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
+                          float* dst, int ld_dst, void* stream);
+
+/* BertEmbeddings sum (A1, vilmodel.py:62-66): z[b*L+l] = word[ids[b,l]] + pos[l] + type0 */
+int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* word, const float* pos,
+                       const float* type_row, float* z, void* stream);
+/* backward: dword[ids] += dz (atomic), dpos[l] += sum_b dz, dtype_row += sum dz */
+int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword,
+                       float* dpos, float* dtype_row, void* stream);
+
+/* broadcast row ops over x[B, S, H]:
+ *   mean over the middle axis  (A11 vilmodel.py:563-564):  y[b,:] = mean_s x[b,s,:]
+ *   mul_bcast (A16 pretrain_cmt.py:176, A13 :722):  y[b,s,:] = a[b,s,:] * c[b,:]
+ */
+int hamt_mean_mid_fwd(int B, int S, int H, const float* x, float* y, void* stream);
+int hamt_mean_mid_bwd(int B, int S, int H, const float* dy, float* dx, void* stream);
+int hamt_mul_bcast_fwd(int B, int S, int H, const float* a, const float* c, int ldc_rows, float* y, void* stream);
+int hamt_mul_bcast_bwd(int B, int S, int H, const float* a, const float* c, int ldc_rows, const float* dy,
+                       float* da, float* dc, void* stream);
+/* sums x[B,S,H] over b and/or s into out (accumulate): mode 0: out[H] += sum_{b,s}; 1: out[s,H] += sum_b */
+int hamt_sum_rows(int B, int S, int H, const float* x, int mode, float* out, float* ws, void* stream);
+
+/* elementwise: out = a + b (+ c) ; dropout forward/backward (feature dropout, model_HAMT.py:32-52) */
+int hamt_add3(size_t n, const float* a, const float* b, const float* c, float* out, void* stream);
+int hamt_dropout(size_t n, const float* x, float* y, float p, uint32_t call_id, const uint64_t* rng, void* stream);
+int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* stream);
+/* x[i] = value where flag[i] == 0  (A16 in-place masked_fill_(nav_types == 0, -inf), pretrain_cmt.py:177;
+ * its backward zeroes the gradient at the same positions) */
+int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, void* stream);
+/* dx = dy * act'(h): mode 1 erf-GELU (vilmodel.py:23-29), mode 2 ReLU (h may be the ReLU output) */
+int hamt_act_bwd(size_t n, const float* dy, const float* h, int mode, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * losses, reduction='none' as in the reference
+ *   ce:  loss[r] = logsumexp(x[r,:C]) - x[r,label[r]]     (A15/A16/A20; -inf logits allowed)
+ *        backward  dx[r,c] = g[r] * (softmax(x[r])[c] - [c == label[r]])
+ *   mse: loss = (x - t)^2 elementwise (A17/A18); backward dx = 2 g (x - t)
+ *   kl:  loss[r] = sum_c t*(log t - log_softmax(x)[c]) with 0*log0 = 0 (A19, pretrain_cmt.py:239-240)
+ *        backward dx[r,c] = g[r] * (softmax(x)[c] * sum_c t - t[c])
+ * ---------------------------------------------------------------------------------------------- */
+int hamt_ce_fwd(int R, int C, const float* x, int ldx, const int64_t* label, float* loss, float* lse, void* stream);
+int hamt_ce_bwd(int R, int C, const float* x, int ldx, const int64_t* label, const float* lse,
+                const float* g, float* dx, int lddx, void* stream);
+int hamt_mse_fwd(size_t n, const float* x, const float* t, float* loss, void* stream);
+int hamt_mse_bwd(size_t n, const float* x, const float* t, const float* g, float* dx, void* stream);
+int hamt_kl_fwd(int R, int C, const float* x, int ldx, const float* t, int ldt, float* loss, float* lse, void* stream);
+int hamt_kl_bwd(int R, int C, const float* x, int ldx, const float* t, int ldt, const float* lse,
+                const float* g, float* dx, int lddx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * optimiser side (A24): global L2 norm over a flat gradient arena, then the reference's HF AdamW
+ * (optim/adamw.py:53-112): m,v update; p -= step_size * m / (sqrt(v) + eps); THEN p -= lr*wd*p.
+ * hyper is a DEVICE array: [0]=lr, [1]=step_size (bias corrected lr), [2]=max_grad_norm (<=0: no clip).
+ * gnorm_sq is a device scalar holding sum(g^2) (from hamt_sumsq); the clip coefficient
+ * min(1, max_norm/(sqrt(gnorm_sq)+1e-6)) (torch clip_grad_norm_, main_r2r.py:271) is applied to g on
+ * the fly.  p16 (optional) receives the bf16 shadow of the updated parameters; g is zeroed when
+ * zero_grad != 0 (optimizer.zero_grad(), main_r2r.py:280).
+ * ---------------------------------------------------------------------------------------------- */
+int hamt_sumsq(size_t n, const float* g, float* out, int accumulate, float* ws, void* stream);
+int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v, void* p16, const float* hyper,
+                    const float* gnorm_sq, float beta1, float beta2, float eps, float weight_decay,
+                    int zero_grad, void* stream);
+/* g *= min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  -- standalone clip for torch-optimiser users */
+int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream);
+
+/* rng[1] += 1 on the stream (new dropout epoch; call once per optimisation step) */
+int hamt_rng_advance(uint64_t* rng, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAMT_H */

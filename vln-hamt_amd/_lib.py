@@ -1,0 +1,108 @@
+"""ctypes binding of libhamt_hip.so (include/hamt.h).
+
+The product path has NO fallback: if the library is missing, or a call returns a negative status,
+this module raises.  Build it with ``python vln-hamt_amd/csrc/build.py`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhamt_hip.so")
+
+HAMT_F32, HAMT_BF16 = 0, 1
+PREC_BF16, PREC_F32 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_RELU, EPI_ACCUM, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
+
+vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldaux", i32),
+                ("a_kmajor", i32), ("b_kmajor", i32), ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
+                ("dtype_aux", i32), ("prec", i32), ("epilogue", i32), ("alpha", f32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("B", i32), ("heads", i32), ("Sq", i32), ("Sk", i32), ("d_head", i32), ("ldq", i32), ("ldk", i32),
+                ("ldv", i32), ("ldo", i32), ("dtype_qkv", i32), ("dtype_o", i32), ("scale", f32), ("p_drop", f32),
+                ("call_id", u32)]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32)]
+
+
+# name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
+SIGNATURES = {
+    "hamt_version": [],
+    "hamt_last_error": [C.c_char_p, sz],
+    "hamt_gemm": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp],
+    "hamt_colsum": [i32, i32, vp, i32, i32, vp, i32, vp, vp],
+    "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_attn_small_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
+    "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
+    "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "hamt_embed_sum_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "hamt_mean_mid_fwd": [i32, i32, i32, vp, vp, vp],
+    "hamt_mean_mid_bwd": [i32, i32, i32, vp, vp, vp],
+    "hamt_mul_bcast_fwd": [i32, i32, i32, vp, vp, i32, vp, vp],
+    "hamt_mul_bcast_bwd": [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp],
+    "hamt_sum_rows": [i32, i32, i32, vp, i32, vp, vp, vp],
+    "hamt_add3": [sz, vp, vp, vp, vp, vp],
+    "hamt_dropout": [sz, vp, vp, f32, u32, vp, vp],
+    "hamt_cast_f32_bf16": [sz, vp, vp, vp],
+    "hamt_fill_where_zero": [sz, vp, vp, f32, vp],
+    "hamt_act_bwd": [sz, vp, vp, i32, vp, vp],
+    "hamt_ce_fwd": [i32, i32, vp, i32, vp, vp, vp, vp],
+    "hamt_ce_bwd": [i32, i32, vp, i32, vp, vp, vp, vp, i32, vp],
+    "hamt_mse_fwd": [sz, vp, vp, vp, vp],
+    "hamt_mse_bwd": [sz, vp, vp, vp, vp, vp],
+    "hamt_kl_fwd": [i32, i32, vp, i32, vp, i32, vp, vp, vp],
+    "hamt_kl_bwd": [i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp],
+    "hamt_sumsq": [sz, vp, vp, i32, vp, vp],
+    "hamt_adamw_flat": [sz, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp],
+    "hamt_clip_scale": [sz, vp, vp, f32, vp],
+    "hamt_rng_advance": [vp, vp],
+}
+
+_lib = None
+
+
+class HamtError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libhamt_hip.so once.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HamtError(f"{LIB_PATH} is missing: build it with `python vln-hamt_amd/csrc/build.py` "
+                        "(there is no CPU/PyTorch fallback for the HAMT kernels)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    if lib.hamt_version() != 1:
+        raise HamtError("libhamt_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().hamt_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, name: str):
+    if rc != 0:
+        raise HamtError(f"{name} failed (status {rc}): {last_error()}")

@@ -1,0 +1,86 @@
+// Shared device/host helpers for libhamt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/hamt.h"
+
+#define HAMT_WAVE 64
+
+void hamt_set_error(const char* fmt, ...);
+
+#define HAMT_CHECK_ARG(cond, ...)                      \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      hamt_set_error(__VA_ARGS__);                     \
+      return HAMT_ERR_ARG;                             \
+    }                                                  \
+  } while (0)
+
+#define HAMT_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) {                                                           \
+      hamt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));           \
+      return HAMT_ERR_LAUNCH;                                                          \
+    }                                                                                  \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+
+// ---- bf16 <-> f32 (round to nearest even; NaN preserved)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- counter-based dropout RNG: 24-bit uniform from (seed, epoch, call_id, element index)
+__device__ __forceinline__ uint32_t hamt_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+struct RngKey { uint32_t k0, k1; };
+__device__ __forceinline__ RngKey rng_key(const uint64_t* rng, uint32_t call_id) {
+  RngKey k;
+  uint64_t seed = rng ? rng[0] : 0x9E3779B97F4A7C15ull, epoch = rng ? rng[1] : 0ull;
+  k.k0 = hamt_mix32((uint32_t)seed ^ hamt_mix32((uint32_t)epoch + 0x9e3779b9u) ^ (call_id * 0x85ebca6bu));
+  k.k1 = hamt_mix32((uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 32) ^ (call_id + 0xc2b2ae35u));
+  return k;
+}
+// keep-probability test for element idx; returns the multiplicative factor (0 or 1/(1-p))
+__device__ __forceinline__ float drop_scale(RngKey k, uint64_t idx, float p, float inv_keep) {
+  uint32_t x = hamt_mix32((uint32_t)idx ^ k.k0);
+  x = hamt_mix32(x + (uint32_t)(idx >> 32) * 0x9e3779b9u + k.k1);
+  float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

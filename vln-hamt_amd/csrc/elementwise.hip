@@ -1,0 +1,284 @@
+// Gather / scatter / broadcast / elementwise kernels (all HBM- or L2-bound; 16-byte accesses, one row
+// per 64..256 threads).  They carry the integer/index work of the path, which must be bit-exact:
+// embedding lookups (vilmodel.py:62-66, 501, 543, 569), boolean-mask compaction
+// (pretrain_cmt.py:161-165), SPREL anchor gather + concat (pretrain_cmt.py:211-214), hist/obs
+// concat + slice (vilmodel.py:467-468, 475-477, 618), panorama mean (vilmodel.py:563-564), the SAP/ITM
+// fusion products (pretrain_cmt.py:176, vilmodel.py:722) and the -inf fill (pretrain_cmt.py:177).
+#include "common.h"
+
+void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s);
+
+namespace {
+
+__global__ void gather_rows_kernel(int R, int W, const float* __restrict__ src, int ld_src,
+                                   const int64_t* __restrict__ idx, const float* base, int ld_base, float* out, int ld_out,
+                                   int col0) {
+  const int w4 = W >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * w4; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / w4), c = (int)(i % w4) * 4;
+    const int64_t sr = idx ? idx[r] : r;
+    float4 v = *(const float4*)(src + (size_t)sr * ld_src + c);
+    float* o = out + (size_t)r * ld_out + col0 + c;
+    if (base) { const float4 p = *(const float4*)(base + (size_t)r * ld_base + col0 + c); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+    *(float4*)o = v;
+  }
+}
+__global__ void scatter_add_rows_kernel(int R, int W, const float* __restrict__ src, int ld_src, int col0,
+                                        const int64_t* __restrict__ idx, float* __restrict__ dst, int ld_dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * W; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / W), c = (int)(i % W);
+    const int64_t dr = idx ? idx[r] : r;
+    atomicAdd(dst + (size_t)dr * ld_dst + c, src[(size_t)r * ld_src + col0 + c]);
+  }
+}
+__global__ void embed_sum_fwd_kernel(int B, int L, int H, const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                     const float* __restrict__ pos, const float* __restrict__ type_row, float* __restrict__ z) {
+  const int h4 = H >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * L * h4; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / h4), c = (int)(i % h4) * 4, l = row % L;
+    const float4 a = *(const float4*)(word + (size_t)ids[row] * H + c), p = *(const float4*)(pos + (size_t)l * H + c),
+                 ty = *(const float4*)(type_row + c);
+    // same association as the reference: (word + position) + token_type  (vilmodel.py:66)
+    *(float4*)(z + (size_t)row * H + c) = make_float4((a.x + p.x) + ty.x, (a.y + p.y) + ty.y, (a.z + p.z) + ty.z, (a.w + p.w) + ty.w);
+  }
+}
+__global__ void embed_sum_bwd_kernel(int B, int L, int H, const int64_t* __restrict__ ids, const float* __restrict__ dz,
+                                     float* __restrict__ dword) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * L * H; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / H), c = (int)(i % H);
+    atomicAdd(dword + (size_t)ids[row] * H + c, dz[i]);
+  }
+}
+// x[B,S,H]: mode 0 -> partial sums over (b,s) per block-row-chunk; mode 1 -> sums over b per (s,h)
+__global__ void sum_rows_partial_kernel(int R, int H, const float* __restrict__ x, float* __restrict__ ws, int rows_per_chunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(size_t)r * H + c];
+  ws[(size_t)blockIdx.y * H + c] = s;
+}
+__global__ void sum_over_b_kernel(int B, int SH, const float* __restrict__ x, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= SH) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += x[(size_t)b * SH + i];
+  out[i] += s;
+}
+__global__ void mean_mid_fwd_kernel(int B, int S, int H, const float* __restrict__ x, float* __restrict__ y) {
+  const int h4 = H >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * h4) return;
+  const int b = (int)(i / h4), c = (int)(i % h4) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < S; ++j) {
+    const float4 v = *(const float4*)(x + ((size_t)b * S + j) * H + c);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = 1.0f / (float)S;  // torch.mean: sum then divide
+  *(float4*)(y + (size_t)b * H + c) = make_float4(s.x / (float)S, s.y / (float)S, s.z / (float)S, s.w / (float)S);
+  (void)inv;
+}
+__global__ void mean_mid_bwd_kernel(int B, int S, int H, const float* __restrict__ dy, float* __restrict__ dx) {
+  const int h4 = H >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * S * h4; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / h4), c = (int)(i % h4) * 4, b = row / S;
+    const float4 v = *(const float4*)(dy + (size_t)b * H + c);
+    const float inv = 1.0f / (float)S;
+    *(float4*)(dx + (size_t)row * H + c) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  }
+}
+__global__ void mul_bcast_fwd_kernel(int B, int S, int H, const float* __restrict__ a, const float* __restrict__ c, int ldc_rows,
+                                     float* __restrict__ y) {
+  const int h4 = H >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * S * h4; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / h4), col = (int)(i % h4) * 4, b = row / S;
+    const float4 x = *(const float4*)(a + (size_t)row * H + col), m = *(const float4*)(c + (size_t)b * ldc_rows + col);
+    *(float4*)(y + (size_t)row * H + col) = make_float4(x.x * m.x, x.y * m.y, x.z * m.z, x.w * m.w);
+  }
+}
+// da = dy * c ; dc[b] = sum_s dy * a   (one block per (b, 256-column chunk))
+__global__ void mul_bcast_bwd_kernel(int B, int S, int H, const float* __restrict__ a, const float* __restrict__ c, int ldc_rows,
+                                     const float* __restrict__ dy, float* __restrict__ da, float* __restrict__ dc) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (col >= H) return;
+  const float m = c[(size_t)b * ldc_rows + col];
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t o = ((size_t)b * S + s) * H + col;
+    const float g = dy[o];
+    da[o] = g * m;
+    acc += g * a[o];
+  }
+  dc[(size_t)b * H + col] = acc;
+}
+__global__ void add3_kernel(size_t n4, const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c,
+                            float4* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 x = a[i], y = b[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    if (c) { float4 z = c[i]; x.x += z.x; x.y += z.y; x.z += z.z; x.w += z.w; }
+    out[i] = x;
+  }
+}
+__global__ void dropout_kernel(size_t n, const float* __restrict__ x, float* __restrict__ y, float p, uint32_t call_id,
+                               const uint64_t* __restrict__ rng) {
+  const RngKey k = rng_key(rng, call_id);
+  const float ik = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = x[i] * drop_scale(k, i, p, ik);
+}
+__global__ void cast_bf16_kernel(size_t n8, size_t n, const float* __restrict__ x, bf16_t* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = *(const float4*)(x + i * 8), b = *(const float4*)(x + i * 8 + 4);
+    *(uint4*)(y + i * 8) = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[n8 * 8 + threadIdx.x] = f2bf(x[n8 * 8 + threadIdx.x]);
+}
+__global__ void fill_where_zero_kernel(size_t n, const int64_t* __restrict__ flag, float* __restrict__ x, float value) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (flag[i] == 0) x[i] = value;
+}
+// dx = dy * act'(h): mode 1 = erf-GELU (h = pre-activation), mode 2 = ReLU (h = pre-activation or output)
+__global__ void act_bwd_kernel(size_t n4, const float4* __restrict__ dy, const float4* __restrict__ h, int mode, float4* __restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 g = dy[i], x = h[i];
+    float4 r;
+    if (mode == 1) { r.x = g.x * dgelu_erf(x.x); r.y = g.y * dgelu_erf(x.y); r.z = g.z * dgelu_erf(x.z); r.w = g.w * dgelu_erf(x.w); }
+    else { r.x = x.x > 0.f ? g.x : 0.f; r.y = x.y > 0.f ? g.y : 0.f; r.z = x.z > 0.f ? g.z : 0.f; r.w = x.w > 0.f ? g.w : 0.f; }
+    dx[i] = r;
+  }
+}
+__global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
+
+inline int nblocks(size_t work, int bs = 256, int cap = 2048) {
+  size_t b = (work + bs - 1) / bs;
+  return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int hamt_gather_rows(int R, int W, const float* src, int ld_src, const int64_t* idx, const float* base, int ld_base,
+                                float* out, int ld_out, int col0, void* stream) {
+  HAMT_CHECK_ARG(src && out && W % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && col0 % 4 == 0 && (!base || ld_base % 4 == 0),
+                 "hamt_gather_rows: bad argument");
+  if (R == 0) return HAMT_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nblocks((size_t)R * W / 4)), dim3(256), 0, as_stream(stream), R, W, src, ld_src, idx, base, ld_base, out, ld_out, col0);
+  HAMT_CHECK_LAUNCH("hamt_gather_rows");
+  return HAMT_OK;
+}
+extern "C" int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst,
+                                     int ld_dst, void* stream) {
+  HAMT_CHECK_ARG(src && dst, "hamt_scatter_add_rows: null pointer");
+  if (R == 0) return HAMT_OK;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nblocks((size_t)R * W)), dim3(256), 0, as_stream(stream), R, W, src, ld_src, col0, idx, dst, ld_dst);
+  HAMT_CHECK_LAUNCH("hamt_scatter_add_rows");
+  return HAMT_OK;
+}
+extern "C" int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* word, const float* pos,
+                                  const float* type_row, float* z, void* stream) {
+  HAMT_CHECK_ARG(ids && word && pos && type_row && z && H % 4 == 0, "hamt_embed_sum_fwd: bad argument");
+  if (B * L == 0) return HAMT_OK;
+  hipLaunchKernelGGL(embed_sum_fwd_kernel, dim3(nblocks((size_t)B * L * H / 4)), dim3(256), 0, as_stream(stream), B, L, H, ids, word, pos, type_row, z);
+  HAMT_CHECK_LAUNCH("hamt_embed_sum_fwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_sum_rows(int B, int S, int H, const float* x, int mode, float* out, float* ws, void* stream) {
+  HAMT_CHECK_ARG(x && out, "hamt_sum_rows: null pointer");
+  if (B * S == 0) return HAMT_OK;
+  hipStream_t s = as_stream(stream);
+  if (mode == 0) {
+    HAMT_CHECK_ARG(ws, "hamt_sum_rows: mode 0 needs ws (64*H floats)");
+    const int R = B * S;
+    int chunks = R >= 64 * 16 ? 64 : (R + 15) / 16;
+    if (chunks < 1) chunks = 1;
+    const int rpc = (R + chunks - 1) / chunks;
+    hipLaunchKernelGGL(sum_rows_partial_kernel, dim3((H + 255) / 256, chunks), dim3(256), 0, s, R, H, x, ws, rpc);
+    hamt_reduce_partials(chunks, H, ws, out, 1, s);
+  } else {
+    hipLaunchKernelGGL(sum_over_b_kernel, dim3((S * H + 255) / 256), dim3(256), 0, s, B, S * H, x, out);
+  }
+  HAMT_CHECK_LAUNCH("hamt_sum_rows");
+  return HAMT_OK;
+}
+extern "C" int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword, float* dpos,
+                                  float* dtype_row, void* stream) {
+  HAMT_CHECK_ARG(ids && dz, "hamt_embed_sum_bwd: null pointer");
+  if (B * L == 0) return HAMT_OK;
+  hipStream_t s = as_stream(stream);
+  if (dword) hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(nblocks((size_t)B * L * H)), dim3(256), 0, s, B, L, H, ids, dz, dword);
+  if (dpos) hipLaunchKernelGGL(sum_over_b_kernel, dim3((L * H + 255) / 256), dim3(256), 0, s, B, L * H, dz, dpos);
+  (void)dtype_row;  // callers use hamt_sum_rows(mode 0) for the type row (needs a workspace)
+  HAMT_CHECK_LAUNCH("hamt_embed_sum_bwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_mean_mid_fwd(int B, int S, int H, const float* x, float* y, void* stream) {
+  HAMT_CHECK_ARG(x && y && H % 4 == 0 && S > 0, "hamt_mean_mid_fwd: bad argument");
+  if (B == 0) return HAMT_OK;
+  hipLaunchKernelGGL(mean_mid_fwd_kernel, dim3(((size_t)B * H / 4 + 255) / 256), dim3(256), 0, as_stream(stream), B, S, H, x, y);
+  HAMT_CHECK_LAUNCH("hamt_mean_mid_fwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_mean_mid_bwd(int B, int S, int H, const float* dy, float* dx, void* stream) {
+  HAMT_CHECK_ARG(dy && dx && H % 4 == 0 && S > 0, "hamt_mean_mid_bwd: bad argument");
+  if (B == 0) return HAMT_OK;
+  hipLaunchKernelGGL(mean_mid_bwd_kernel, dim3(nblocks((size_t)B * S * H / 4)), dim3(256), 0, as_stream(stream), B, S, H, dy, dx);
+  HAMT_CHECK_LAUNCH("hamt_mean_mid_bwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_mul_bcast_fwd(int B, int S, int H, const float* a, const float* c, int ldc_rows, float* y, void* stream) {
+  HAMT_CHECK_ARG(a && c && y && H % 4 == 0 && ldc_rows % 4 == 0, "hamt_mul_bcast_fwd: bad argument");
+  if (B * S == 0) return HAMT_OK;
+  hipLaunchKernelGGL(mul_bcast_fwd_kernel, dim3(nblocks((size_t)B * S * H / 4)), dim3(256), 0, as_stream(stream), B, S, H, a, c, ldc_rows, y);
+  HAMT_CHECK_LAUNCH("hamt_mul_bcast_fwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_mul_bcast_bwd(int B, int S, int H, const float* a, const float* c, int ldc_rows, const float* dy,
+                                  float* da, float* dc, void* stream) {
+  HAMT_CHECK_ARG(a && c && dy && da && dc, "hamt_mul_bcast_bwd: null pointer");
+  if (B * S == 0) return HAMT_OK;
+  hipLaunchKernelGGL(mul_bcast_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, as_stream(stream), B, S, H, a, c, ldc_rows, dy, da, dc);
+  HAMT_CHECK_LAUNCH("hamt_mul_bcast_bwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_add3(size_t n, const float* a, const float* b, const float* c, float* out, void* stream) {
+  HAMT_CHECK_ARG(a && b && out && n % 4 == 0, "hamt_add3: bad argument");
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(add3_kernel, dim3(nblocks(n / 4)), dim3(256), 0, as_stream(stream), n / 4, (const float4*)a, (const float4*)b, (const float4*)c, (float4*)out);
+  HAMT_CHECK_LAUNCH("hamt_add3");
+  return HAMT_OK;
+}
+extern "C" int hamt_dropout(size_t n, const float* x, float* y, float p, uint32_t call_id, const uint64_t* rng, void* stream) {
+  HAMT_CHECK_ARG(x && y && p >= 0.f && p < 1.f, "hamt_dropout: bad argument");
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n)), dim3(256), 0, as_stream(stream), n, x, y, p, call_id, rng);
+  HAMT_CHECK_LAUNCH("hamt_dropout");
+  return HAMT_OK;
+}
+extern "C" int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* stream) {
+  HAMT_CHECK_ARG(x && y, "hamt_cast_f32_bf16: null pointer");
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblocks(n / 8 + 1)), dim3(256), 0, as_stream(stream), n / 8, n, x, (bf16_t*)y);
+  HAMT_CHECK_LAUNCH("hamt_cast_f32_bf16");
+  return HAMT_OK;
+}
+extern "C" int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, void* stream) {
+  HAMT_CHECK_ARG(flag && x, "hamt_fill_where_zero: null pointer");
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(fill_where_zero_kernel, dim3(nblocks(n)), dim3(256), 0, as_stream(stream), n, flag, x, value);
+  HAMT_CHECK_LAUNCH("hamt_fill_where_zero");
+  return HAMT_OK;
+}
+extern "C" int hamt_act_bwd(size_t n, const float* dy, const float* h, int mode, float* dx, void* stream) {
+  HAMT_CHECK_ARG(dy && h && dx && n % 4 == 0 && (mode == 1 || mode == 2), "hamt_act_bwd: bad argument");
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(nblocks(n / 4)), dim3(256), 0, as_stream(stream), n / 4, (const float4*)dy, (const float4*)h, mode, (float4*)dx);
+  HAMT_CHECK_LAUNCH("hamt_act_bwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_rng_advance(uint64_t* rng, void* stream) {
+  HAMT_CHECK_ARG(rng, "hamt_rng_advance: null pointer");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), rng);
+  HAMT_CHECK_LAUNCH("hamt_rng_advance");
+  return HAMT_OK;
+}

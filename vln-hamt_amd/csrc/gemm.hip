@@ -1,0 +1,393 @@
+// GEMM kernels for gfx950 (MI355X).
+//
+//   C[M,N] = epilogue(alpha * A[M,K] * B[K,N])
+//
+// Two arithmetic paths behind one entry point (hamt_gemm, include/hamt.h):
+//   HAMT_PREC_BF16: v_mfma_f32_16x16x32_bf16, operands rounded to bf16 while they are staged
+//                   global -> VGPR -> LDS (fp32 or bf16 sources), fp32 accumulate, fp32 epilogue.
+//   HAMT_PREC_F32 : v_mfma_f32_16x16x4_f32 -- exact fp32 (an fmaf chain per output), used for the
+//                   <=1e-3 parity mode and for gradient checks.
+// Both handle the three operand layouts of forward / dgrad / wgrad (a_kmajor, b_kmajor) and ragged
+// M/N/K by zero-filling the staging loads.  K-strided ("k-major") operands keep their global
+// layout [k][r] in LDS and are turned into MFMA fragments with ds_read_b64_tr_b16.
+//
+// Replaces every nn.Linear forward/backward on the reference path (vilmodel.py:97-99, 140, 169,
+// 182, 263, 284, 323-325, 497-498, 549-558; pretrain_cmt.py:16-68).
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  int M, N, K, lda, ldb, ldc, ldaux;
+  int dtype_c, dtype_aux, epi;
+  float alpha;
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  void* aux;
+};
+
+// ---------------------------------------------------------------- shared epilogue (one element)
+__device__ __forceinline__ void epi_store(const GemmArgs& g, int row, int col, float acc) {
+  if (row >= g.M || col >= g.N) return;
+  float v = acc * g.alpha;
+  if (g.epi & HAMT_EPI_BIAS) v += g.bias[col];
+  size_t ia = (size_t)row * g.ldaux + col;
+  if (g.epi & HAMT_EPI_SAVE_PRE) {
+    if (g.dtype_aux == HAMT_BF16) ((bf16_t*)g.aux)[ia] = f2bf(v); else ((float*)g.aux)[ia] = v;
+  }
+  if (g.epi & HAMT_EPI_GELU) v = gelu_erf(v);
+  if (g.epi & HAMT_EPI_RELU) v = fmaxf(v, 0.0f);
+  if (g.epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
+    float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
+    v *= (g.epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h) : (h > 0.0f ? 1.0f : 0.0f);
+  }
+  size_t ic = (size_t)row * g.ldc + col;
+  if (g.dtype_c == HAMT_BF16) {
+    bf16_t* c = (bf16_t*)g.C;
+    if (g.epi & HAMT_EPI_ACCUM) v += bf2f(c[ic]);
+    c[ic] = f2bf(v);
+  } else {
+    float* c = (float*)g.C;
+    if (g.epi & HAMT_EPI_ACCUM) v += c[ic];
+    c[ic] = v;
+  }
+}
+
+// =================================================================================================
+// fp32 exact path: 64x64x16 tile, 4 waves (2x2), each wave 2x2 fragments of v_mfma_f32_16x16x4_f32.
+// LDS tiles are kept k-major ([k][r], r contiguous, row stride R+16 floats => the two 16-lane halves
+// of a 32-lane ds_read_b32 group hit disjoint banks).
+// =================================================================================================
+constexpr int F_BM = 64, F_BN = 64, F_BK = 16, F_LD = 64 + 16;
+
+template <bool KMAJOR>
+__device__ __forceinline__ void f32_stage_load(const float* __restrict__ P, int ld, int r0, int rlim, int k0,
+                                               int klim, int t, float (&v)[4]) {
+  // KMAJOR == false: global [r][k] (k contiguous): thread -> r = t%64, k = (t/64)*4 .. +3
+  // KMAJOR == true : global [k][r] (r contiguous): thread -> k = t/16, r = (t%16)*4 .. +3
+  if (!KMAJOR) {
+    int r = r0 + (t & 63), k = k0 + (t >> 6) * 4;
+    if (r < rlim && k + 4 <= klim) {
+      float4 x = *(const float4*)(P + (size_t)r * ld + k);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (r < rlim && k + j < klim) ? P[(size_t)r * ld + k + j] : 0.0f;
+    }
+  } else {
+    int k = k0 + (t >> 4), r = r0 + (t & 15) * 4;
+    if (k < klim && r + 4 <= rlim) {
+      float4 x = *(const float4*)(P + (size_t)k * ld + r);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (k < klim && r + j < rlim) ? P[(size_t)k * ld + r + j] : 0.0f;
+    }
+  }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void f32_stage_write(float* lds, int t, const float (&v)[4]) {
+  if (!KMAJOR) {
+    int r = t & 63, k = (t >> 6) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lds[(k + j) * F_LD + r] = v[j];
+  } else {
+    int k = t >> 4, r = (t & 15) * 4;
+    *(float4*)(lds + k * F_LD + r) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][F_BK * F_LD];  // [buf][A|B]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int tiles_n = (g.N + F_BN - 1) / F_BN;
+  const int m0 = (blockIdx.x / tiles_n) * F_BM, n0 = (blockIdx.x % tiles_n) * F_BN;
+  const float* A = (const float*)g.A;
+  const float* B = (const float*)g.B;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float ra[4], rb[4];
+  const int nk = (g.K + F_BK - 1) / F_BK;
+  f32_stage_load<A_KM>(A, g.lda, m0, g.M, 0, g.K, t, ra);
+  f32_stage_load<B_KM>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
+  f32_stage_write<A_KM>(lds[0][0], t, ra);
+  f32_stage_write<B_KM>(lds[0][1], t, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      f32_stage_load<A_KM>(A, g.lda, m0, g.M, (kt + 1) * F_BK, g.K, t, ra);
+      f32_stage_load<B_KM>(B, g.ldb, n0, g.N, (kt + 1) * F_BK, g.K, t, rb);
+    }
+    const float* As = lds[cur][0];
+    const float* Bs = lds[cur][1];
+#pragma unroll
+    for (int s = 0; s < F_BK / 4; ++s) {
+      const int kk = s * 4 + (lane >> 4);
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk * F_LD + wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk * F_LD + wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      f32_stage_write<A_KM>(lds[cur ^ 1][0], t, ra);
+      f32_stage_write<B_KM>(lds[cur ^ 1][1], t, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        epi_store(g, m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, n0 + wn * 32 + j * 16 + (lane & 15), acc[i][j][r]);
+}
+
+// =================================================================================================
+// bf16 MFMA path: BMxBNx32 tile (128x128 or 64x64), 4 waves (2x2), v_mfma_f32_16x16x32_bf16.
+//   k-contiguous operand  -> LDS [R][32+8] bf16, fragments by ds_read_b128 (8 consecutive k per lane)
+//   k-strided operand     -> LDS [32][R+8] bf16 (global layout kept), fragments by 2x
+//                            ds_read_b64_tr_b16 (hardware 4x16 transpose: lane (l&15) gets column
+//                            (l&15), 4 consecutive k per read)
+// Staging is global -> VGPR (issued before the MFMAs of the current tile) -> LDS (written after them),
+// two LDS buffers, one barrier per k-step.
+// =================================================================================================
+constexpr int H_BK = 32, H_PAD = 8;
+
+template <typename T> struct Ld8;  // load 8 consecutive elements as 8 bf16 packed in a uint4
+template <> struct Ld8<float> {
+  static __device__ __forceinline__ uint4 vec(const float* p) {
+    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    return make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+  static __device__ __forceinline__ bf16_t one(const float* p) { return f2bf(*p); }
+};
+template <> struct Ld8<bf16_t> {
+  static __device__ __forceinline__ uint4 vec(const bf16_t* p) { return *(const uint4*)p; }
+  static __device__ __forceinline__ bf16_t one(const bf16_t* p) { return *p; }
+};
+
+// one 8-element chunk of a tile.  row-type: chunk c -> (r = c/4, k = (c%4)*8); col-type: (k = c/(R/8), r = (c%(R/8))*8)
+template <typename T, bool KMAJOR, int R>
+__device__ __forceinline__ uint4 h_stage_load(const T* __restrict__ P, int ld, int r0, int rlim, int k0, int klim, int c) {
+  int r, k;
+  const T* p;
+  bool full;
+  if (!KMAJOR) {
+    r = r0 + (c >> 2); k = k0 + (c & 3) * 8;
+    p = P + (size_t)r * ld + k;
+    full = (r < rlim) && (k + 8 <= klim);
+  } else {
+    k = k0 + c / (R / 8); r = r0 + (c % (R / 8)) * 8;
+    p = P + (size_t)k * ld + r;
+    full = (k < klim) && (r + 8 <= rlim);
+  }
+  if (full) return Ld8<T>::vec(p);
+  unsigned short e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bool ok = KMAJOR ? (k < klim && r + j < rlim) : (r < rlim && k + j < klim);
+    e[j] = ok ? Ld8<T>::one(p + j) : (unsigned short)0;
+  }
+  return make_uint4(e[0] | (uint32_t)e[1] << 16, e[2] | (uint32_t)e[3] << 16, e[4] | (uint32_t)e[5] << 16,
+                    e[6] | (uint32_t)e[7] << 16);
+}
+template <bool KMAJOR, int R>
+__device__ __forceinline__ void h_stage_write(bf16_t* lds, int c, uint4 v) {
+  if (!KMAJOR) *(uint4*)(lds + (c >> 2) * (H_BK + H_PAD) + (c & 3) * 8) = v;
+  else *(uint4*)(lds + (c / (R / 8)) * (R + H_PAD) + (c % (R / 8)) * 8) = v;
+}
+// fragment for the 16 rows (or columns) starting at r16 of the tile
+template <bool KMAJOR, int R, bool USE_TR>
+__device__ __forceinline__ bf16x8 h_frag(const bf16_t* lds, int r16, int lane) {
+  union { uint4 u; bf16x8 v; s16x4 h[2]; unsigned short e[8]; } f;
+  if (!KMAJOR) {
+    f.u = *(const uint4*)(lds + (r16 + (lane & 15)) * (H_BK + H_PAD) + (lane >> 4) * 8);
+  } else if (USE_TR) {
+    const bf16_t* p = lds + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * (R + H_PAD) + r16 + (lane & 3) * 4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * (R + H_PAD)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.e[j] = lds[((lane >> 4) * 8 + j) * (R + H_PAD) + r16 + (lane & 15)];
+  }
+  return f.v;
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM, typename TA, typename TB, bool USE_TR>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  constexpr int A_SZ = A_KM ? H_BK * (BM + H_PAD) : BM * (H_BK + H_PAD);
+  constexpr int B_SZ = B_KM ? H_BK * (BN + H_PAD) : BN * (H_BK + H_PAD);
+  constexpr int CA = BM * H_BK / 8 / 256, CB = BN * H_BK / 8 / 256;  // chunks per thread
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (A_SZ + B_SZ)];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const TA* A = (const TA*)g.A;
+  const TB* B = (const TB*)g.B;
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[CA], rb[CB];
+  const int nk = (g.K + H_BK - 1) / H_BK;
+#pragma unroll
+  for (int c = 0; c < CA; ++c) ra[c] = h_stage_load<TA, A_KM, BM>(A, g.lda, m0, g.M, 0, g.K, t + c * 256);
+#pragma unroll
+  for (int c = 0; c < CB; ++c) rb[c] = h_stage_load<TB, B_KM, BN>(B, g.ldb, n0, g.N, 0, g.K, t + c * 256);
+#pragma unroll
+  for (int c = 0; c < CA; ++c) h_stage_write<A_KM, BM>(lds, t + c * 256, ra[c]);
+#pragma unroll
+  for (int c = 0; c < CB; ++c) h_stage_write<B_KM, BN>(lds + A_SZ, t + c * 256, rb[c]);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bf16_t* As = lds + (kt & 1) * (A_SZ + B_SZ);
+    const bf16_t* Bs = As + A_SZ;
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int c = 0; c < CA; ++c) ra[c] = h_stage_load<TA, A_KM, BM>(A, g.lda, m0, g.M, (kt + 1) * H_BK, g.K, t + c * 256);
+#pragma unroll
+      for (int c = 0; c < CB; ++c) rb[c] = h_stage_load<TB, B_KM, BN>(B, g.ldb, n0, g.N, (kt + 1) * H_BK, g.K, t + c * 256);
+    }
+    bf16x8 af[FM], bf[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = h_frag<A_KM, BM, USE_TR>(As, wm * WM + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[j] = h_frag<B_KM, BN, USE_TR>(Bs, wn * WN + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) {
+      bf16_t* An = lds + ((kt + 1) & 1) * (A_SZ + B_SZ);
+#pragma unroll
+      for (int c = 0; c < CA; ++c) h_stage_write<A_KM, BM>(An, t + c * 256, ra[c]);
+#pragma unroll
+      for (int c = 0; c < CB; ++c) h_stage_write<B_KM, BN>(An + A_SZ, t + c * 256, rb[c]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        epi_store(g, m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r, n0 + wn * WN + j * 16 + (lane & 15), acc[i][j][r]);
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM, typename TA, typename TB>
+void launch_bf16(const GemmArgs& g, bool use_tr, hipStream_t s) {
+  int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (use_tr) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, A_KM, B_KM, TA, TB, true>), dim3(tiles), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, A_KM, B_KM, TA, TB, false>), dim3(tiles), dim3(256), 0, s, g);
+}
+template <bool A_KM, bool B_KM, typename TA, typename TB>
+void pick_tile_bf16(const GemmArgs& g, bool use_tr, int force_tile, hipStream_t s) {
+  long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  bool big = force_tile ? (force_tile == 128) : (t128 >= 192);
+  if (big) launch_bf16<128, 128, A_KM, B_KM, TA, TB>(g, use_tr, s);
+  else launch_bf16<64, 64, A_KM, B_KM, TA, TB>(g, use_tr, s);
+}
+template <bool A_KM, bool B_KM>
+void pick_types_bf16(const GemmArgs& g, int da, int db, bool use_tr, int force_tile, hipStream_t s) {
+  if (da == HAMT_F32 && db == HAMT_F32) pick_tile_bf16<A_KM, B_KM, float, float>(g, use_tr, force_tile, s);
+  else if (da == HAMT_F32) pick_tile_bf16<A_KM, B_KM, float, bf16_t>(g, use_tr, force_tile, s);
+  else if (db == HAMT_F32) pick_tile_bf16<A_KM, B_KM, bf16_t, float>(g, use_tr, force_tile, s);
+  else pick_tile_bf16<A_KM, B_KM, bf16_t, bf16_t>(g, use_tr, force_tile, s);
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const T* __restrict__ x, int ldx,
+                                                             float* __restrict__ ws, int rows_per_chunk) {
+  // block = 64 columns x 4 row-phases; grid = (ceil(N/64), chunks)
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + ph; r < r1; r += 4) {
+      if constexpr (sizeof(T) == 2) s += bf2f(x[(size_t)r * ldx + col]); else s += x[(size_t)r * ldx + col];
+    }
+  __shared__ float red[4][64];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && col < N) ws[(size_t)blockIdx.y * N + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void reduce_partials_kernel(int R, int N, const float* __restrict__ ws, float* __restrict__ out, int accumulate) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += ws[(size_t)r * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+}  // namespace
+
+void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, R, N, ws, out, accumulate);
+}
+
+extern "C" int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
+                         void* stream) {
+  HAMT_CHECK_ARG(d && A && B && C, "hamt_gemm: null pointer");
+  HAMT_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "hamt_gemm: negative size");
+  if (d->M == 0 || d->N == 0) return HAMT_OK;
+  const int sa = d->dtype_a == HAMT_BF16 ? 2 : 4, sb = d->dtype_b == HAMT_BF16 ? 2 : 4;
+  HAMT_CHECK_ARG((d->lda * sa) % 16 == 0 && (d->ldb * sb) % 16 == 0, "hamt_gemm: lda/ldb rows must be 16-byte aligned (lda=%d ldb=%d)", d->lda, d->ldb);
+  HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
+  HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
+  HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) || aux, "hamt_gemm: epilogue needs aux");
+  GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
+  hipStream_t s = as_stream(stream);
+  if (d->prec == HAMT_PREC_F32) {
+    HAMT_CHECK_ARG(d->dtype_a == HAMT_F32 && d->dtype_b == HAMT_F32, "hamt_gemm: PREC_F32 needs fp32 operands");
+    int tiles = ((d->M + F_BM - 1) / F_BM) * ((d->N + F_BN - 1) / F_BN);
+    if (!d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(tiles), dim3(256), 0, s, g);
+    else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(tiles), dim3(256), 0, s, g);
+    else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(tiles), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(tiles), dim3(256), 0, s, g);
+  } else {
+    static const bool use_tr = getenv("HAMT_NO_TR") == nullptr;
+    static const int force_tile = getenv("HAMT_GEMM_TILE") ? atoi(getenv("HAMT_GEMM_TILE")) : 0;
+    if (!d->a_kmajor && !d->b_kmajor) pick_types_bf16<false, false>(g, d->dtype_a, d->dtype_b, use_tr, force_tile, s);
+    else if (!d->a_kmajor && d->b_kmajor) pick_types_bf16<false, true>(g, d->dtype_a, d->dtype_b, use_tr, force_tile, s);
+    else if (d->a_kmajor && d->b_kmajor) pick_types_bf16<true, true>(g, d->dtype_a, d->dtype_b, use_tr, force_tile, s);
+    else { hamt_set_error("hamt_gemm: a_kmajor=1,b_kmajor=0 is not used by the path"); return HAMT_ERR_UNSUPPORTED; }
+  }
+  HAMT_CHECK_LAUNCH("hamt_gemm");
+  return HAMT_OK;
+}
+
+extern "C" int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate, float* ws,
+                           void* stream) {
+  HAMT_CHECK_ARG(x && out && ws && M >= 0 && N > 0, "hamt_colsum: bad argument");
+  hipStream_t s = as_stream(stream);
+  int chunks = M >= 64 * 64 ? 64 : (M + 63) / 64;
+  if (chunks < 1) chunks = 1;
+  int rpc = (M + chunks - 1) / chunks;
+  if (rpc < 1) rpc = 1;
+  dim3 grid((N + 63) / 64, chunks);
+  if (dtype_x == HAMT_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, M, N, (const bf16_t*)x, ldx, ws, rpc);
+  else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, M, N, (const float*)x, ldx, ws, rpc);
+  hamt_reduce_partials(chunks, N, ws, out, accumulate, s);
+  HAMT_CHECK_LAUNCH("hamt_colsum");
+  return HAMT_OK;
+}

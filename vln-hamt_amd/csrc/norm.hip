@@ -1,0 +1,206 @@
+// LayerNorm family for gfx950:  y = dropout_post( LN( dropout_pre(x) + residual ) ), fp32 statistics.
+// One 64-lane wave per row (H <= 1024 kept in registers as float4s), 4 rows per 256-thread block,
+// wave-shuffle reductions, 16-byte coalesced loads/stores.  HBM/L2-bound: 3 reads + 2 writes per element.
+//
+// Replaces BertSelfOutput/BertOutput's dropout+add+LayerNorm (vilmodel.py:139-143, 181-185), the
+// LayerNorm+dropout tails of BertEmbeddings / ImageEmbeddings / HistoryEmbeddings (vilmodel.py:67-68,
+// 503-504, 545-546, 570-571) and the LN(+Dropout) inside the prediction heads (pretrain_cmt.py:18-19).
+#include "common.h"
+
+void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s);
+
+namespace {
+
+constexpr uint32_t POST_SALT = 0x5bd1e995u;
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float* __restrict__ x,
+                                                     const float* __restrict__ res, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ z,
+                                                     float* __restrict__ y, bf16_t* __restrict__ y16,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     const uint64_t* __restrict__ rng) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= d.M) return;
+  const int H = d.H;
+  const RngKey kpre = rng_key(rng, d.call_id), kpost = rng_key(rng, d.call_id ^ POST_SALT);
+  const float ik_pre = d.p_pre > 0.f ? 1.0f / (1.0f - d.p_pre) : 1.0f, ik_post = d.p_post > 0.f ? 1.0f / (1.0f - d.p_post) : 1.0f;
+  float4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const size_t o = (size_t)row * H + c;
+      float4 a = *(const float4*)(x + o);
+      if (d.p_pre > 0.f) {
+        a.x *= drop_scale(kpre, o, d.p_pre, ik_pre); a.y *= drop_scale(kpre, o + 1, d.p_pre, ik_pre);
+        a.z *= drop_scale(kpre, o + 2, d.p_pre, ik_pre); a.w *= drop_scale(kpre, o + 3, d.p_pre, ik_pre);
+      }
+      if (res) { float4 r = *(const float4*)(res + o); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+      v[i] = a;
+      sum += a.x + a.y + a.z + a.w;
+    } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+      sq += a * a + b * b + cc * cc + e * e;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + d.eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const size_t o = (size_t)row * H + c;
+      if (z) *(float4*)(z + o) = v[i];
+      const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+      float4 r;
+      r.x = (v[i].x - mean) * rstd * g.x + b.x; r.y = (v[i].y - mean) * rstd * g.y + b.y;
+      r.z = (v[i].z - mean) * rstd * g.z + b.z; r.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (d.p_post > 0.f) {
+        r.x *= drop_scale(kpost, o, d.p_post, ik_post); r.y *= drop_scale(kpost, o + 1, d.p_post, ik_post);
+        r.z *= drop_scale(kpost, o + 2, d.p_post, ik_post); r.w *= drop_scale(kpost, o + 3, d.p_post, ik_post);
+      }
+      *(float4*)(y + o) = r;
+      if (y16) *(uint2*)(y16 + o) = make_uint2(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w));
+    }
+  }
+  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float* __restrict__ dy,
+                                                     const float* __restrict__ z, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, const float* __restrict__ gamma,
+                                                     float* __restrict__ dz, float* __restrict__ dx,
+                                                     float* __restrict__ ws, const uint64_t* __restrict__ rng) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int H = d.H;
+  const RngKey kpre = rng_key(rng, d.call_id), kpost = rng_key(rng, d.call_id ^ POST_SALT);
+  const float ik_pre = d.p_pre > 0.f ? 1.0f / (1.0f - d.p_pre) : 1.0f, ik_post = d.p_post > 0.f ? 1.0f / (1.0f - d.p_post) : 1.0f;
+  float4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    gam[i] = c < H ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x * 4 + w; row < d.M; row += gridDim.x * 4) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        const size_t o = (size_t)row * H + c;
+        float4 a = *(const float4*)(dy + o);
+        if (d.p_post > 0.f) {
+          a.x *= drop_scale(kpost, o, d.p_post, ik_post); a.y *= drop_scale(kpost, o + 1, d.p_post, ik_post);
+          a.z *= drop_scale(kpost, o + 2, d.p_post, ik_post); a.w *= drop_scale(kpost, o + 3, d.p_post, ik_post);
+        }
+        const float4 zz = *(const float4*)(z + o);
+        float4 h;
+        h.x = (zz.x - mean) * rstd; h.y = (zz.y - mean) * rstd; h.z = (zz.z - mean) * rstd; h.w = (zz.w - mean) * rstd;
+        dg[i].x += a.x * h.x; dg[i].y += a.y * h.y; dg[i].z += a.z * h.z; dg[i].w += a.w * h.w;
+        db[i].x += a.x; db[i].y += a.y; db[i].z += a.z; db[i].w += a.w;
+        a.x *= gam[i].x; a.y *= gam[i].y; a.z *= gam[i].z; a.w *= gam[i].w;
+        s1 += a.x + a.y + a.z + a.w;
+        s2 += a.x * h.x + a.y * h.y + a.z * h.z + a.w * h.w;
+        g[i] = a; xh[i] = h;
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        const size_t o = (size_t)row * H + c;
+        float4 r;
+        r.x = rstd * (g[i].x - c1 - xh[i].x * c2); r.y = rstd * (g[i].y - c1 - xh[i].y * c2);
+        r.z = rstd * (g[i].z - c1 - xh[i].z * c2); r.w = rstd * (g[i].w - c1 - xh[i].w * c2);
+        *(float4*)(dz + o) = r;
+        if (dx) {
+          r.x *= drop_scale(kpre, o, d.p_pre, ik_pre); r.y *= drop_scale(kpre, o + 1, d.p_pre, ik_pre);
+          r.z *= drop_scale(kpre, o + 2, d.p_pre, ik_pre); r.w *= drop_scale(kpre, o + 3, d.p_pre, ik_pre);
+          *(float4*)(dx + o) = r;
+        }
+      }
+    }
+  }
+  // block partials: ws[block][0][H] = dgamma, ws[block][1][H] = dbeta
+  __shared__ float4 red[4][2][NV * 64];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { red[w][0][i * 64 + lane] = dg[i]; red[w][1][i * 64 + lane] = db[i]; }
+  __syncthreads();
+  if (w < 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        float4 a = red[0][w][i * 64 + lane], b = red[1][w][i * 64 + lane], cc = red[2][w][i * 64 + lane], e = red[3][w][i * 64 + lane];
+        *(float4*)(ws + ((size_t)blockIdx.x * 2 + w) * H + c) = make_float4(a.x + b.x + cc.x + e.x, a.y + b.y + cc.y + e.y, a.z + b.z + cc.z + e.z, a.w + b.w + cc.w + e.w);
+      }
+    }
+  }
+}
+
+// ws[block][2][H] -> dgamma[H], dbeta[H] (accumulate)
+__global__ void ln_bwd_reduce_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * H) return;
+  const int which = c / H, col = c % H;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += ws[((size_t)b * 2 + which) * H + col];
+  float* o = which ? dbeta : dgamma;
+  if (o) o[col] += s;
+}
+
+}  // namespace
+
+extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
+                           const float* beta, float* z, float* y, void* y16, float* mean, float* rstd,
+                           const uint64_t* rng, void* stream) {
+  HAMT_CHECK_ARG(d && x && gamma && beta && y && mean && rstd, "hamt_ln_fwd: null pointer");
+  HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_fwd: H=%d unsupported (need H%%4==0, H<=1024)", d->H);
+  HAMT_CHECK_ARG(d->p_pre >= 0.f && d->p_pre < 1.f && d->p_post >= 0.f && d->p_post < 1.f, "hamt_ln_fwd: bad dropout p");
+  if (d->M == 0) return HAMT_OK;
+  const int nv = (d->H + 255) / 256;
+  dim3 grid((d->M + 3) / 4), block(256);
+  hipStream_t s = as_stream(stream);
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV>), grid, block, 0, s, *d, x, residual, gamma, beta, z, y, (bf16_t*)y16, mean, rstd, rng)
+  switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+  HAMT_CHECK_LAUNCH("hamt_ln_fwd");
+  return HAMT_OK;
+}
+
+extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+                           const float* rstd, const float* gamma, float* dz, float* dx, float* dgamma,
+                           float* dbeta, float* ws, const uint64_t* rng, void* stream) {
+  HAMT_CHECK_ARG(d && dy && z && mean && rstd && gamma && dz && ws, "hamt_ln_bwd: null pointer");
+  HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_bwd: H=%d unsupported", d->H);
+  HAMT_CHECK_ARG(!(d->p_pre > 0.f) || dx, "hamt_ln_bwd: p_pre > 0 needs dx");
+  if (d->M == 0) return HAMT_OK;
+  const int nv = (d->H + 255) / 256;
+  int nb = (d->M + 3) / 4;
+  if (nb > 256) nb = 256;
+  hipStream_t s = as_stream(stream);
+  float* dxx = d->p_pre > 0.f ? dx : nullptr;
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, ws, rng)
+  switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+  if (dgamma || dbeta)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d->H + 255) / 256), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta);
+  HAMT_CHECK_LAUNCH("hamt_ln_bwd");
+  return HAMT_OK;
+}

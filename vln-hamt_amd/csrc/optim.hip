@@ -1,0 +1,107 @@
+// Optimiser-side kernels over flat fp32 arenas (pure HBM streaming, 16-byte accesses):
+//   hamt_sumsq       global L2 norm of the gradient arena (torch clip_grad_norm_, main_r2r.py:271-273)
+//   hamt_adamw_flat  the reference's HF AdamW (optim/adamw.py:85-110) fused with the clip scaling, the
+//                    bf16 shadow refresh used by the MFMA GEMMs, and optimizer.zero_grad (main_r2r.py:280)
+// Traffic per parameter: read p,g,m,v (16 B) + write p,m,v (12 B) + g zero (4 B) + bf16 shadow (2 B) = 34 B.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(size_t n, const float* __restrict__ g, float* __restrict__ ws) {
+  float s = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = ((const float4*)g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(int nb, const float* __restrict__ ws, float* __restrict__ out, int accumulate) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += ws[i];
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { const float t = (red[0] + red[1]) + (red[2] + red[3]); *out = accumulate ? *out + t : t; }
+}
+__device__ __forceinline__ float clip_coef(const float* gnorm_sq, float max_norm) {
+  if (!gnorm_sq || max_norm <= 0.f) return 1.0f;
+  return fminf(1.0f, max_norm / (sqrtf(*gnorm_sq) + 1e-6f));
+}
+__device__ __forceinline__ void adamw_one(float& p, float& g, float& m, float& v, float coef, float lr, float step, float b1,
+                                          float b2, float eps, float wd) {
+  const float gg = g * coef;
+  m = m * b1 + (1.0f - b1) * gg;                    // exp_avg.mul_(b1).add_(grad, alpha=1-b1)           adamw.py:89
+  v = v * b2 + (1.0f - b2) * gg * gg;               // exp_avg_sq.mul_(b2).addcmul_(grad, grad, 1-b2)    adamw.py:90
+  p = p - step * (m / (sqrtf(v) + eps));            // denom = sqrt(v)+eps; p.addcdiv_(m, denom, -step)  adamw.py:91-99
+  if (wd > 0.f) p = p - lr * wd * p;                // decoupled decay AFTER the update                   adamw.py:109-110
+}
+__global__ __launch_bounds__(256) void adamw_kernel(size_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16, const float* __restrict__ hyper,
+                                                    const float* __restrict__ gnorm_sq, float b1, float b2, float eps, float wd,
+                                                    int zero_grad) {
+  const float lr = hyper[0], step = hyper[1], coef = clip_coef(gnorm_sq, hyper[2]);
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 P = ((float4*)p)[i], G = ((float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+    adamw_one(P.x, G.x, M.x, V.x, coef, lr, step, b1, b2, eps, wd);
+    adamw_one(P.y, G.y, M.y, V.y, coef, lr, step, b1, b2, eps, wd);
+    adamw_one(P.z, G.z, M.z, V.z, coef, lr, step, b1, b2, eps, wd);
+    adamw_one(P.w, G.w, M.w, V.w, coef, lr, step, b1, b2, eps, wd);
+    ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p16) ((uint2*)p16)[i] = make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    float P = p[i], G = g[i], M = m[i], V = v[i];
+    adamw_one(P, G, M, V, coef, lr, step, b1, b2, eps, wd);
+    p[i] = P; m[i] = M; v[i] = V;
+    if (zero_grad) g[i] = 0.f;
+    if (p16) p16[i] = f2bf(P);
+  }
+}
+__global__ void clip_scale_kernel(size_t n, float* __restrict__ g, const float* __restrict__ gnorm_sq, float max_norm) {
+  const float coef = clip_coef(gnorm_sq, max_norm);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
+}  // namespace
+
+extern "C" int hamt_sumsq(size_t n, const float* g, float* out, int accumulate, float* ws, void* stream) {
+  HAMT_CHECK_ARG(g && out && ws && ((uintptr_t)g % 16) == 0, "hamt_sumsq: bad argument (ws needs 1024 floats, g 16-byte aligned)");
+  size_t b = (n / 4 + 255) / 256;
+  int nb = (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
+  HAMT_CHECK_LAUNCH("hamt_sumsq");
+  return HAMT_OK;
+}
+extern "C" int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v, void* p16, const float* hyper,
+                               const float* gnorm_sq, float beta1, float beta2, float eps, float weight_decay, int zero_grad,
+                               void* stream) {
+  HAMT_CHECK_ARG(p && g && m && v && hyper, "hamt_adamw_flat: null pointer");
+  HAMT_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                 ((uintptr_t)p16 % 8) == 0, "hamt_adamw_flat: arenas must be 16-byte aligned");
+  if (n == 0) return HAMT_OK;
+  size_t b = (n / 4 + 255) / 256;
+  int nb = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+  hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v, (bf16_t*)p16, hyper, gnorm_sq, beta1, beta2, eps, weight_decay, zero_grad);
+  HAMT_CHECK_LAUNCH("hamt_adamw_flat");
+  return HAMT_OK;
+}
+extern "C" int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream) {
+  HAMT_CHECK_ARG(g && gnorm_sq, "hamt_clip_scale: null pointer");
+  if (n == 0) return HAMT_OK;
+  size_t b = (n + 255) / 256;
+  hipLaunchKernelGGL(clip_scale_kernel, dim3((int)(b > 4096 ? 4096 : b)), dim3(256), 0, as_stream(stream), n, g, gnorm_sq, max_norm);
+  HAMT_CHECK_LAUNCH("hamt_clip_scale");
+  return HAMT_OK;
+}

@@ -1,0 +1,200 @@
+"""MI355X-native mirror of ``pretrain_src/model/pretrain_cmt.py``: the six proxy-task heads and their
+losses on top of the HIP trunk.  Same class names / parameter names / ``forward(batch, task, compute_loss)``
+contract (losses with reduction='none'; MRC and ITM return 2-tuples when compute_loss is False).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..modeling import precision_of
+from .vilmodel import BertLayerNorm, BertOnlyMLMHead, BertPreTrainedModel, NavPreTrainedModel
+
+
+class _MlpHead(nn.Module):
+    """Linear -> ReLU -> LayerNorm(1e-12) -> [Dropout] -> Linear, kept as nn.Sequential `net` so the
+    parameter names are net.0 / net.2 / net.4 (or net.3) as in pretrain_cmt.py:13-71."""
+
+    def __init__(self, in_size, hidden_size, out_size, dropout_rate=None, prec="bf16"):
+        super().__init__()
+        mods = [nn.Linear(in_size, hidden_size), nn.ReLU(), BertLayerNorm(hidden_size, eps=1e-12)]
+        if dropout_rate is not None:
+            mods.append(nn.Dropout(dropout_rate))
+        mods.append(nn.Linear(hidden_size, out_size))
+        self.net = nn.Sequential(*mods)
+        self.prec = prec
+
+    def forward(self, x):
+        lin0, ln, last = self.net[0], self.net[2], self.net[-1]
+        p = float(self.net[3].p) if (len(self.net) == 5 and self.training) else 0.0
+        h = ops.linear(x, lin0.weight, lin0.bias, ops.ACT_RELU, self.prec)
+        h = ops.layer_norm(h, None, ln, p_post=p)
+        # the 1..3 / 1000-wide output projections are tiny: keep them exact
+        return ops.linear(h, last.weight, last.bias, ops.ACT_NONE, self.prec)
+
+
+class NextActionPrediction(_MlpHead):          # pretrain_cmt.py:13-23
+    def __init__(self, hidden_size, dropout_rate, prec="bf16"):
+        super().__init__(hidden_size, hidden_size, 1, dropout_rate, prec)
+
+
+class NextActionRegression(_MlpHead):          # pretrain_cmt.py:25-35
+    def __init__(self, hidden_size, dropout_rate, prec="bf16"):
+        super().__init__(hidden_size, hidden_size, 3, dropout_rate, prec)
+
+
+class SpatialRelRegression(_MlpHead):          # pretrain_cmt.py:37-47
+    def __init__(self, hidden_size, dropout_rate, prec="bf16"):
+        super().__init__(hidden_size * 2, hidden_size, 2, dropout_rate, prec)
+
+
+class RegionClassification(_MlpHead):          # pretrain_cmt.py:49-60  (MRC-kl)
+    def __init__(self, hidden_size, label_dim, prec="bf16"):
+        super().__init__(hidden_size, hidden_size, label_dim, None, prec)
+
+
+class ItmPrediction(_MlpHead):                 # pretrain_cmt.py:62-71
+    def __init__(self, hidden_size, prec="bf16"):
+        super().__init__(hidden_size, hidden_size, 1, None, prec)
+
+
+class MultiStepNavCMTPreTraining(BertPreTrainedModel):
+    """pretrain_cmt.py:73-262."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.config = config
+        self.bert = NavPreTrainedModel(config)
+        prec = precision_of(config)
+        H = config.hidden_size
+        if 'mlm' in config.pretrain_tasks:
+            self.mlm_head = BertOnlyMLMHead(config)
+        if 'sap' in config.pretrain_tasks:
+            self.next_action = NextActionPrediction(H, config.pred_head_dropout_prob, prec)
+        if 'sar' in config.pretrain_tasks:
+            self.regress_action = NextActionRegression(H, config.pred_head_dropout_prob, prec)
+        if 'sprel' in config.pretrain_tasks:
+            self.sprel_head = SpatialRelRegression(H, config.pred_head_dropout_prob, prec)
+        if 'mrc' in config.pretrain_tasks:
+            self.image_classifier = RegionClassification(H, config.image_prob_size, prec)
+        if 'itm' in config.pretrain_tasks:
+            self.itm_head = ItmPrediction(H, prec)
+        self.init_weights()
+        self.tie_weights()
+
+    def tie_weights(self):
+        if 'mlm' in self.config.pretrain_tasks:
+            self._tie_or_clone_weights(self.mlm_head.predictions.decoder, self.bert.embeddings.word_embeddings)
+
+    def forward(self, batch, task, compute_loss=True):
+        batch = defaultdict(lambda: None, batch)
+        hist = (batch['txt_ids'], batch['txt_masks'], batch['hist_img_fts'], batch['hist_ang_fts'],
+                batch['hist_pano_img_fts'], batch['hist_pano_ang_fts'], batch['hist_masks'])
+        ob = (batch['ob_img_fts'], batch['ob_ang_fts'], batch['ob_nav_types'], batch['ob_masks'])
+        if task.startswith('mlm'):
+            return self.forward_mlm(*hist, batch['txt_labels'], compute_loss)
+        elif task.startswith('sap'):
+            return self.forward_sap(*hist, *ob, batch['ob_action_viewindex'], compute_loss)
+        elif task.startswith('sar'):
+            return self.forward_sar(*hist, *ob, batch['ob_action_angles'], batch['ob_progress'], compute_loss)
+        elif task.startswith('sprel'):
+            return self.forward_sprel(*hist, *ob, batch['sp_anchor_idxs'], batch['sp_targets'], compute_loss)
+        elif task.startswith('mrc'):
+            return self.forward_mrc(*hist, batch['hist_mrc_masks'], batch['hist_img_probs'], compute_loss)
+        elif task.startswith('itm'):
+            return self.forward_itm(*hist, 4, compute_loss, neg_idxs=batch['itm_neg_idxs'],
+                                    shuffled_pos_ids=batch['itm_shuffled_pos_ids'])
+        else:
+            raise ValueError('invalid task')
+
+    # ---- A15
+    def forward_mlm(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
+                    hist_masks, txt_labels, compute_loss):
+        txt_embeds, _, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
+                                     hist_pano_ang_fts, hist_masks, None, None, None, None)
+        sel = txt_labels != -1
+        masked_output = self._compute_masked_hidden(txt_embeds, sel)
+        prediction_scores = self.mlm_head(masked_output)
+        if compute_loss:
+            return ops.cross_entropy(prediction_scores, txt_labels[sel])
+        return prediction_scores
+
+    def _compute_masked_hidden(self, hidden, mask):
+        """rows of `hidden` where `mask` is set, in row-major order (pretrain_cmt.py:161-165): the index list
+        is integer work done once, the row gather (and its scatter in backward) is a HIP kernel."""
+        idx = mask.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        return ops.gather_rows(hidden.reshape(-1, hidden.size(-1)), idx)
+
+    # ---- A16
+    def forward_sap(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
+                    hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, act_labels, compute_loss):
+        txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
+                                                       hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
+        fused = ops.mul_bcast(ob_embeds, txt_embeds[:, 0])
+        prediction_scores = self.next_action(fused).squeeze(-1)
+        prediction_scores = ops.fill_where_zero(prediction_scores, ob_nav_types, -float('inf'))
+        if compute_loss:
+            return ops.cross_entropy(prediction_scores, act_labels)
+        return prediction_scores
+
+    # ---- A17
+    def forward_sar(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
+                    hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, ob_act_angles, ob_progress, compute_loss):
+        txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
+                                                       hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
+        B, L, H = txt_embeds.shape
+        cls_rows = torch.arange(B, device=txt_embeds.device) * L
+        prediction_scores = self.regress_action(ops.gather_rows(txt_embeds.reshape(B * L, H), cls_rows))
+        if compute_loss:
+            act_targets = torch.cat([ob_act_angles, ob_progress.unsqueeze(1)], dim=1)
+            return ops.mse_loss(prediction_scores, act_targets)
+        return prediction_scores
+
+    # ---- A18
+    def forward_sprel(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
+                      hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, sp_anchor_idxs, sp_targets, compute_loss):
+        txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
+                                                       hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
+        B, S, H = ob_embeds.shape                                  # S = 37; the reference hard-codes 36 views (:211-212)
+        flat = ob_embeds.reshape(B * S, H)
+        base = torch.arange(B, device=flat.device) * S
+        anchor = ops.gather_rows(flat, (base + sp_anchor_idxs).repeat_interleave(36))
+        rest = ops.gather_rows(flat, (base[:, None] + torch.arange(S - 1, device=flat.device)[None]).reshape(-1))
+        cat_ob_embeds = torch.cat([anchor, rest], -1).view(B, S - 1, 2 * H)
+        prediction_scores = self.sprel_head(cat_ob_embeds)
+        if compute_loss:
+            return ops.mse_loss(prediction_scores, sp_targets)
+        return prediction_scores
+
+    # ---- A19
+    def forward_mrc(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
+                    hist_masks, hist_mrc_masks, hist_img_probs, compute_loss=True):
+        txt_embeds, hist_embeds, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
+                                               hist_pano_ang_fts, hist_masks, None, None, None, None)
+        B, T1, H = hist_embeds.shape
+        bt = hist_mrc_masks.nonzero(as_tuple=False)                 # (n, 2) row-major (b, t)
+        rows = bt[:, 0] * T1 + bt[:, 1] + 1                         # +1: drop the global cls slot (:232)
+        masked_output = ops.gather_rows(hist_embeds.reshape(B * T1, H), rows)
+        prediction_soft_labels = self.image_classifier(masked_output)
+        hist_mrc_targets = hist_img_probs[hist_mrc_masks]
+        if compute_loss:
+            return ops.kl_div_logsoftmax(prediction_soft_labels, hist_mrc_targets)
+        return prediction_soft_labels, hist_mrc_targets
+
+    # ---- A20
+    def forward_itm(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
+                    hist_masks, num_neg_trajs, compute_loss, neg_idxs=None, shuffled_pos_ids=None):
+        fused_embeds = self.bert.forward_itm(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
+                                             hist_pano_ang_fts, hist_masks, num_neg_trajs=num_neg_trajs,
+                                             neg_idxs=neg_idxs, shuffled_pos_ids=shuffled_pos_ids)
+        prediction_scores = self.itm_head(fused_embeds).squeeze(2)
+        itm_targets = torch.zeros(fused_embeds.size(0), dtype=torch.long, device=fused_embeds.device)
+        if compute_loss:
+            return ops.cross_entropy(prediction_scores, itm_targets)
+        return prediction_scores, itm_targets

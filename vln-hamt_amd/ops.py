@@ -1,0 +1,658 @@
+"""autograd Functions over the C-ABI of libhamt_hip.so.
+
+Every Function's forward and backward are HIP kernel launches on torch's *current* stream (raw
+pointers + hipStream_t through ctypes); torch only owns the memory and the autograd graph.
+There is no CPU or eager-PyTorch fallback: tensors must live on an AMD GPU and the library must load.
+
+Precision: ``prec`` is ``"bf16"`` (bf16 MFMA operands, fp32 accumulate/epilogue; activations stay
+fp32 in HBM and are rounded while staged) or ``"fp32"`` (exact fp32 MFMA).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+# ------------------------------------------------------------------------------------------ plumbing
+_rng_state = {}
+_call_counter = [0]
+
+
+def rng_state(device) -> torch.Tensor:
+    """Per-device dropout RNG words [seed, epoch] (uint64 stored as int64)."""
+    key = torch.device(device).index or 0
+    t = _rng_state.get(key)
+    if t is None:
+        t = torch.tensor([0x243F6A8885A308D3 & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        _rng_state[key] = t
+    return t
+
+
+def manual_seed(seed: int, device="cuda"):
+    rng_state(device).copy_(torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+    _call_counter[0] = 0
+
+
+def advance_rng_epoch(device="cuda"):
+    """New dropout epoch (one kernel; graph-capturable).  Call once per optimisation step."""
+    st = rng_state(device)
+    L.check(L.load().hamt_rng_advance(_p(st), _stream()), "hamt_rng_advance")
+
+
+def next_call_id() -> int:
+    _call_counter[0] = (_call_counter[0] + 1) & 0xFFFFFFFF
+    return _call_counter[0]
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise L.HamtError(f"{name}: tensor is on {t.device}; the HAMT kernels run on the GPU only (no CPU fallback)")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.HAMT_F32
+    if t.dtype == torch.bfloat16:
+        return L.HAMT_BF16
+    raise L.HamtError(f"unsupported dtype {t.dtype}")
+
+
+def _prec(prec: str) -> int:
+    return L.PREC_F32 if prec == "fp32" else L.PREC_BF16
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Leading dimension (elements) of a 2-D row-major view whose last dim is contiguous."""
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _pad_cols(n: int, elem_size: int) -> int:
+    q = 16 // elem_size
+    return (n + q - 1) // q * q
+
+
+def empty_rows(M: int, N: int, device, dtype=torch.float32) -> torch.Tensor:
+    """[M,N] view whose rows start 16-byte aligned (row stride padded), e.g. the 30522-wide MLM logits."""
+    return torch.empty(M, _pad_cols(N, torch.empty((), dtype=dtype).element_size()), dtype=dtype, device=device)[:, :N]
+
+
+def _operand(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` if it satisfies the GEMM operand contract (unit inner stride, 16-byte aligned rows and
+    base); otherwise a padded copy (only skinny / odd-width tensors such as [M,1] head gradients)."""
+    es = t.element_size()
+    ok = (t.stride(1) == 1 or t.shape[1] == 1) and t.data_ptr() % 16 == 0 and (t.shape[0] <= 1 or (t.stride(0) * es) % 16 == 0)
+    if ok and not (t.shape[0] <= 1 and (t.shape[1] * es) % 16):
+        return t
+    o = empty_rows(t.shape[0], t.shape[1], t.device, t.dtype)
+    o.copy_(t)
+    return o
+
+
+# ------------------------------------------------------------------------------------------ raw GEMM
+def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, aux=None, prec="bf16", alpha=1.0):
+    """out[M,N] = epi(alpha * op(a) @ op(b)); 2-D views with unit inner stride (strided rows allowed)."""
+    _chk(a, "gemm")
+    a, b = _operand(a), _operand(b)
+    M, N = out.shape
+    K = a.shape[0] if a_kmajor else a.shape[1]
+    assert (a.shape == (K, M)) if a_kmajor else (a.shape == (M, K)), (a.shape, out.shape)
+    assert (b.shape == (K, N)) if b_kmajor else (b.shape == (N, K)), (b.shape, out.shape, K)
+    if _prec(prec) == L.PREC_F32:
+        assert a.dtype == torch.float32 and b.dtype == torch.float32
+    d = L.GemmDesc(M, N, K, _ld(a), _ld(b), _ld(out), _ld(aux) if aux is not None else 0, int(a_kmajor), int(b_kmajor),
+                   _dt(a), _dt(b), _dt(out), _dt(aux) if aux is not None else 0, _prec(prec),
+                   epilogue | (L.EPI_BIAS if bias is not None else 0), alpha)
+    L.check(L.load().hamt_gemm(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux), _stream()), "hamt_gemm")
+    return out
+
+
+def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False) -> torch.Tensor:
+    M, N = x2d.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(64 * N, dtype=torch.float32, device=x2d.device)
+    L.check(L.load().hamt_colsum(M, N, _p(x2d), _ld(x2d), _dt(x2d), _p(out), int(accumulate), _p(ws), _stream()), "hamt_colsum")
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().hamt_cast_f32_bf16(x.numel(), _p(x), _p(y), _stream()), "hamt_cast_f32_bf16")
+    return y
+
+
+def weight_operand(w: torch.Tensor, prec: str) -> torch.Tensor:
+    """GEMM B-operand for a parameter: fp32 master in fp32 mode, cached bf16 shadow in bf16 mode.
+    The shadow is refreshed when the parameter's version counter or storage changes."""
+    wd = w.detach()
+    if prec == "fp32":
+        return wd
+    c = getattr(w, "_hamt_w16", None)
+    if c is None or c[0] != w._version or c[1] != w.data_ptr():
+        c = (w._version, w.data_ptr(), cast_bf16(wd))
+        try:
+            w._hamt_w16 = c
+        except Exception:
+            pass
+    return c[2]
+
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def _linear_fwd(x2, w_op, bias, out, act, prec, pre=None):
+    epi = 0
+    if act == ACT_GELU:
+        epi |= L.EPI_GELU | (L.EPI_SAVE_PRE if pre is not None else 0)
+    elif act == ACT_RELU:
+        epi |= L.EPI_RELU
+    gemm(x2, w_op, out, bias=bias, epilogue=epi, aux=pre if act == ACT_GELU else None, prec=prec)
+
+
+def _linear_bwd(dy2, x2, w_op, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False):
+    """dy2 [M,N] (strided rows ok), x2 [M,K], w_op [N,K] -> (dx [M,K], dW [N,K], db [N])."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dx = dw = db = None
+    if need_dx:
+        dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=torch.float32, device=dy2.device)
+        gemm(dy2, w_op, dx, b_kmajor=True, epilogue=L.EPI_ACCUM if dx_accumulate else 0, prec=prec)
+    if need_dw:
+        dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
+        gemm(dy2, x2, dw, a_kmajor=True, b_kmajor=True, prec=prec)
+    if need_db:
+        db = colsum(dy2)
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------ Linear
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b)  (nn.Linear + optional erf-GELU / ReLU; vilmodel.py:140, 168-171, 182, 263-264)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, prec):
+        _chk(x, "LinearFn")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        N = weight.shape[0]
+        w_op = weight_operand(weight, prec)
+        y = empty_rows(x2.shape[0], N, x.device)
+        pre = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device) if act == ACT_GELU else None
+        _linear_fwd(x2, w_op, bias.detach() if bias is not None else None, y, act, prec, pre)
+        ctx.save_for_backward(x2, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
+        ctx.act, ctx.prec, ctx.has_bias, ctx.xshape = act, prec, bias is not None, x.shape
+        return y if x.dim() == 2 else y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, h = ctx.saved_tensors
+        N = weight.shape[0]
+        dy2 = dy.reshape(-1, N)
+        if ctx.act != ACT_NONE:
+            dy2 = dy2.contiguous()
+            h = h.contiguous()
+            dh = torch.empty_like(dy2)
+            L.check(L.load().hamt_act_bwd(dy2.numel(), _p(dy2), _p(h), ctx.act, _p(dh), _stream()), "hamt_act_bwd")
+            dy2 = dh
+        dy2 = _operand(dy2)
+        dx, dw, db = _linear_bwd(dy2, x2, weight_operand(weight, ctx.prec), ctx.prec, ctx.needs_input_grad[0],
+                                 ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None, None
+
+
+def linear(x, weight, bias, act=ACT_NONE, prec="bf16"):
+    return LinearFn.apply(x, weight, bias, act, prec)
+
+
+class PackedLinearFn(torch.autograd.Function):
+    """Several nn.Linear layers applied to the same input, written side by side into ONE packed buffer
+    [M, sum(N_i)] (query/key/value of vilmodel.py:97-99 -> qkv; key/value of :324-325 -> kv) so the
+    attention kernel reads heads by pointer arithmetic and no permute/contiguous copy is needed."""
+
+    @staticmethod
+    def forward(ctx, x, prec, *wb):
+        _chk(x, "PackedLinearFn")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        ws, bs = wb[0::2], wb[1::2]
+        ns = [w.shape[0] for w in ws]
+        out = torch.empty(x2.shape[0], sum(ns), dtype=torch.float32, device=x.device)
+        c = 0
+        for w, b, n in zip(ws, bs, ns):
+            _linear_fwd(x2, weight_operand(w, prec), b.detach(), out[:, c:c + n], ACT_NONE, prec)
+            c += n
+        ctx.save_for_backward(x2, *ws)
+        ctx.prec, ctx.ns, ctx.xshape = prec, ns, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, *ws = ctx.saved_tensors
+        dout = dout.contiguous()
+        grads = []
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        c = 0
+        for i, (w, n) in enumerate(zip(ws, ctx.ns)):
+            dy2 = dout[:, c:c + n]
+            _, dw, db = _linear_bwd(dy2, x2, weight_operand(w, ctx.prec), ctx.prec, dx is not None, True, True,
+                                    dx_out=dx, dx_accumulate=i > 0)
+            grads += [dw, db]
+            c += n
+        return (dx.view(ctx.xshape) if dx is not None else None), None, *grads
+
+
+def packed_linear(x, prec, *linears):
+    wb = []
+    for lin in linears:
+        wb += [lin.weight, lin.bias]
+    return PackedLinearFn.apply(x, prec, *wb)
+
+
+# ------------------------------------------------------------------------------------------ attention
+class AttnFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(d) + mask) V with dropout on the probabilities (vilmodel.py:101-126, 327-348).
+    `q_src` is either the packed self-attention buffer [B*S, 3H] (kv_src None) or the query projection
+    [B*Sq, H] with `kv_src` = packed [B*Sk, 2H].  `add_mask` is the reference's additive (B,1,1,Sk) mask."""
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, add_mask, B, heads, p_drop):
+        _chk(q_src, "AttnFn")
+        packed = kv_src is None
+        H = q_src.shape[1] // 3 if packed else q_src.shape[1]
+        Sq = q_src.shape[0] // B
+        if packed:
+            q, k, v, Sk = q_src[:, :H], q_src[:, H:2 * H], q_src[:, 2 * H:], Sq
+        else:
+            q, k, v, Sk = q_src, kv_src[:, :H], kv_src[:, H:], kv_src.shape[0] // B
+        mask2 = None
+        if add_mask is not None:
+            mask2 = add_mask.reshape(B, Sk).to(torch.float32).contiguous()
+        out = torch.empty(B * Sq, H, dtype=torch.float32, device=q_src.device)
+        lse = torch.empty(B * heads * Sq, dtype=torch.float32, device=q_src.device)
+        cid = next_call_id()
+        rng = rng_state(q_src.device)
+        d = L.AttnDesc(B, heads, Sq, Sk, H // heads, _ld(q), _ld(k), _ld(v), H, _dt(q), L.HAMT_F32,
+                       1.0 / math.sqrt(H // heads), float(p_drop), cid)
+        L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(out), _p(lse), _p(rng), _stream()),
+                "hamt_attn_small_fwd")
+        ctx.save_for_backward(q_src, kv_src, mask2, out, lse)
+        ctx.desc_args = (B, heads, Sq, Sk, H, float(p_drop), cid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_src, kv_src, mask2, out, lse = ctx.saved_tensors
+        B, heads, Sq, Sk, H, p_drop, cid = ctx.desc_args
+        packed = kv_src is None
+        dout = dout.contiguous()
+        dq_src = torch.empty_like(q_src)
+        dkv_src = None if packed else torch.empty_like(kv_src)
+        if packed:
+            q, k, v = q_src[:, :H], q_src[:, H:2 * H], q_src[:, 2 * H:]
+            dq, dk, dv = dq_src[:, :H], dq_src[:, H:2 * H], dq_src[:, 2 * H:]
+        else:
+            q, k, v = q_src, kv_src[:, :H], kv_src[:, H:]
+            dq, dk, dv = dq_src, dkv_src[:, :H], dkv_src[:, H:]
+        d = L.AttnDesc(B, heads, Sq, Sk, H // heads, _ld(q), _ld(k), _ld(v), H, _dt(q), L.HAMT_F32,
+                       1.0 / math.sqrt(H // heads), p_drop, cid)
+        L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(out), _p(dout), _p(lse), None,
+                                             _p(dq), _p(dk), _p(dv), _p(rng_state(q_src.device)), _stream()),
+                "hamt_attn_small_bwd")
+        return dq_src, dkv_src, None, None, None, None
+
+
+def attention(q_src, kv_src, add_mask, B, heads, p_drop):
+    return AttnFn.apply(q_src, kv_src, add_mask, B, heads, p_drop)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm family
+class LnFn(torch.autograd.Function):
+    """y = dropout_post(LayerNorm(dropout_pre(x) + residual)) -- see hamt_ln_fwd in include/hamt.h."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps, p_pre, p_post):
+        _chk(x, "LnFn")
+        H = x.shape[-1]
+        x2 = x.reshape(-1, H).contiguous()
+        r2 = residual.reshape(-1, H).contiguous() if residual is not None else None
+        M = x2.shape[0]
+        dev = x.device
+        z = torch.empty(M, H, dtype=torch.float32, device=dev)
+        y = torch.empty(M, H, dtype=torch.float32, device=dev)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        cid = next_call_id() if (p_pre > 0 or p_post > 0) else 0
+        d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid)
+        L.check(L.load().hamt_ln_fwd(C.byref(d), _p(x2), _p(r2), _p(gamma.detach()), _p(beta.detach()), _p(z), _p(y), None,
+                                     _p(mean), _p(rstd), _p(rng_state(dev)), _stream()), "hamt_ln_fwd")
+        ctx.save_for_backward(z, mean, rstd, gamma)
+        ctx.args = (M, H, float(eps), float(p_pre), float(p_post), cid, residual is not None, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, gamma = ctx.saved_tensors
+        M, H, eps, p_pre, p_post, cid, has_res, xshape = ctx.args
+        dev = dy.device
+        dy2 = dy.reshape(M, H).contiguous()
+        dz = torch.empty(M, H, dtype=torch.float32, device=dev)
+        dx = torch.empty(M, H, dtype=torch.float32, device=dev) if p_pre > 0 else None
+        dgamma = torch.zeros(H, dtype=torch.float32, device=dev)
+        dbeta = torch.zeros(H, dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * 256 * H, dtype=torch.float32, device=dev)
+        d = L.LnDesc(M, H, eps, p_pre, p_post, cid)
+        L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma.detach()), _p(dz), _p(dx),
+                                     _p(dgamma), _p(dbeta), _p(ws), _p(rng_state(dev)), _stream()), "hamt_ln_bwd")
+        gx = (dx if dx is not None else dz).view(xshape)
+        return gx, (dz.view(xshape) if has_res else None), dgamma, dbeta, None, None, None
+
+
+def layer_norm(x, residual, ln_module, p_pre=0.0, p_post=0.0, eps=None):
+    return LnFn.apply(x, residual, ln_module.weight, ln_module.bias, ln_module.eps if eps is None else eps, p_pre, p_post)
+
+
+# ------------------------------------------------------------------------------------------ gathers / embeddings
+class EmbedSumFn(torch.autograd.Function):
+    """word[ids] + position[:L] + token_type[0]  (vilmodel.py:62-66; int64 gather is bit exact)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ):
+        _chk(word, "EmbedSumFn")
+        B, Lq = ids.shape
+        H = word.shape[1]
+        ids = ids.contiguous()
+        z = torch.empty(B, Lq, H, dtype=torch.float32, device=word.device)
+        L.check(L.load().hamt_embed_sum_fwd(B, Lq, H, _p(ids), _p(word.detach()), _p(pos.detach()), _p(typ.detach()), _p(z), _stream()),
+                "hamt_embed_sum_fwd")
+        ctx.save_for_backward(ids)
+        ctx.shapes = (word.shape, pos.shape, typ.shape)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (ids,) = ctx.saved_tensors
+        B, Lq = ids.shape
+        dz = dz.contiguous()
+        H = dz.shape[-1]
+        dev = dz.device
+        dword = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+        dpos = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
+        dtyp = torch.zeros(ctx.shapes[2], dtype=torch.float32, device=dev)
+        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, _p(ids), _p(dz), _p(dword), _p(dpos), None, _stream()), "hamt_embed_sum_bwd")
+        ws = torch.empty(64 * H, dtype=torch.float32, device=dev)
+        L.check(L.load().hamt_sum_rows(B, Lq, H, _p(dz), 0, _p(dtyp), _p(ws), _stream()), "hamt_sum_rows")  # row 0 of the type table
+        return None, dword, dpos, dtyp
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[r] = (base[r] if base is not None else 0) + table[idx[r]]  over rows of width W.
+    Serves embedding lookups, boolean-mask compaction, anchor gathers and slices (idx arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, base):
+        _chk(table, "GatherRowsFn")
+        W = table.shape[-1]
+        t2 = table.reshape(-1, W)
+        if t2.stride(-1) != 1:
+            t2 = t2.contiguous()
+        idx = idx.reshape(-1).contiguous()
+        R = idx.numel()
+        b2 = base.reshape(R, W).contiguous() if base is not None else None
+        out = torch.empty(R, W, dtype=torch.float32, device=table.device)
+        L.check(L.load().hamt_gather_rows(R, W, _p(t2.detach()), _ld(t2), _p(idx), _p(b2), W, _p(out), W, 0, _stream()),
+                "hamt_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.tshape, ctx.has_base, ctx.bshape = table.shape, base is not None, (base.shape if base is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, W = dout.shape
+        dtab = None
+        if ctx.needs_input_grad[0]:
+            dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
+            L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(dtab), W, _stream()), "hamt_scatter_add_rows")
+        return dtab, None, (dout.view(ctx.bshape) if ctx.has_base else None)
+
+
+def gather_rows(table, idx, base=None):
+    return GatherRowsFn.apply(table, idx, base)
+
+
+class Add3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        _chk(a, "Add3Fn")
+        a, b = a.contiguous(), b.contiguous()
+        c = c.contiguous() if c is not None else None
+        out = torch.empty_like(a)
+        L.check(L.load().hamt_add3(a.numel(), _p(a), _p(b), _p(c), _p(out), _stream()), "hamt_add3")
+        ctx.has_c = c is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, (g if ctx.has_c else None)
+
+
+def add3(a, b, c=None):
+    return Add3Fn.apply(a, b, c)
+
+
+class MeanMidFn(torch.autograd.Function):
+    """(B,S,H) -> (B,H) mean over S (panorama mean pooling, vilmodel.py:563-564)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "MeanMidFn")
+        x = x.contiguous()
+        B, S, H = x.shape
+        y = torch.empty(B, H, dtype=torch.float32, device=x.device)
+        L.check(L.load().hamt_mean_mid_fwd(B, S, H, _p(x), _p(y), _stream()), "hamt_mean_mid_fwd")
+        ctx.shape = (B, S, H)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, H = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, S, H, dtype=torch.float32, device=dy.device)
+        L.check(L.load().hamt_mean_mid_bwd(B, S, H, _p(dy), _p(dx), _stream()), "hamt_mean_mid_bwd")
+        return dx
+
+
+class MulBcastFn(torch.autograd.Function):
+    """y[b,s,:] = a[b,s,:] * c[b,:]  (SAP fusion ob*txt_cls pretrain_cmt.py:176; ITM cls product vilmodel.py:722).
+    `c` may be a strided row view such as txt_embeds[:, 0]."""
+
+    @staticmethod
+    def forward(ctx, a, c):
+        _chk(a, "MulBcastFn")
+        a = a.contiguous()
+        B, S, H = a.shape
+        if c.stride(-1) != 1 or (c.stride(0) % 4):
+            c = c.contiguous()
+        y = torch.empty_like(a)
+        L.check(L.load().hamt_mul_bcast_fwd(B, S, H, _p(a), _p(c), c.stride(0), _p(y), _stream()), "hamt_mul_bcast_fwd")
+        ctx.save_for_backward(a, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, c = ctx.saved_tensors
+        B, S, H = a.shape
+        dy = dy.contiguous()
+        da = torch.empty_like(a)
+        dc = torch.empty(B, H, dtype=torch.float32, device=a.device)
+        L.check(L.load().hamt_mul_bcast_bwd(B, S, H, _p(a), _p(c), c.stride(0), _p(dy), _p(da), _p(dc), _stream()), "hamt_mul_bcast_bwd")
+        return da, dc
+
+
+class FillWhereZeroFn(torch.autograd.Function):
+    """x.masked_fill(flag == 0, value) (pretrain_cmt.py:177 does it in place on a fresh tensor; the result
+    is the same object-wise for callers); backward zeroes the gradient at the filled positions."""
+
+    @staticmethod
+    def forward(ctx, x, flag, value):
+        _chk(x, "FillWhereZeroFn")
+        flag = flag.contiguous()
+        assert flag.numel() == x.numel()
+        y = x.contiguous().clone()
+        L.check(L.load().hamt_fill_where_zero(y.numel(), _p(flag), _p(y), float(value), _stream()), "hamt_fill_where_zero")
+        ctx.save_for_backward(flag)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (flag,) = ctx.saved_tensors
+        g = g.contiguous().clone()
+        L.check(L.load().hamt_fill_where_zero(g.numel(), _p(flag), _p(g), 0.0, _stream()), "hamt_fill_where_zero")
+        return g, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """Feature dropout (finetune model_HAMT.py:32-52); same counter-based mask replayed in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        _chk(x, "DropoutFn")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx.cid, ctx.p = next_call_id(), float(p)
+        L.check(L.load().hamt_dropout(x.numel(), _p(x), _p(y), ctx.p, ctx.cid, _p(rng_state(x.device)), _stream()), "hamt_dropout")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        L.check(L.load().hamt_dropout(g.numel(), _p(g), _p(dx), ctx.p, ctx.cid, _p(rng_state(g.device)), _stream()), "hamt_dropout")
+        return dx, None
+
+
+def fill_where_zero(x, flag, value):
+    return FillWhereZeroFn.apply(x, flag, value)
+
+
+def mean_mid(x):
+    return MeanMidFn.apply(x)
+
+
+def mul_bcast(a, c):
+    return MulBcastFn.apply(a, c)
+
+
+def embed_sum(ids, word, pos, typ):
+    return EmbedSumFn.apply(ids, word, pos, typ)
+
+
+def dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+# ------------------------------------------------------------------------------------------ losses
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(x, label, reduction='none') (pretrain_cmt.py:154, 180, 259)."""
+
+    @staticmethod
+    def forward(ctx, x, label):
+        _chk(x, "CrossEntropyFn")
+        assert x.dim() == 2 and x.stride(1) == 1
+        R, Cc = x.shape
+        label = label.contiguous()
+        loss = torch.empty(R, dtype=torch.float32, device=x.device)
+        lse = torch.empty(R, dtype=torch.float32, device=x.device)
+        L.check(L.load().hamt_ce_fwd(R, Cc, _p(x), x.stride(0), _p(label), _p(loss), _p(lse), _stream()), "hamt_ce_fwd")
+        ctx.save_for_backward(x, label, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, label, lse = ctx.saved_tensors
+        R, Cc = x.shape
+        g = g.contiguous()
+        ld = (Cc + 7) // 8 * 8                       # keep rows 16-byte aligned for the following GEMMs
+        buf = torch.empty(R, ld, dtype=torch.float32, device=x.device)
+        L.check(L.load().hamt_ce_bwd(R, Cc, _p(x), x.stride(0), _p(label), _p(lse), _p(g), _p(buf), ld, _stream()), "hamt_ce_bwd")
+        return buf[:, :Cc], None
+
+
+class MseFn(torch.autograd.Function):
+    """F.mse_loss(x, t, reduction='none') (pretrain_cmt.py:197, 219)."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        _chk(x, "MseFn")
+        x, t = x.contiguous(), t.contiguous().to(torch.float32)
+        loss = torch.empty_like(x)
+        L.check(L.load().hamt_mse_fwd(x.numel(), _p(x), _p(t), _p(loss), _stream()), "hamt_mse_fwd")
+        ctx.save_for_backward(x, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().hamt_mse_bwd(x.numel(), _p(x), _p(t), _p(g), _p(dx), _stream()), "hamt_mse_bwd")
+        return dx, None
+
+
+class KlFn(torch.autograd.Function):
+    """F.kl_div(F.log_softmax(x, -1), t, reduction='none').sum(1) (pretrain_cmt.py:239-240)."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        _chk(x, "KlFn")
+        assert x.dim() == 2 and x.stride(1) == 1
+        t = t.contiguous().to(torch.float32)
+        R, Cc = x.shape
+        loss = torch.empty(R, dtype=torch.float32, device=x.device)
+        lse = torch.empty(R, dtype=torch.float32, device=x.device)
+        L.check(L.load().hamt_kl_fwd(R, Cc, _p(x), x.stride(0), _p(t), Cc, _p(loss), _p(lse), _stream()), "hamt_kl_fwd")
+        ctx.save_for_backward(x, t, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, lse = ctx.saved_tensors
+        R, Cc = x.shape
+        g = g.contiguous()
+        ld = (Cc + 7) // 8 * 8
+        buf = torch.empty(R, ld, dtype=torch.float32, device=x.device)
+        L.check(L.load().hamt_kl_bwd(R, Cc, _p(x), x.stride(0), _p(t), Cc, _p(lse), _p(g), _p(buf), ld, _stream()), "hamt_kl_bwd")
+        return buf[:, :Cc], None
+
+
+def cross_entropy(x, label):
+    return CrossEntropyFn.apply(x, label)
+
+
+def mse_loss(x, t):
+    return MseFn.apply(x, t)
+
+
+def kl_div_logsoftmax(x, t):
+    return KlFn.apply(x, t)
