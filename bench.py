@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- HAMT R2R proxy-task pretraining throughput on MI355X (panorama-steps/s).
+
+One "step" = one full optimisation step of the hot path on one synthetic minibatch per GPU:
+forward + backward (+ RCCL gradient all-reduce when N > 1) + global-norm clip + AdamW + zero_grad, dropout on,
+on the R2R-canon model (H=768, 12 heads, 9 text + 2 pano + 4 cross-modal layers, vocab 30522, 174.8 M params),
+36x768 view features, 80-token instructions, history 5, tasks cycled with the reference's 5:1:1:1:2:2 mix.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--prec bf16|fp32] [--task mix|sap|...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+H, FFN, L_TXT, T_HIST, V = 768, 3072, 80, 5, 36
+
+
+def layer_flops(S):            # 24*S*H^2 + 4*S^2*H
+    return 24 * S * H * H + 4 * S * S * H
+
+
+def xlayer_flops(Lq, Vn):
+    return 32 * (Lq + Vn) * H * H + 8 * Lq * Vn * H + 4 * Lq * Lq * H + 4 * Vn * Vn * H
+
+
+def trunk_fwd_flops(task, L=L_TXT, T=T_HIST):
+    """forward FLOPs per ORIGINAL sample (SURVEY.md 8a formula; ITM runs the x-layers on 5x the batch)."""
+    ob = task in ("sap", "sar", "sprel")
+    f = 9 * layer_flops(L) + T * (2 * layer_flops(V) + 2 * V * H * H + 2 * V * 4 * H) + T * (2 * H * H + 2 * 4 * H)
+    if ob:
+        f += (V + 1) * (2 * H * H + 2 * 4 * H)
+    vn = T + 1 + (V + 1 if ob else 0)
+    f += (5 if task == "itm" else 1) * 4 * xlayer_flops(L, vn)
+    if task == "mlm":
+        f += 2 * 12 * H * 30522 + 2 * 12 * H * H
+    return f
+
+
+def build_model(prec, device):
+    from vln_hamt_amd.model.pretrain_cmt import MultiStepNavCMTPreTraining
+    from vln_hamt_amd.modeling import HamtConfig
+    cfg = HamtConfig(hamt_precision=prec, pretrain_tasks={"mlm", "sap", "sar", "sprel", "mrc", "itm"})
+    torch.manual_seed(0)
+    model = MultiStepNavCMTPreTraining(cfg).to(device)
+    model.train()
+    return model, cfg
+
+
+def time_gemm_roofline(batch, device, iters=30):
+    """Live HIP-event timing of the dominant kernel: the bf16 MFMA GEMM at the text FFN-1 shape
+    (M = B*80 rows, N = 3072, K = 768; forward).  Algorithmic FLOPs = 2*M*N*K per launch."""
+    from vln_hamt_amd import ops
+    M, N, K = batch * L_TXT, FFN, H
+    a = torch.randn(M, K, device=device)
+    w = torch.randn(N, K, device=device).to(torch.bfloat16)
+    bias = torch.randn(N, device=device)
+    out = torch.empty(M, N, device=device)
+    for _ in range(5):
+        ops.gemm(a, w, out, bias=bias, prec="bf16")
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
+    s.record()
+    for _ in range(iters):
+        ops.gemm(a, w, out, bias=bias, prec="bf16")
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "kernel": f"gemm_bf16_kernel<128,128,NT> M={M} N={N} K={K}", "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(budget_s=20.0, batch=16):
+    """The CPU oracle (oracle/hamt_oracle.py, a port pinned to the reference's goldens) timed on the host:
+    SAP train step (forward, mean, backward, clip 5.0, HF AdamW), dropout on, fp32, all host cores."""
+    import torch as th
+    from oracle.hamt_oracle import (HamtOracle, OracleConfig, adamw_step, clip_grad_norm, make_state_dict,
+                                    pretrain_param_shapes)
+    from vln_hamt_amd.synth import make_batch
+    # measured on the GPU box (2 x EPYC 9575F, 256 logical CPUs): this model's small GEMMs get SLOWER beyond ~16
+    # threads (1.4 s/step at 16, 1.9 at 32, 3.9 at 64), so the baseline uses the fastest setting, not all cores
+    cores = int(os.environ.get("HAMT_CPU_THREADS", min(16, os.cpu_count() or 1)))
+    th.set_num_threads(cores)
+    cfg = OracleConfig()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=1)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
+    state, times = {}, []
+    t_start = time.time()
+    i = 0
+    while True:
+        b = make_batch("sap", batch, cfg, seed=1000 + i)
+        t0 = time.time()
+        loss = HamtOracle(params, cfg, training=True).forward(b, "sap", True).mean()
+        loss.backward()
+        grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+        clip_grad_norm(list(grads.values()), 5.0)
+        with th.no_grad():
+            adamw_step(params, grads, state, 5e-5)
+        for p in params.values():
+            p.grad = None
+        times.append(time.time() - t0)
+        i += 1
+        if i >= 2 and (time.time() - t_start > budget_s or i >= 8):
+            break
+    steady = times[1:] if len(times) > 1 else times
+    per_step = sorted(steady)[len(steady) // 2]
+    return {"value": round(batch / per_step, 3), "unit": "panorama-steps/s", "cores": cores, "kind": "port",
+            "sample": f"SAP train step (fwd+bwd+clip+AdamW, dropout on, fp32), B={batch}, L=80, T=5, "
+                      f"{len(times)} steps, median of steps 2.. ({per_step:.2f} s/step)"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU minibatch (ITM uses batch/2 originals, loader.py:130)")
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--task", default="mix", help="mix (5:1:1:1:2:2 cycle) or one of mlm/sap/sar/sprel/mrc/itm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    from vln_hamt_amd import ops
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    from vln_hamt_amd.parallel import TaskSchedule, barrier, init_distributed, max_over_ranks, sum_over_ranks, wrap_ddp
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HAMT kernels have no CPU path"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    ops.manual_seed(1234 + rank, device)
+
+    log("building model")
+    model, cfg = build_model(args.prec, device)
+    named = list(model.named_parameters())
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in NO_DECAY)], "weight_decay": 0.01},
+              {"params": [p for n, p in named if any(nd in n for nd in NO_DECAY)], "weight_decay": 0.0}]
+    opt = AdamW(groups, lr=5e-5, betas=(0.9, 0.98))
+    opt.materialize()                                   # flat arenas before DDP captures the parameters
+    net = wrap_ddp(model, local_rank) if world > 1 else model
+
+    sched = TaskSchedule(cyclic=True) if args.task == "mix" else None
+    n_distinct = 12
+    batches = {}
+
+    def get_batch(step):
+        task = sched.task_at(step) if sched else args.task
+        key = (task, step % n_distinct)
+        if key not in batches:                          # synthetic inputs resident in HBM before the timed region
+            b = make_batch(task, args.batch, cfg, seed=1234 + rank + 7919 * (step % n_distinct), txt_len=L_TXT,
+                           hist_len=T_HIST, mlm_exact=12 if task == "mlm" else None, device=device)
+            if task == "itm":
+                r = make_itm_rng(b, seed=step)
+                b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+            batches[key] = b
+        return task, batches[key]
+
+    log("generating synthetic batches")
+    for s in range(args.warmup + args.steps):
+        get_batch(s)
+    log("batches resident in HBM")
+    gstep = [0]
+
+    def train_step(step):
+        task, b = get_batch(step)
+        loss = net(b, task, True).mean()
+        loss.backward()
+        gstep[0] += 1
+        lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)
+        opt.step()
+        opt.zero_grad()
+        ops.advance_rng_epoch(device)
+        return task, b["txt_ids"].shape[0]
+
+    for s in range(args.warmup):
+        t_ = time.perf_counter()
+        tk, _ = train_step(s)
+        if s < 3:
+            torch.cuda.synchronize()
+            log(f"warmup step {s} ({tk}): {time.perf_counter() - t_:.3f} s")
+    torch.cuda.synchronize()
+    log("warmup done")
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples, flops = 0, 0.0
+    for s in range(args.warmup, args.warmup + args.steps):
+        task, n = train_step(s)
+        samples += n
+        flops += 3.0 * trunk_fwd_flops(task) * n
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = max_over_ranks(time.perf_counter() - t0, device)
+    log(f"timed region: {dt:.3f} s for {args.steps} steps")
+    total_samples = sum_over_ranks(float(samples), device)
+    total_flops = sum_over_ranks(flops, device)
+
+    if rank == 0:
+        out = {
+            "metric": "panorama-steps/sec, R2R proxy pretrain (36x768 views, 80-tok instr)",
+            "value": round(total_samples / dt, 2), "unit": "panorama-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "R2R 6-proxy-task pretrain step (fwd+bwd+clip+AdamW, dropout 0.1), fixed ViT features, "
+                                   "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
+                       "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
+                       "parallelism": f"dp{world}"},
+            "per_gpu": round(total_samples / dt / world, 2),
+            "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
+            "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+        }
+        out["roofline"] = time_gemm_roofline(args.batch, device)
+        log("roofline probe done; timing the CPU oracle baseline")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    barrier()
+
+
+if __name__ == "__main__":
+    main()

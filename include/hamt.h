@@ -70,6 +70,13 @@ typedef struct {
 int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
               void* aux, void* stream);
 
+/* operand preparation for the bf16 fast path (both GEMM operands bf16, K-contiguous, K % 64 == 0):
+ *   cast_pad_bf16:   y[R][Cpad] (bf16) = x[R][C] (fp32), columns >= C zero filled
+ *   cast_transpose:  y[C][Rpad] (bf16) = x[R][C]^T (fp32 or bf16 source), rows >= R zero filled
+ * (dgrad uses the transposed weight, wgrad the transposed activations / gradients.) */
+int hamt_cast_pad_bf16(int R, int C, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream);
+int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dtype_x, void* y, int ldy, int Rpad, void* stream);
+
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
 int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate,
                 float* ws, void* stream);

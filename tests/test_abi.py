@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library loads and exports exactly what include/hamt.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_protos():
+    src = open(os.path.join(ROOT, "include", "hamt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(hamt_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        protos[m.group(1)] = n
+    return protos
+
+
+def test_header_and_binding_agree():
+    from vln_hamt_amd import _lib
+    protos = _header_protos()
+    assert len(protos) >= 30
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    for name, n in protos.items():
+        assert len(_lib.SIGNATURES[name]) == n, (name, n, len(_lib.SIGNATURES[name]))
+
+
+def test_library_exports_every_symbol():
+    from vln_hamt_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    for name in _header_protos():
+        assert hasattr(lib, name), name
+    assert lib.hamt_version() == 1
+    buf = ctypes.create_string_buffer(64)
+    assert lib.hamt_last_error(buf, 64) >= 0
+
+
+def test_struct_layouts_match_header():
+    """field order/count of the descriptor structs (plain ints/floats, no padding surprises)."""
+    from vln_hamt_amd import _lib
+    assert ctypes.sizeof(_lib.GemmDesc) == 16 * 4
+    assert ctypes.sizeof(_lib.AttnDesc) == 14 * 4
+    assert ctypes.sizeof(_lib.LnDesc) == 6 * 4
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under vln-hamt_amd/ may import it (or torch CPU fallbacks)."""
+    pkg = os.path.join(ROOT, "vln-hamt_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    from vln_hamt_amd import ops
+    from vln_hamt_amd._lib import HamtError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(HamtError):
+        ops.linear(torch.randn(4, 8), torch.randn(8, 8), torch.randn(8), 0, "fp32")
+    with pytest.raises(HamtError):
+        ops.layer_norm(torch.randn(4, 8), None, torch.nn.LayerNorm(8))

@@ -43,7 +43,8 @@ def close(a, b, tol, what=""):
 
 # ------------------------------------------------------------------------------------------ GEMM
 LAYOUTS = {"nt": (False, False), "nn": (False, True), "tn": (True, True)}
-SHAPES = [(200, 136, 96), (130, 70, 36), (64, 3, 768), (33, 1, 40), (50, 64, 4), (77, 100, 1001), (2048, 1536, 64)]
+SHAPES = [(200, 136, 96), (130, 70, 36), (64, 3, 768), (33, 1, 40), (50, 64, 4), (77, 100, 1001), (2048, 1536, 64),
+          (300, 200, 768), (129, 1000, 128), (1, 130, 64)]
 
 
 def _mk(layout, M, N, K, seed):
@@ -137,6 +138,20 @@ torch.save((o1.cpu(), o2.cpu()), sys.argv[1])
         outs.append(torch.load(name))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_cast_pad_and_transpose_exact():
+    ops = _ops()
+    x = rnd(77, 100, seed=1)
+    y = ops.cast_pad16(x.to(DEV))
+    assert y.shape == (77, 128) and torch.equal(y[:, :100].float().cpu(), bf16_round(x)) and float(y[:, 100:].float().abs().max()) == 0
+    buf = torch.zeros(77, 104, device=DEV)
+    buf[:, 1:101] = x.to(DEV)                                   # odd column offset: unaligned rows take the scalar path
+    assert torch.equal(ops.cast_pad16(buf[:, 1:101]).cpu(), y.cpu())
+    t = ops.cast_t16(x.to(DEV))
+    assert t.shape == (100, 128) and torch.equal(t[:, :77].float().cpu(), bf16_round(x).t()) and float(t[:, 77:].float().abs().max()) == 0
+    t2 = ops.cast_t16(x.to(DEV).to(torch.bfloat16))
+    assert torch.equal(t2.cpu(), t.cpu())
 
 
 def test_colsum():
@@ -280,8 +295,7 @@ def test_ln_dropout_pre_post():
     y2.backward(rnd(M, H, seed=3).to(DEV))
     ratio = xg2.grad / rg2.grad
     z = ratio[torch.isfinite(ratio)]
-    vals = torch.unique(torch.round(z * 1e4) / 1e4)
-    assert set(np.round(vals.cpu().numpy(), 3).tolist()) <= {0.0, round(1 / (1 - p), 3)}, vals
+    assert bool(((z.abs() < 1e-6) | ((z - 1 / (1 - p)).abs() < 1e-4)).all()), torch.unique(torch.round(z * 1e4) / 1e4)
     assert abs(float((xg2.grad == 0).float().mean()) - p) < 0.01
 
 
@@ -410,9 +424,17 @@ def test_linear_and_packed_linear_autograd(prec):
         y = ops.linear(xg, glins[0].weight, glins[0].bias, act, prec)
         y.backward(go.to(DEV))
         close(y, ref, tol, f"linear act{act}")
-        close(xg.grad, xr.grad, tol, "linear dx")
-        close(glins[0].weight.grad, ld.weight.grad, tol, "linear dW")
-        close(glins[0].bias.grad, ld.bias.grad, tol, "linear db")
+        if prec == "bf16" and act == ops.ACT_RELU:
+            # bf16 operand rounding flips the sign of a few near-zero pre-activations, and one flipped mask entry
+            # moves dW/dx by a whole |dy * x| term: build the reference gradients with the kernel's OWN mask
+            dh = go.double().reshape(-1, N) * (y.detach().cpu().reshape(-1, N) > 0)
+            close(xg.grad.reshape(-1, K), dh @ ld.weight.detach(), tol, "linear dx relu")
+            close(glins[0].weight.grad, dh.t() @ x.double().reshape(-1, K), tol, "linear dW relu")
+            close(glins[0].bias.grad, dh.sum(0), tol, "linear db relu")
+            continue
+        close(xg.grad, xr.grad, tol, f"linear dx act{act}")
+        close(glins[0].weight.grad, ld.weight.grad, tol, f"linear dW act{act}")
+        close(glins[0].bias.grad, ld.bias.grad, tol, f"linear db act{act}")
     xr = x.clone().double().requires_grad_(True)
     lds = [torch.nn.Linear(K, N).double() for _ in range(3)]
     for a, b in zip(lds, lins):
@@ -421,6 +443,8 @@ def test_linear_and_packed_linear_autograd(prec):
     go = rnd(B * S, 3 * N, seed=3)
     ref.reshape(B * S, 3 * N).backward(go.double())
     xg.grad = None
+    for l in glins:
+        l.zero_grad()
     y = ops.packed_linear(xg, prec, *glins)
     y.backward(go.to(DEV))
     close(y, ref.reshape(B * S, 3 * N), tol, "packed y")

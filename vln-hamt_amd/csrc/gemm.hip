@@ -331,18 +331,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const
   __syncthreads();
   if (ph == 0 && col < N) ws[(size_t)blockIdx.y * N + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void reduce_partials_kernel(int R, int N, const float* __restrict__ ws, float* __restrict__ out, int accumulate) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int R, int N, const float* __restrict__ ws, float* __restrict__ out,
+                                                              int accumulate) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   float s = 0.f;
-  for (int r = 0; r < R; ++r) s += ws[(size_t)r * N + n];
-  out[n] = accumulate ? out[n] + s : s;
+  if (n < N)
+    for (int r = ph; r < R; r += 4) s += ws[(size_t)r * N + n];
+  __shared__ float red[4][64];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && n < N) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[n] = accumulate ? out[n] + t : t;
+  }
 }
 
 }  // namespace
 
+bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void* B);
+void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux, hipStream_t s);
+
 void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, R, N, ws, out, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, s, R, N, ws, out, accumulate);
 }
 
 extern "C" int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
@@ -357,6 +367,12 @@ extern "C" int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, 
   HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) || aux, "hamt_gemm: epilogue needs aux");
   GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
   hipStream_t s = as_stream(stream);
+  static const bool no_fast = getenv("HAMT_NO_FAST") != nullptr;
+  if (!no_fast && hamt_gemm_fast_eligible(d, A, B)) {  // bf16 x bf16, K-contiguous operands, K % 64 == 0
+    hamt_gemm_fast_launch(d, A, B, C, bias, aux, s);
+    HAMT_CHECK_LAUNCH("hamt_gemm(fast)");
+    return HAMT_OK;
+  }
   if (d->prec == HAMT_PREC_F32) {
     HAMT_CHECK_ARG(d->dtype_a == HAMT_F32 && d->dtype_b == HAMT_F32, "hamt_gemm: PREC_F32 needs fp32 operands");
     int tiles = ((d->M + F_BM - 1) / F_BM) * ((d->N + F_BN - 1) / F_BN);

@@ -153,16 +153,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
   }
 }
 
-// ws[block][2][H] -> dgamma[H], dbeta[H] (accumulate)
-__global__ void ln_bwd_reduce_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * H) return;
+// ws[block][2][H] -> dgamma[H], dbeta[H] (accumulate).  block = 64 columns x 4 partial-row phases.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   const int which = c / H, col = c % H;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += ws[((size_t)b * 2 + which) * H + col];
-  float* o = which ? dbeta : dgamma;
-  if (o) o[col] += s;
+  if (c < 2 * H)
+    for (int b = ph; b < nb; b += 4) s += ws[((size_t)b * 2 + which) * H + col];
+  __shared__ float red[4][64];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < 2 * H) {
+    float* o = which ? dbeta : dgamma;
+    if (o) o[col] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
 }
 
 }  // namespace
@@ -200,7 +205,7 @@ extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* 
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
   if (dgamma || dbeta)
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d->H + 255) / 256), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta);
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
   return HAMT_OK;
 }

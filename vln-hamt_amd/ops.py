@@ -154,26 +154,88 @@ def weight_operand(w: torch.Tensor, prec: str) -> torch.Tensor:
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
-def _linear_fwd(x2, w_op, bias, out, act, prec, pre=None):
+# ---- operand preparation for the bf16 fast GEMM (both operands bf16, K-contiguous, K % 64 == 0)
+def _rup(n: int, m: int = 64) -> int:
+    return (n + m - 1) // m * m
+
+
+def cast_pad16(x2: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    """fp32 [R,C] (strided rows ok) -> bf16 [R,Cpad] with zero-filled padding columns."""
+    R, Cc = x2.shape
+    cpad = _rup(Cc) if cpad is None else cpad
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty(R, cpad, dtype=torch.bfloat16, device=x2.device)
+    L.check(L.load().hamt_cast_pad_bf16(R, Cc, cpad, _p(x2), _ld(x2), _p(y), cpad, _stream()), "hamt_cast_pad_bf16")
+    return y
+
+
+def cast_t16(x2: torch.Tensor, rpad: Optional[int] = None) -> torch.Tensor:
+    """[R,C] fp32/bf16 (strided rows ok) -> bf16 [C,Rpad] = x^T, zero-filled padding columns."""
+    R, Cc = x2.shape
+    rpad = _rup(R) if rpad is None else rpad
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty(Cc, rpad, dtype=torch.bfloat16, device=x2.device)
+    L.check(L.load().hamt_cast_transpose(R, Cc, _p(x2), _ld(x2), _dt(x2), _p(y), rpad, rpad, _stream()), "hamt_cast_transpose")
+    return y
+
+
+def weight_t16(w: torch.Tensor) -> torch.Tensor:
+    """cached bf16 W^T [K, Npad64] of a [N,K] parameter (B operand of the dgrad dX = dY W in NT form)."""
+    c = getattr(w, "_hamt_wt16", None)
+    if c is None or c[0] != w._version or c[1] != w.data_ptr():
+        c = (w._version, w.data_ptr(), cast_t16(w.detach()))
+        try:
+            w._hamt_wt16 = c
+        except Exception:
+            pass
+    return c[2]
+
+
+def _fast_ok(K: int) -> bool:
+    return K % 64 == 0 and K >= 64
+
+
+def _linear_fwd(x2, w_op, bias, out, act, prec, pre=None, x16=None):
+    """out = act(x2 @ W^T + b).  bf16 mode with K % 64 == 0: x is cast once (x16 may be passed in to share it)
+    and the GEMM takes the glds fast path; otherwise the generic kernel converts while staging."""
     epi = 0
     if act == ACT_GELU:
         epi |= L.EPI_GELU | (L.EPI_SAVE_PRE if pre is not None else 0)
     elif act == ACT_RELU:
         epi |= L.EPI_RELU
-    gemm(x2, w_op, out, bias=bias, epilogue=epi, aux=pre if act == ACT_GELU else None, prec=prec)
+    a = x2
+    if prec == "bf16" and _fast_ok(x2.shape[1]) and w_op.dtype == torch.bfloat16:
+        a = x16 if x16 is not None else (x2 if x2.dtype == torch.bfloat16 else cast_pad16(x2, x2.shape[1]))
+    gemm(a, w_op, out, bias=bias, epilogue=epi, aux=pre if act == ACT_GELU else None, prec=prec)
 
 
-def _linear_bwd(dy2, x2, w_op, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False):
-    """dy2 [M,N] (strided rows ok), x2 [M,K], w_op [N,K] -> (dx [M,K], dW [N,K], db [N])."""
+def _linear_bwd(dy2, x2, weight, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False, dy16=None, dy16t=None,
+                x16t=None):
+    """dy2 [M,N] (strided rows ok), x2 [M,K], weight [N,K] parameter -> (dx [M,K], dW [N,K], db [N]).
+    bf16 mode routes both contractions through the NT fast kernel: dx = dy16[M,Np] * (W^T)16[K,Np]^T and
+    dW = (dy^T)16[N,Mp] * (x^T)16[K,Mp]^T, padding the reduction dimension with zeros to a multiple of 64."""
     M, N = dy2.shape
     K = x2.shape[1]
     dx = dw = db = None
+    fast = prec == "bf16"
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=torch.float32, device=dy2.device)
-        gemm(dy2, w_op, dx, b_kmajor=True, epilogue=L.EPI_ACCUM if dx_accumulate else 0, prec=prec)
+        epi = L.EPI_ACCUM if dx_accumulate else 0
+        if fast and N >= 64:
+            a = dy16 if dy16 is not None else cast_pad16(dy2)
+            gemm(a, weight_t16(weight), dx, epilogue=epi, prec=prec)
+        else:
+            gemm(dy2, weight_operand(weight, prec), dx, b_kmajor=True, epilogue=epi, prec=prec)
     if need_dw:
         dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
-        gemm(dy2, x2, dw, a_kmajor=True, b_kmajor=True, prec=prec)
+        if fast and M >= 64 and N >= 8 and K >= 8:
+            a = dy16t if dy16t is not None else cast_t16(dy2)
+            b = x16t if x16t is not None else cast_t16(x2)
+            gemm(a, b, dw, prec=prec)
+        else:
+            gemm(dy2, x2, dw, a_kmajor=True, b_kmajor=True, prec=prec)
     if need_db:
         db = colsum(dy2)
     return dx, dw, db
@@ -192,7 +254,9 @@ class LinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         N = weight.shape[0]
         w_op = weight_operand(weight, prec)
-        y = empty_rows(x2.shape[0], N, x.device)
+        # wide odd-width outputs (the 30522-column MLM logits) get a padded row stride so that they can feed the
+        # backward GEMMs as 16-byte aligned operands; everything else is plain contiguous
+        y = empty_rows(x2.shape[0], N, x.device) if (N % 4 and N >= 256) else torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device)
         pre = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device) if act == ACT_GELU else None
         _linear_fwd(x2, w_op, bias.detach() if bias is not None else None, y, act, prec, pre)
         ctx.save_for_backward(x2, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
@@ -211,7 +275,7 @@ class LinearFn(torch.autograd.Function):
             L.check(L.load().hamt_act_bwd(dy2.numel(), _p(dy2), _p(h), ctx.act, _p(dh), _stream()), "hamt_act_bwd")
             dy2 = dh
         dy2 = _operand(dy2)
-        dx, dw, db = _linear_bwd(dy2, x2, weight_operand(weight, ctx.prec), ctx.prec, ctx.needs_input_grad[0],
+        dx, dw, db = _linear_bwd(dy2, x2, weight, ctx.prec, ctx.needs_input_grad[0],
                                  ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None, None
 
@@ -235,9 +299,10 @@ class PackedLinearFn(torch.autograd.Function):
         ws, bs = wb[0::2], wb[1::2]
         ns = [w.shape[0] for w in ws]
         out = torch.empty(x2.shape[0], sum(ns), dtype=torch.float32, device=x.device)
+        x16 = cast_pad16(x2, K) if (prec == "bf16" and _fast_ok(K) and x2.dtype == torch.float32) else None
         c = 0
         for w, b, n in zip(ws, bs, ns):
-            _linear_fwd(x2, weight_operand(w, prec), b.detach(), out[:, c:c + n], ACT_NONE, prec)
+            _linear_fwd(x2, weight_operand(w, prec), b.detach(), out[:, c:c + n], ACT_NONE, prec, x16=x16)
             c += n
         ctx.save_for_backward(x2, *ws)
         ctx.prec, ctx.ns, ctx.xshape = prec, ns, x.shape
@@ -248,12 +313,17 @@ class PackedLinearFn(torch.autograd.Function):
         x2, *ws = ctx.saved_tensors
         dout = dout.contiguous()
         grads = []
-        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dx = torch.empty(x2.shape, dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[0] else None
+        M = x2.shape[0]
+        fast = ctx.prec == "bf16" and all(n % 64 == 0 for n in ctx.ns) and M >= 64
+        d16 = cast_pad16(dout, dout.shape[1]) if fast else None          # [M, sum n]
+        d16t = cast_t16(dout) if fast else None                           # [sum n, Mpad]
+        x16t = cast_t16(x2) if fast else None                             # [K, Mpad]
         c = 0
         for i, (w, n) in enumerate(zip(ws, ctx.ns)):
             dy2 = dout[:, c:c + n]
-            _, dw, db = _linear_bwd(dy2, x2, weight_operand(w, ctx.prec), ctx.prec, dx is not None, True, True,
-                                    dx_out=dx, dx_accumulate=i > 0)
+            _, dw, db = _linear_bwd(dy2, x2, w, ctx.prec, dx is not None, True, True, dx_out=dx, dx_accumulate=i > 0,
+                                    dy16=d16[:, c:c + n] if fast else None, dy16t=d16t[c:c + n] if fast else None, x16t=x16t)
             grads += [dw, db]
             c += n
         return (dx.view(ctx.xshape) if dx is not None else None), None, *grads
@@ -579,7 +649,9 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, label):
         _chk(x, "CrossEntropyFn")
-        assert x.dim() == 2 and x.stride(1) == 1
+        assert x.dim() == 2
+        if x.stride(1) != 1:
+            x = x.contiguous()
         R, Cc = x.shape
         label = label.contiguous()
         loss = torch.empty(R, dtype=torch.float32, device=x.device)
@@ -626,7 +698,9 @@ class KlFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, t):
         _chk(x, "KlFn")
-        assert x.dim() == 2 and x.stride(1) == 1
+        assert x.dim() == 2
+        if x.stride(1) != 1:
+            x = x.contiguous()
         t = t.contiguous().to(torch.float32)
         R, Cc = x.shape
         loss = torch.empty(R, dtype=torch.float32, device=x.device)

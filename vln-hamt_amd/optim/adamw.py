@@ -62,6 +62,12 @@ class AdamW(Optimizer):
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
 
+    def materialize(self):
+        """Build the flat arenas now (re-homes p.data); call before wrapping the model in DDP."""
+        if self._flat is None:
+            self._build()
+        return self
+
     def _pack_grads(self):
         """Copy the autograd-produced gradients into the flat arenas (one fused multi-tensor copy per group)."""
         if self._flat is None:
