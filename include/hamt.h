@@ -69,6 +69,12 @@ typedef struct {
 } hamt_gemm_desc;
 int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
               void* aux, void* stream);
+/* Same, with a caller-provided fp32 workspace that enables deterministic split-K for small outputs with a long
+ * reduction (weight gradients: dW[768,768] = dY^T X over K = B*L rows).  hamt_gemm_ksplit() tells how many K
+ * slices S the kernel would use for `d`; pass ws_bytes >= S*M*N*4 (less => fewer slices; NULL => no split). */
+int hamt_gemm_ksplit(const hamt_gemm_desc* d);
+int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                 void* aux, void* ws, size_t ws_bytes, void* stream);
 
 /* operand preparation for the bf16 fast path (both GEMM operands bf16, K-contiguous, K % 64 == 0):
  *   cast_pad_bf16:   y[R][Cpad] (bf16) = x[R][C] (fp32), columns >= C zero filled

@@ -40,6 +40,8 @@ SIGNATURES = {
     "hamt_version": [],
     "hamt_last_error": [C.c_char_p, sz],
     "hamt_gemm": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp],
+    "hamt_gemm_ksplit": [C.POINTER(GemmDesc)],
+    "hamt_gemm_ws": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, sz, vp],
     "hamt_cast_pad_bf16": [i32, i32, i32, vp, i32, vp, i32, vp],
     "hamt_cast_transpose": [i32, i32, vp, i32, i32, vp, i32, i32, vp],
     "hamt_colsum": [i32, i32, vp, i32, i32, vp, i32, vp, vp],

@@ -349,14 +349,28 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int R, int N, cons
 }  // namespace
 
 bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void* B);
-void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux, hipStream_t s);
+int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes);
+void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux, float* ws,
+                           size_t ws_bytes, hipStream_t s);
 
 void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, s, R, N, ws, out, accumulate);
 }
 
+extern "C" int hamt_gemm_ksplit(const hamt_gemm_desc* d) {
+  if (!d || d->prec != HAMT_PREC_BF16 || d->dtype_a != HAMT_BF16 || d->dtype_b != HAMT_BF16 || d->a_kmajor || d->b_kmajor ||
+      d->K < 64 || d->K % 64)
+    return 1;
+  return hamt_gemm_fast_ksplit(d, (size_t)-1);
+}
+
 extern "C" int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
                          void* stream) {
+  return hamt_gemm_ws(d, A, B, C, bias, aux, nullptr, 0, stream);
+}
+
+extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
+                            void* ws, size_t ws_bytes, void* stream) {
   HAMT_CHECK_ARG(d && A && B && C, "hamt_gemm: null pointer");
   HAMT_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "hamt_gemm: negative size");
   if (d->M == 0 || d->N == 0) return HAMT_OK;
@@ -369,7 +383,7 @@ extern "C" int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, 
   hipStream_t s = as_stream(stream);
   static const bool no_fast = getenv("HAMT_NO_FAST") != nullptr;
   if (!no_fast && hamt_gemm_fast_eligible(d, A, B)) {  // bf16 x bf16, K-contiguous operands, K % 64 == 0
-    hamt_gemm_fast_launch(d, A, B, C, bias, aux, s);
+    hamt_gemm_fast_launch(d, A, B, C, bias, aux, (float*)ws, ws_bytes, s);
     HAMT_CHECK_LAUNCH("hamt_gemm(fast)");
     return HAMT_OK;
   }

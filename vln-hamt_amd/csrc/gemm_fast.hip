@@ -4,16 +4,22 @@
 // dgrad: dY16 * (W^T)16^T; wgrad: (dY^T)16 * (X^T)16^T -- transposed bf16 copies come from
 // hamt_cast_transpose), so ONE kernel needs tuning.
 //
-// Structure (cdna_hip_programming.md section 5, "step 3" + T2 swizzle):
-//   * 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 fragments of
-//     v_mfma_f32_16x16x32_bf16, fp32 accumulators (64 VGPRs);
-//   * operands go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR
-//     round trip), two LDS stages (2 x 32 KiB), next tile's DMA issued before the current tile's MFMAs;
+// Structure (cdna_hip_programming.md section 5: glds staging, T2 swizzle, T3/T4 counted waits):
+//   * BMx128x64 tile (BM = 128 or 64), 256 threads = 4 waves (2x2); each wave (BM/2)x64 output as fragments of
+//     v_mfma_f32_16x16x32_bf16 with the operand roles SWAPPED (mfma(B,A)): a lane then owns 4 consecutive
+//     columns of one C row, so the epilogue stores 16 bytes per lane instead of four 4-byte scatters;
+//   * operands go L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR round
+//     trip) into a 3-stage ring; tile kt+2 is issued while tile kt is multiplied and the wait is a COUNTED
+//     s_waitcnt vmcnt(n) in front of a raw s_barrier, so one tile stays in flight across every barrier;
 //   * LDS image is lane-linear per DMA instruction (8 rows x 128 B); the 16-byte k-chunk index is XOR-swizzled
 //     with (row & 7) on the SOURCE address and on the fragment read (conflict-free ds_read_b128);
-//   * ragged M/N: row indices are clamped for the loads (no OOB), the epilogue masks the stores;
-//   * blockIdx -> tile mapping keeps the tiles that share an A row-panel on one XCD (private L2).
+//   * ragged M/N: row indices are clamped for the loads (no OOB access), the epilogue masks the stores;
+//   * split-K (grid.y slices of the K loop writing fp32 partial tiles, summed by a second kernel in a fixed
+//     order) for the weight-gradient shapes: 768x768 outputs with K = B*L >= 5120 would otherwise use 36 CUs;
+//   * the epilogue is compiled per flag set (template) -- a dynamic one unrolled 64x overflowed the I-cache.
 #include "common.h"
+
+void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s);
 
 struct GemmArgsF {
   int M, N, K, lda, ldb, ldc, ldaux;
@@ -24,6 +30,8 @@ struct GemmArgsF {
   void* C;
   const float* bias;
   void* aux;
+  int ksplit;      // number of K slices (grid.y); > 1 => raw fp32 partials to `part`
+  float* part;
 };
 
 namespace {
@@ -31,47 +39,28 @@ namespace {
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_ELEMS = BM * BK;  // per operand per stage (bf16 elements) = 16 KiB
+constexpr int BN = 128, BK = 64, NSTAGE = 3;
 
-__device__ __forceinline__ void epi_store_f(const GemmArgsF& g, int row, int col, float acc) {
-  if (row >= g.M || col >= g.N) return;
-  float v = acc * g.alpha;
-  if (g.epi & HAMT_EPI_BIAS) v += g.bias[col];
-  const size_t ia = (size_t)row * g.ldaux + col;
-  if (g.epi & HAMT_EPI_SAVE_PRE) {
-    if (g.dtype_aux == HAMT_BF16) ((bf16_t*)g.aux)[ia] = f2bf(v); else ((float*)g.aux)[ia] = v;
-  }
-  if (g.epi & HAMT_EPI_GELU) v = gelu_erf(v);
-  if (g.epi & HAMT_EPI_RELU) v = fmaxf(v, 0.0f);
-  if (g.epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
-    const float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
-    v *= (g.epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h) : (h > 0.0f ? 1.0f : 0.0f);
-  }
-  const size_t ic = (size_t)row * g.ldc + col;
-  if (g.dtype_c == HAMT_BF16) {
-    bf16_t* c = (bf16_t*)g.C;
-    if (g.epi & HAMT_EPI_ACCUM) v += bf2f(c[ic]);
-    c[ic] = f2bf(v);
-  } else {
-    float* c = (float*)g.C;
-    if (g.epi & HAMT_EPI_ACCUM) v += c[ic];
-    c[ic] = v;
-  }
-}
-
-// DMA one operand tile (128 rows x 64 k) into LDS: wave w moves rows [32w, 32w+32) with 4 instructions.
+// DMA `rows` rows x 64 k of an operand into LDS; every wave-instruction moves 8 rows (64 lanes x 16 B).
+template <int ROWS>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, bf16_t* lds, int w,
                                            int lane) {
+  constexpr int PER_WAVE = ROWS / 4;            // rows per wave
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rbase = w * 32 + j * 8;              // wave-uniform
-    const int r = rbase + (lane >> 3);             // tile row of this lane
-    const int chunk = (lane & 7) ^ (r & 7);        // source k-chunk that lands in LDS slot (lane & 7)
+  for (int j = 0; j < PER_WAVE / 8; ++j) {
+    const int rbase = w * PER_WAVE + j * 8;      // wave-uniform
+    const int r = rbase + (lane >> 3);           // tile row of this lane
+    const int chunk = (lane & 7) ^ (r & 7);      // source k-chunk that lands in LDS slot (lane & 7)
     int gr = r0 + r;
-    gr = gr < rmax ? gr : rmax;                    // clamp: rows past the edge re-read the last valid row
+    gr = gr < rmax ? gr : rmax;                  // clamp: rows past the edge re-read the last valid row
     const bf16_t* src = P + (size_t)gr * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(lds + rbase * BK), 16, 0, 0);
+    // Issued through inline asm on purpose: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first
+    // ds_read that follows a __builtin_amdgcn_global_load_lds it can see, which drains the prefetch of tile kt+2
+    // before tile kt is multiplied.  The DMA is ordered by the counted vmcnt + s_barrier in the main loop instead.
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)(lds + rbase * BK));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   }
 }
 
@@ -81,8 +70,59 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* lds, int r, int chunk) {
   return f.v;
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt();
+template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+
+// one row segment of 4 consecutive columns
+template <int EPI>
+__device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col, f32x4 acc) {
+  if (row >= g.M || col >= g.N) return;
+  const int epi = EPI >= 0 ? EPI : g.epi;
+  float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
+  const bool full = col + 4 <= g.N;
+  if (epi & HAMT_EPI_BIAS) {
+    if (full) { const float4 b = *(const float4*)(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    else for (int j = 0; j < 4; ++j) if (col + j < g.N) v[j] += g.bias[col + j];
+  }
+  const size_t ia = (size_t)row * g.ldaux + col, ic = (size_t)row * g.ldc + col;
+  if (epi & HAMT_EPI_SAVE_PRE) {
+    if (g.dtype_aux == HAMT_BF16) { for (int j = 0; j < 4; ++j) if (col + j < g.N) ((bf16_t*)g.aux)[ia + j] = f2bf(v[j]); }
+    else if (full && (g.ldaux & 3) == 0) *(float4*)((float*)g.aux + ia) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int j = 0; j < 4; ++j) if (col + j < g.N) ((float*)g.aux)[ia + j] = v[j];
+  }
+  if (epi & HAMT_EPI_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]); }
+  if (epi & HAMT_EPI_RELU) { for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f); }
+  if (epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
+    for (int j = 0; j < 4; ++j) if (col + j < g.N) {
+      const float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j];
+      v[j] *= (epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h) : (h > 0.0f ? 1.0f : 0.0f);
+    }
+  }
+  if (g.dtype_c == HAMT_BF16) {
+    bf16_t* c = (bf16_t*)g.C + ic;
+    if (epi & HAMT_EPI_ACCUM) { for (int j = 0; j < 4; ++j) if (col + j < g.N) v[j] += bf2f(c[j]); }
+    if (full && (g.ldc & 3) == 0) *(uint2*)c = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    else for (int j = 0; j < 4; ++j) if (col + j < g.N) c[j] = f2bf(v[j]);
+  } else {
+    float* c = (float*)g.C + ic;
+    if (full && (g.ldc & 3) == 0) {
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (epi & HAMT_EPI_ACCUM) { const float4 p = *(const float4*)c; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      *(float4*)c = o;
+    } else {
+      for (int j = 0; j < 4; ++j) if (col + j < g.N) c[j] = (epi & HAMT_EPI_ACCUM) ? c[j] + v[j] : v[j];
+    }
+  }
+}
+
+template <int BM, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmArgsF g) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TILE_ELEMS];  // [stage][A|B] = 64 KiB
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+  constexpr int FM = BM / 32;                    // 16-row fragments per wave along M (wave tile = BM/2 x 64)
+  constexpr int NLD = (BM + BN) / 32;            // glds instructions per wave per stage (8 or 6)
+  __shared__ __attribute__((aligned(16))) bf16_t lds[NSTAGE * STAGE];
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   // XCD-aware remap (blocks are dealt round-robin to the 8 XCDs): give each XCD a contiguous run of tile ids
@@ -92,46 +132,65 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmArgsF g) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-  f32x4 acc[4][4];
+  // K range of this slice
+  const int nk_all = g.K / BK;
+  const int kt0 = (int)((long)nk_all * blockIdx.y / g.ksplit), kt1 = (int)((long)nk_all * (blockIdx.y + 1) / g.ksplit);
+  const int nk = kt1 - kt0;
+
+  f32x4 acc[FM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / BK;
-  stage_tile(g.A, g.lda, m0, g.M - 1, 0, lds, w, lane);
-  stage_tile(g.B, g.ldb, n0, g.N - 1, 0, lds + TILE_ELEMS, w, lane);
-  __syncthreads();  // (compiler drains vmcnt before the barrier while LDS-DMA is in flight)
+  auto stage = [&](int kt, int slot) {
+    bf16_t* dst = lds + slot * STAGE;
+    stage_tile<BM>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, dst, w, lane);
+    stage_tile<BN>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, dst + A_ELEMS, w, lane);
+  };
+  if (nk > 0) stage(0, 0);
+  if (nk > 1) stage(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    const bf16_t* As = lds + (kt & 1) * 2 * TILE_ELEMS;
-    const bf16_t* Bs = As + TILE_ELEMS;
-    if (kt + 1 < nk) {
-      bf16_t* An = lds + ((kt + 1) & 1) * 2 * TILE_ELEMS;
-      stage_tile(g.A, g.lda, m0, g.M - 1, (kt + 1) * BK, An, w, lane);
-      stage_tile(g.B, g.ldb, n0, g.N - 1, (kt + 1) * BK, An + TILE_ELEMS, w, lane);
-    }
+    // tile kt has landed when at most the NLD loads of tile kt+1 are still outstanding
+    if (kt + 1 < nk) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();               // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
+    if (kt + 2 < nk) stage(kt + 2, (kt + 2) % NSTAGE);   // overwrites the slot tile kt-1 was read from
+    const bf16_t* As = lds + (kt % NSTAGE) * STAGE;
+    const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[FM], bfr[4];
       const int chunk = 4 * s + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = frag(As, wm * 64 + i * 16 + (lane & 15), chunk);
+      for (int i = 0; i < FM; ++i) af[i] = frag(As, wm * (BM / 2) + i * 16 + (lane & 15), chunk);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bfr[j] = frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)   // swapped roles: D[n][m] => lane owns C[m = lane&15][n = 4*(lane>>4) .. +3]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  }
+  if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
+    float* P = g.part + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = m0 + wm * (BM / 2) + i * 16 + (lane & 15), col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (row < g.M) {
+          if (col + 4 <= g.N && (g.N & 3) == 0) *(float4*)(P + (size_t)row * g.N + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          else for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = acc[i][j][e];
+        }
+      }
+    return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        epi_store_f(g, m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r, n0 + wn * 64 + j * 16 + (lane & 15), acc[i][j][r]);
+      epi_store4<EPI>(g, m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
 }
 
 // ---------------------------------------------------------------- fp32/bf16 [R][C] -> bf16 [C][Rpad] (zero padded)
@@ -157,6 +216,19 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(int R, int C, const
   }
 }
 
+template <int BM>
+void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
+  const int e = g.epi;
+#define HAMT_L(E) hipLaunchKernelGGL((gemm_nt_fast_kernel<BM, E>), grid, dim3(256), 0, s, g)
+  if (e == 0) HAMT_L(0);
+  else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
+  else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_RELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_RELU);
+  else HAMT_L(-1);
+#undef HAMT_L
+}
+
 }  // namespace
 
 bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void* B) {
@@ -165,12 +237,33 @@ bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void*
          d->M >= 1 && d->N >= 1;
 }
 
+// K slices to use for this problem given `ws_bytes` of workspace (1 = no split).
+int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes) {
+  if (d->epilogue & ~HAMT_EPI_ACCUM) return 1;
+  if (d->dtype_c != HAMT_F32 || d->ldc != d->N) return 1;
+  const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+  const int nk = d->K / BK;
+  if (tiles >= 192 || nk < 16) return 1;
+  int s = (int)(384 / tiles);
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  while (s > 1 && (size_t)s * d->M * d->N * 4 > ws_bytes) --s;
+  return s < 2 ? 1 : s;
+}
+
 void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
-                           hipStream_t s) {
+                           float* ws, size_t ws_bytes, hipStream_t s) {
   GemmArgsF g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha,
-              (const bf16_t*)A, (const bf16_t*)B, C, bias, aux};
-  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_nt_fast_kernel, dim3(tiles), dim3(256), 0, s, g);
+              (const bf16_t*)A, (const bf16_t*)B, C, bias, aux, 1, nullptr};
+  const int ks = ws ? hamt_gemm_fast_ksplit(d, ws_bytes) : 1;
+  const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+  static const int force_bm = getenv("HAMT_FAST_BM") ? atoi(getenv("HAMT_FAST_BM")) : 0;
+  const bool bm64 = force_bm ? force_bm == 64 : (t128 * ks < 384);   // fewer than 1.5 blocks per CU: halve the tile height
+  g.ksplit = ks;
+  g.part = ks > 1 ? ws : nullptr;
+  if (bm64) launch_bm<64>(g, dim3(((d->M + 63) / 64) * ((d->N + BN - 1) / BN), ks), s);
+  else launch_bm<128>(g, dim3(((d->M + 127) / 128) * ((d->N + BN - 1) / BN), ks), s);
+  if (ks > 1) hamt_reduce_partials(ks, d->M * d->N, ws, (float*)C, (d->epilogue & HAMT_EPI_ACCUM) ? 1 : 0, s);
 }
 
 extern "C" int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dtype_x, void* y, int ldy, int Rpad, void* stream) {

@@ -115,7 +115,15 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, au
     d = L.GemmDesc(M, N, K, _ld(a), _ld(b), _ld(out), _ld(aux) if aux is not None else 0, int(a_kmajor), int(b_kmajor),
                    _dt(a), _dt(b), _dt(out), _dt(aux) if aux is not None else 0, _prec(prec),
                    epilogue | (L.EPI_BIAS if bias is not None else 0), alpha)
-    L.check(L.load().hamt_gemm(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux), _stream()), "hamt_gemm")
+    lib = L.load()
+    ks = 1
+    if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and not (a_kmajor or b_kmajor):
+        ks = lib.hamt_gemm_ksplit(C.byref(d))
+    if ks > 1:      # deterministic split-K: fp32 partial tiles in a scratch buffer, summed in slice order
+        ws = torch.empty(ks * M * N, dtype=torch.float32, device=out.device)
+        L.check(lib.hamt_gemm_ws(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux), _p(ws), ws.numel() * 4, _stream()), "hamt_gemm_ws")
+    else:
+        L.check(lib.hamt_gemm(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux), _stream()), "hamt_gemm")
     return out
 
 
