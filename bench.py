@@ -63,8 +63,8 @@ def time_gemm_roofline(batch, device, iters=30):
     (M = B*80 rows, N = 3072, K = 768; forward).  Algorithmic FLOPs = 2*M*N*K per launch."""
     from vln_hamt_amd import ops
     M, N, K = batch * L_TXT, FFN, H
-    a = torch.randn(M, K, device=device)
-    w = torch.randn(N, K, device=device).to(torch.bfloat16)
+    a = torch.randn(M, K, device=device).to(torch.bfloat16)      # operands as the step feeds them: bf16, K-contiguous
+    w = (torch.randn(N, K, device=device) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=device)
     out = torch.empty(M, N, device=device)
     for _ in range(5):
@@ -80,7 +80,7 @@ def time_gemm_roofline(batch, device, iters=30):
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": f"gemm_bf16_kernel<128,128,NT> M={M} N={N} K={K}", "avg_launch_us": round(ms * 1e3, 2)}
+            "kernel": f"gemm_nt_fast_kernel<128,BIAS> M={M} N={N} K={K} (text FFN-1 forward)", "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def cpu_baseline(budget_s=20.0, batch=16):
