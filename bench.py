@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU minibatch (ITM uses batch/2 originals, loader.py:130)")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--task", default="mix", help="mix (5:1:1:1:2:2 cycle) or one of mlm/sap/sar/sprel/mrc/itm")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1 only uses graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -182,9 +183,21 @@ def main():
         get_batch(s)
     log("batches resident in HBM")
     gstep = [0]
+    use_graph = (world == 1) and not args.no_graph
+    graphed = None
+    if use_graph:
+        from vln_hamt_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, max_grad_norm=5.0)
 
     def train_step(step):
         task, b = get_batch(step)
+        if graphed is not None:
+            gstep[0] += 1
+            lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
+            for g in opt.param_groups:
+                g["lr"] = lr
+            graphed.step((task, step % n_distinct), b, task)
+            return task, b["txt_ids"].shape[0]
         loss = net(b, task, True).mean()
         loss.backward()
         gstep[0] += 1
@@ -197,6 +210,9 @@ def main():
         ops.advance_rng_epoch(device)
         return task, b["txt_ids"].shape[0]
 
+    if graphed is not None and args.warmup < n_distinct:
+        log(f"note: warmup raised to {n_distinct} so that every (task, batch) graph is captured before the timed region")
+        args.warmup = n_distinct
     for s in range(args.warmup):
         t_ = time.perf_counter()
         tk, _ = train_step(s)
@@ -231,7 +247,7 @@ def main():
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if graphed is not None else "eager"},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -202,6 +202,13 @@ int hamt_sumsq(size_t n, const float* g, float* out, int accumulate, float* ws, 
 int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v, void* p16, const float* hyper,
                     const float* gnorm_sq, float beta1, float beta2, float eps, float weight_decay,
                     int zero_grad, void* stream);
+/* Whole-arena form: parameter i owns elements [ends[i-1], ends[i]) (offsets multiples of 8, n = ends[nparams-1]);
+ * hyp[4*i..4*i+3] = {lr, step_size, weight_decay, active}; parameters with active == 0 are skipped entirely (the
+ * reference's `if p.grad is None: continue`).  ends / hyp are DEVICE arrays refreshed by the host each step, so
+ * the launch itself is static (hipGraph-capturable). */
+int hamt_adamw_table(size_t n, float* p, float* g, float* m, float* v, void* p16, const int* ends,
+                     const float* hyp, int nparams, const float* gnorm_sq, float max_norm, float beta1,
+                     float beta2, float eps, int zero_grad, void* stream);
 /* g *= min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  -- standalone clip for torch-optimiser users */
 int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream);
 

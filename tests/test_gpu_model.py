@@ -284,3 +284,50 @@ def test_finetune_navcmt_modes_vs_reference_goldens(tag, extra, prec):
         errs[n] = rel_err(t, store[f"{tag}/{n}"])
     print(f"[finetune {tag} {prec}] " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
     assert max(errs.values()) <= TOL[prec], errs
+
+
+def test_graph_replay_matches_eager_steps(tiny):
+    """hipGraph-captured training steps (vln_hamt_amd.graph) == the same steps launched eagerly (dropout off so that
+    masks cannot differ; the rest is the same kernels, the optimizer table refreshed on the host per replay)."""
+    from vln_hamt_amd.graph import GraphedTrainStep
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+    store, cfg, sd = tiny
+
+    def make():
+        m = build(cfg, sd, "bf16", train=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        named = list(m.named_parameters())
+        groups = [{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+                  {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}]
+        return m, AdamW(groups, lr=1e-3, betas=(0.9, 0.98))
+
+    seq = ["sap", "mlm", "itm", "sap", "mlm", "itm", "mrc", "sap", "mrc"]
+    batches = {}
+    for t in set(seq):
+        b = make_batch(t, 4, cfg, seed=hash(t) % 1000, txt_len=20, hist_len=4, ragged=True, device=DEV)
+        if t == "itm":
+            r = make_itm_rng(b, seed=3)
+            b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+        batches[t] = b
+    m1, o1 = make()
+    for t in seq:
+        m1(batches[t], t, True).mean().backward()
+        clip_grad_norm_(m1.parameters(), 5.0, optimizer=o1)
+        o1.step()
+        o1.zero_grad()
+    m2, o2 = make()
+    gs = GraphedTrainStep(m2, o2, 5.0)
+    losses = []
+    for t in seq:
+        losses.append(float(gs.step(t, batches[t], t)))
+    torch.cuda.synchronize()
+    assert len(gs.graphs) == 4
+    worst = 0.0
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        worst = max(worst, float((a - b).abs().max()))
+    print(f"[graph vs eager] worst parameter difference after {len(seq)} steps: {worst:.2e}")
+    assert worst < 1e-5, worst

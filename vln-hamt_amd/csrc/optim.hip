@@ -67,6 +67,41 @@ __global__ __launch_bounds__(256) void adamw_kernel(size_t n, float* __restrict_
     if (p16) p16[i] = f2bf(P);
   }
 }
+// One launch for the whole arena: per-parameter hyper-parameters come from a device table
+// (ends[i] = exclusive end offset of parameter i, hyp[i] = {lr, step_size, weight_decay, active}); parameters with
+// active == 0 (grad is None this step -- the reference's `continue`, adamw.py:70-71) are left untouched.
+// Offsets are multiples of 8, so a 4-element chunk never straddles two parameters.
+__global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, bf16_t* __restrict__ p16, const int* __restrict__ ends,
+                                                          const float4* __restrict__ hyp, int nparams, const float* __restrict__ gnorm_sq,
+                                                          float max_norm, float b1, float b2, float eps, int zero_grad) {
+  const float coef = clip_coef(gnorm_sq, max_norm);
+  const size_t n4 = n >> 2;
+  const size_t per_block = (n4 + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per_block, hi = min(n4, lo + per_block);
+  // binary search: first parameter whose end is beyond this block's first element
+  int pi = 0;
+  {
+    int a = 0, b = nparams - 1;
+    const long e0 = (long)lo * 4;
+    while (a < b) { const int mid = (a + b) >> 1; if ((long)ends[mid] > e0) b = mid; else a = mid + 1; }
+    pi = a;
+  }
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const long e = (long)i * 4;
+    while (pi < nparams - 1 && e >= (long)ends[pi]) ++pi;
+    const float4 h = hyp[pi];
+    if (h.w == 0.f) continue;
+    float4 P = ((float4*)p)[i], G = ((float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+    adamw_one(P.x, G.x, M.x, V.x, coef, h.x, h.y, b1, b2, eps, h.z);
+    adamw_one(P.y, G.y, M.y, V.y, coef, h.x, h.y, b1, b2, eps, h.z);
+    adamw_one(P.z, G.z, M.z, V.z, coef, h.x, h.y, b1, b2, eps, h.z);
+    adamw_one(P.w, G.w, M.w, V.w, coef, h.x, h.y, b1, b2, eps, h.z);
+    ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p16) ((uint2*)p16)[i] = make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
+  }
+}
 __global__ void clip_scale_kernel(size_t n, float* __restrict__ g, const float* __restrict__ gnorm_sq, float max_norm) {
   const float coef = clip_coef(gnorm_sq, max_norm);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= coef;
@@ -95,6 +130,20 @@ extern "C" int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v,
   int nb = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
   hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v, (bf16_t*)p16, hyper, gnorm_sq, beta1, beta2, eps, weight_decay, zero_grad);
   HAMT_CHECK_LAUNCH("hamt_adamw_flat");
+  return HAMT_OK;
+}
+extern "C" int hamt_adamw_table(size_t n, float* p, float* g, float* m, float* v, void* p16, const int* ends, const float* hyp,
+                                int nparams, const float* gnorm_sq, float max_norm, float beta1, float beta2, float eps,
+                                int zero_grad, void* stream) {
+  HAMT_CHECK_ARG(p && g && m && v && ends && hyp && nparams > 0 && n % 4 == 0, "hamt_adamw_table: bad argument");
+  HAMT_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                 ((uintptr_t)p16 % 8) == 0 && ((uintptr_t)hyp % 16) == 0, "hamt_adamw_table: arenas must be 16-byte aligned");
+  if (n == 0) return HAMT_OK;
+  size_t b = (n / 4 + 2047) / 2048;
+  int nb = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  hipLaunchKernelGGL(adamw_table_kernel, dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v, (bf16_t*)p16, ends, (const float4*)hyp,
+                     nparams, gnorm_sq, max_norm, beta1, beta2, eps, zero_grad);
+  HAMT_CHECK_LAUNCH("hamt_adamw_table");
   return HAMT_OK;
 }
 extern "C" int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream) {

@@ -95,7 +95,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                 batch['hist_pano_img_fts'], batch['hist_pano_ang_fts'], batch['hist_masks'])
         ob = (batch['ob_img_fts'], batch['ob_ang_fts'], batch['ob_nav_types'], batch['ob_masks'])
         if task.startswith('mlm'):
-            return self.forward_mlm(*hist, batch['txt_labels'], compute_loss)
+            return self.forward_mlm(*hist, batch['txt_labels'], compute_loss, label_idx=batch['txt_label_idx'])
         elif task.startswith('sap'):
             return self.forward_sap(*hist, *ob, batch['ob_action_viewindex'], compute_loss)
         elif task.startswith('sar'):
@@ -103,7 +103,8 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
         elif task.startswith('sprel'):
             return self.forward_sprel(*hist, *ob, batch['sp_anchor_idxs'], batch['sp_targets'], compute_loss)
         elif task.startswith('mrc'):
-            return self.forward_mrc(*hist, batch['hist_mrc_masks'], batch['hist_img_probs'], compute_loss)
+            return self.forward_mrc(*hist, batch['hist_mrc_masks'], batch['hist_img_probs'], compute_loss,
+                                    mrc_idx=batch['hist_mrc_idx'])
         elif task.startswith('itm'):
             return self.forward_itm(*hist, 4, compute_loss, neg_idxs=batch['itm_neg_idxs'],
                                     shuffled_pos_ids=batch['itm_shuffled_pos_ids'])
@@ -112,14 +113,17 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
 
     # ---- A15
     def forward_mlm(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
-                    hist_masks, txt_labels, compute_loss):
+                    hist_masks, txt_labels, compute_loss, label_idx=None):
+        """`label_idx` (optional, int64 flat positions of the masked tokens in row-major order, e.g. built by the
+        collate on the host) avoids the device->host sync of boolean indexing, so the step is graph-capturable."""
         txt_embeds, _, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
                                      hist_pano_ang_fts, hist_masks, None, None, None, None)
-        sel = txt_labels != -1
-        masked_output = self._compute_masked_hidden(txt_embeds, sel)
+        if label_idx is None:
+            label_idx = (txt_labels != -1).reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        masked_output = ops.gather_rows(txt_embeds.reshape(-1, txt_embeds.size(-1)), label_idx)
         prediction_scores = self.mlm_head(masked_output)
         if compute_loss:
-            return ops.cross_entropy(prediction_scores, txt_labels[sel])
+            return ops.cross_entropy(prediction_scores, txt_labels.reshape(-1).index_select(0, label_idx))
         return prediction_scores
 
     def _compute_masked_hidden(self, hidden, mask):
@@ -174,15 +178,18 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
 
     # ---- A19
     def forward_mrc(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
-                    hist_masks, hist_mrc_masks, hist_img_probs, compute_loss=True):
+                    hist_masks, hist_mrc_masks, hist_img_probs, compute_loss=True, mrc_idx=None):
+        """`mrc_idx` (optional): int64 flat positions b*T+t of the masked steps in row-major order (see forward_mlm)."""
         txt_embeds, hist_embeds, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
                                                hist_pano_ang_fts, hist_masks, None, None, None, None)
         B, T1, H = hist_embeds.shape
-        bt = hist_mrc_masks.nonzero(as_tuple=False)                 # (n, 2) row-major (b, t)
-        rows = bt[:, 0] * T1 + bt[:, 1] + 1                         # +1: drop the global cls slot (:232)
+        T = T1 - 1
+        if mrc_idx is None:
+            mrc_idx = hist_mrc_masks.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        rows = torch.div(mrc_idx, T, rounding_mode='floor') * T1 + mrc_idx % T + 1   # +1: drop the global cls slot (:232)
         masked_output = ops.gather_rows(hist_embeds.reshape(B * T1, H), rows)
         prediction_soft_labels = self.image_classifier(masked_output)
-        hist_mrc_targets = hist_img_probs[hist_mrc_masks]
+        hist_mrc_targets = hist_img_probs.reshape(B * T, -1).index_select(0, mrc_idx)
         if compute_loss:
             return ops.kl_div_logsoftmax(prediction_soft_labels, hist_mrc_targets)
         return prediction_soft_labels, hist_mrc_targets

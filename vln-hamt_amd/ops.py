@@ -149,9 +149,13 @@ def weight_operand(w: torch.Tensor, prec: str) -> torch.Tensor:
     wd = w.detach()
     if prec == "fp32":
         return wd
+    a = getattr(w, "_hamt_arena16", None)       # (bf16 view, fp32 arena, arena version at last sync): optim.AdamW
+    if a is not None and a[1]._version == a[2] and a[1].data_ptr() <= w.data_ptr() < a[1].data_ptr() + a[1].numel() * 4:
+        return a[0]
     c = getattr(w, "_hamt_w16", None)
-    if c is None or c[0] != w._version or c[1] != w.data_ptr():
-        c = (w._version, w.data_ptr(), cast_bf16(wd))
+    key = (w._version, _cache_epoch[0])
+    if c is None or c[0] != key or c[1] != w.data_ptr():
+        c = (key, w.data_ptr(), cast_bf16(wd))
         try:
             w._hamt_w16 = c
         except Exception:
@@ -189,11 +193,21 @@ def cast_t16(x2: torch.Tensor, rpad: Optional[int] = None) -> torch.Tensor:
     return y
 
 
+_cache_epoch = [0]
+
+
+def invalidate_weight_caches():
+    """Force every lazily cached weight shadow to be rebuilt at its next use (call right before capturing a graph so
+    that the rebuild kernels are part of the captured step)."""
+    _cache_epoch[0] += 1
+
+
 def weight_t16(w: torch.Tensor) -> torch.Tensor:
     """cached bf16 W^T [K, Npad64] of a [N,K] parameter (B operand of the dgrad dX = dY W in NT form)."""
     c = getattr(w, "_hamt_wt16", None)
-    if c is None or c[0] != w._version or c[1] != w.data_ptr():
-        c = (w._version, w.data_ptr(), cast_t16(w.detach()))
+    key = (w._version, _cache_epoch[0])
+    if c is None or c[0] != key or c[1] != w.data_ptr():
+        c = (key, w.data_ptr(), cast_t16(w.detach()))
         try:
             w._hamt_wt16 = c
         except Exception:

@@ -1,24 +1,34 @@
 """HF-style AdamW (pretrain_src/optim/adamw.py:13-112) as HIP kernels over flat fp32 arenas.
 
-On the first step the parameters of every group are re-homed into ONE contiguous fp32 arena per group
-(``p.data`` becomes a view; names, shapes and values are unchanged), with matching flat gradient / exp_avg /
-exp_avg_sq arenas.  ``step()`` then costs a handful of launches: gradients are packed into the arena, the
-update runs per maximal run of parameters that (a) received a gradient -- parameters with ``grad is None``
-are skipped like the reference's ``continue`` (:70-71) -- and (b) share a step count (bias correction :93-97).
-``clip_grad_norm_`` computes the global L2 norm on device (one reduction over the arena) and defers the
-scaling into the update kernel, so the clip costs no extra pass over the gradients.
+On the first step (or `materialize()`) every parameter is re-homed into ONE contiguous fp32 arena
+(``p.data`` becomes a view; names, shapes and values are unchanged), with matching flat gradient /
+exp_avg / exp_avg_sq arenas and a bf16 shadow arena that the update kernel refreshes in the same pass
+(the MFMA GEMMs read their weight operands from it, so no per-step cast of the weights is needed).
+
+``step()`` = three launches, independent of the number of parameters:
+  1. gradients are packed into the arena (one fused multi-tensor copy);
+  2. ``clip_grad_norm_`` reduces the global L2 norm on device and defers the scaling into the update;
+  3. ``hamt_adamw_table``: per-parameter {lr, bias-corrected step size, weight decay, active} come from a small
+     device table refreshed by the host each step.  Parameters whose ``grad is None`` are skipped like the
+     reference's ``continue`` (:70-71) and keep their own step count for the bias correction (:93-97).
+The launch sequence is static, so a whole training step can be captured in a hipGraph (`prepare_step` does the
+host part before a replay, `launch_step` is what gets captured).
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Iterable
+
+import numpy as np
+from typing import Iterable, List, Optional
 
 import torch
 from torch.optim import Optimizer
 
 from .. import _lib as L
 from ..ops import _p, _stream
+
+ALIGN = 8   # elements: keeps every tensor 32-byte aligned in the fp32 arenas and 16-byte aligned in the bf16 shadow
 
 
 class AdamW(Optimizer):
@@ -32,137 +42,151 @@ class AdamW(Optimizer):
         if not 0.0 <= eps:
             raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
-        self._flat = None          # per group: dict(p=, g=, m=, v=, offs=[...], steps=[...])
-        self._pending_clip = None  # (gnorm_sq device scalar, max_norm)
+        self._built = False
+        self._pending_clip = None   # (gnorm_sq device scalar, max_norm)
         self._packed = False
+        self._active: Optional[List[bool]] = None
 
     # ---------------------------------------------------------------- arenas
     def _build(self):
-        self._flat = []
-        for group in self.param_groups:
-            ps = [p for p in group["params"]]
-            if not ps:
-                self._flat.append(None)
-                continue
-            dev = ps[0].device
-            if not ps[0].is_cuda:
-                raise L.HamtError("AdamW: parameters must live on the GPU (no CPU fallback)")
-            offs, n = [], 0
-            for p in ps:
-                offs.append(n)
-                n += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned inside the arena
-            flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
-            for p, o in zip(ps, offs):
-                flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
-                p.data = flat_p[o:o + p.numel()].view(p.shape)
-            self._flat.append(dict(p=flat_p, g=torch.zeros_like(flat_p), m=torch.zeros_like(flat_p),
-                                   v=torch.zeros_like(flat_p), offs=offs, n=n, steps=[0] * len(ps), params=ps))
-        self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(3)
+        ps, gidx = [], []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                ps.append(p)
+                gidx.append(gi)
+        if not ps:
+            raise ValueError("AdamW: no parameters")
+        if not ps[0].is_cuda:
+            raise L.HamtError("AdamW: parameters must live on the GPU (no CPU fallback)")
+        b0 = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        for g in self.param_groups:
+            if (g["betas"], g["eps"]) != b0:
+                raise ValueError("AdamW: betas/eps must be the same in every group (they are in the reference)")
+        dev = ps[0].device
+        offs, n = [], 0
+        for p in ps:
+            offs.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self._params, self._gidx, self._offs, self._n = ps, gidx, offs, n
+        self._flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            self._flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self._flat_p[o:o + p.numel()].view(p.shape)
+        self._flat_g = torch.zeros_like(self._flat_p)
+        self._flat_m = torch.zeros_like(self._flat_p)
+        self._flat_v = torch.zeros_like(self._flat_p)
+        self._flat_p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        L.check(L.load().hamt_cast_f32_bf16(n, _p(self._flat_p), _p(self._flat_p16), _stream()), "hamt_cast_f32_bf16")
+        self._steps = np.zeros(len(ps), dtype=np.int64)
+        self._gidx_np = np.asarray(gidx, dtype=np.int64)
+        ends = [o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN for p, o in zip(ps, offs)]
+        self._ends = torch.tensor(ends, dtype=torch.int32, device=dev)
+        # ring of pinned staging buffers: the async H2D copy of step k must have run before its slot is rewritten
+        self._hyp_ring = [torch.zeros(len(ps), 4, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._hyp_events = [None] * 4
+        self._hyp_slot = 0
+        self._hyp = torch.zeros(len(ps), 4, dtype=torch.float32, device=dev)
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._sync_shadow_views()
+        self._built = True
+
+    def _sync_shadow_views(self):
+        """Publish the bf16 shadow of every >=2-D parameter as the GEMM weight operand (see ops.weight_operand)."""
+        ver = self._flat_p._version
+        for p, o in zip(self._params, self._offs):
+            if p.dim() >= 2:
+                p._hamt_arena16 = (self._flat_p16[o:o + p.numel()].view(p.shape), self._flat_p, ver)
 
     def materialize(self):
-        """Build the flat arenas now (re-homes p.data); call before wrapping the model in DDP."""
-        if self._flat is None:
+        """Build the flat arenas now (re-homes p.data); call before wrapping the model in DDP / capturing a graph."""
+        if not self._built:
             self._build()
         return self
 
     def _pack_grads(self):
-        """Copy the autograd-produced gradients into the flat arenas (one fused multi-tensor copy per group)."""
-        if self._flat is None:
-            self._build()
-        for fl in self._flat:
-            if fl is None:
-                continue
-            src, dst = [], []
-            for p, o in zip(fl["params"], fl["offs"]):
-                if p.grad is not None:
-                    src.append(p.grad.reshape(-1))
-                    dst.append(fl["g"][o:o + p.numel()])
-            fl["active"] = [p.grad is not None for p in fl["params"]]
-            if src:
-                torch._foreach_copy_(dst, src)
+        """Copy the autograd-produced gradients into the flat arena (one fused multi-tensor copy)."""
+        self.materialize()
+        src, dst, active = [], [], []
+        for p, o in zip(self._params, self._offs):
+            a = p.grad is not None
+            active.append(a)
+            if a:
+                src.append(p.grad.reshape(-1))
+                dst.append(self._flat_g[o:o + p.numel()])
+        if src:
+            torch._foreach_copy_(dst, src)
+        self._active = active
         self._packed = True
 
     def global_grad_sumsq(self) -> torch.Tensor:
-        """device scalar sum(g^2) over every parameter that has a gradient."""
-        self._pack_grads()
-        lib = L.load()
-        first = True
-        for fl in self._flat:
-            if fl is None:
-                continue
-            for (a, b) in self._runs(fl, by_step=False):
-                L.check(lib.hamt_sumsq(b - a, C.c_void_p(fl["g"].data_ptr() + 4 * a), _p(self._gnorm), int(not first),
-                                       _p(self._ws), _stream()), "hamt_sumsq")
-                first = False
-        if first:
-            self._gnorm.zero_()
+        """device scalar sum(g^2) over every parameter that has a gradient (slots of the others are zero)."""
+        if not self._packed:
+            self._pack_grads()
+        L.check(L.load().hamt_sumsq(self._n, _p(self._flat_g), _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq")
         return self._gnorm
 
-    @staticmethod
-    def _runs(fl, by_step=True):
-        """maximal [start, end) element ranges of consecutive active parameters (sharing a step count)."""
-        runs, cur = [], None
-        ps, offs, act, steps = fl["params"], fl["offs"], fl["active"], fl["steps"]
-        for i, p in enumerate(ps):
-            if not act[i]:
-                if cur:
-                    runs.append(cur)
-                    cur = None
-                continue
-            end = offs[i + 1] if i + 1 < len(ps) else fl["n"]
-            if cur and (not by_step or cur[2] == steps[i]):
-                cur[1] = end
-            else:
-                if cur:
-                    runs.append(cur)
-                cur = [offs[i], end, steps[i], i]
-        if cur:
-            runs.append(cur)
-        return [(r[0], r[1]) if not by_step else tuple(r) for r in runs]
+    # ---------------------------------------------------------------- step = host part + launches
+    def prepare_step(self, active: Optional[List[bool]] = None):
+        """Host side of a step: advance the per-parameter step counts, refresh the device hyper-parameter table
+        (async copy from pinned memory on the current stream).  `active` defaults to "has a gradient now"."""
+        self.materialize()
+        if active is None:
+            active = self._active if self._active is not None else [p.grad is not None for p in self._params]
+        act = np.asarray(active, dtype=bool)
+        self._steps[act] += 1
+        t = np.maximum(self._steps, 1).astype(np.float64)
+        b1, b2 = self.param_groups[0]["betas"]
+        lr = np.array([g["lr"] for g in self.param_groups], dtype=np.float64)[self._gidx_np]
+        wd = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float64)[self._gidx_np]
+        cb = np.array([bool(g["correct_bias"]) for g in self.param_groups])[self._gidx_np]
+        ss = np.where(cb, lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t), lr)
+        k = self._hyp_slot
+        self._hyp_slot = (k + 1) % len(self._hyp_ring)
+        if self._hyp_events[k] is not None:
+            self._hyp_events[k].synchronize()   # only blocks when the GPU is >= 4 steps behind the host
+        h = self._hyp_ring[k].numpy()           # pinned memory, shared with the tensor
+        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, act
+        self._hyp.copy_(self._hyp_ring[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyp_events[k] = ev
 
-    # ---------------------------------------------------------------- step
+    def launch_step(self, zero_grad_arena: bool = True):
+        """Device side of a step (static launch sequence; capturable)."""
+        b1, b2 = self.param_groups[0]["betas"]
+        gn, max_norm = self._pending_clip if self._pending_clip is not None else (None, 0.0)
+        L.check(L.load().hamt_adamw_table(self._n, _p(self._flat_p), _p(self._flat_g), _p(self._flat_m), _p(self._flat_v),
+                                          _p(self._flat_p16), _p(self._ends), _p(self._hyp), len(self._params), _p(gn),
+                                          float(max_norm), b1, b2, self.param_groups[0]["eps"], int(zero_grad_arena), _stream()),
+                "hamt_adamw_table")
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if not self._packed:
             self._pack_grads()
-        lib = L.load()
-        gn, max_norm = (self._pending_clip if self._pending_clip is not None else (None, 0.0))
-        touched = []
-        for group, fl in zip(self.param_groups, self._flat):
-            if fl is None:
-                continue
-            b1, b2 = group["betas"]
-            for i, a in enumerate(fl["active"]):
-                if a:
-                    fl["steps"][i] += 1
-            for (s, e, t, _) in self._runs(fl, by_step=True):
-                step_size = group["lr"]
-                if group["correct_bias"]:
-                    step_size = step_size * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-                self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = group["lr"], step_size, max_norm
-                hyper = self._hyper_host.to(self._hyper.device, non_blocking=False)   # tiny H2D; value frozen per launch
-                off = 4 * s
-                L.check(lib.hamt_adamw_flat(e - s, C.c_void_p(fl["p"].data_ptr() + off), C.c_void_p(fl["g"].data_ptr() + off),
-                                            C.c_void_p(fl["m"].data_ptr() + off), C.c_void_p(fl["v"].data_ptr() + off), None,
-                                            _p(hyper), _p(gn), b1, b2, group["eps"], group["weight_decay"], 0, _stream()),
-                        "hamt_adamw_flat")
-            touched.append(fl["p"])
-        for t in touched:                       # parameters changed outside autograd's view: bump versions so
-            torch.autograd.graph.increment_version(t)   # cached bf16 weight shadows are refreshed
+        self.prepare_step()
+        self.launch_step()
+        self.mark_updated()
+        return loss
+
+    def mark_updated(self):
+        """Parameters changed outside autograd's view: bump the version counter (cached transposed shadows are
+        rebuilt lazily) and re-publish the bf16 shadow written by the update kernel."""
+        torch.autograd.graph.increment_version(self._flat_p)
+        self._sync_shadow_views()
         self._pending_clip = None
         self._packed = False
-        return loss
+        self._active = None
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
         self._packed = False
 
-    def flat_state(self):
-        return self._flat
+    @property
+    def active_mask(self):
+        return self._active
 
 
 def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, optimizer: AdamW = None) -> torch.Tensor:

@@ -68,6 +68,7 @@ def make_batch(task: str, batch_size: int, cfg, seed: int = 0, txt_len: int = 80
             labels[b, pick] = ids[b, pick]
             ids[b, pick] = 103 % cfg.vocab_size
         out["txt_labels"] = torch.from_numpy(labels)
+        out["txt_label_idx"] = torch.from_numpy(np.flatnonzero(labels.reshape(-1) != -1).astype(np.int64))
     out["txt_ids"] = torch.from_numpy(ids)
 
     # ---- history
@@ -125,6 +126,7 @@ def make_batch(task: str, batch_size: int, cfg, seed: int = 0, txt_len: int = 80
         img[m] = 0.0                                              # masked step features are zeroed
         out["hist_img_fts"] = torch.from_numpy(img)
         out["hist_mrc_masks"] = torch.from_numpy(m)
+        out["hist_mrc_idx"] = torch.from_numpy(np.flatnonzero(m.reshape(-1)).astype(np.int64))
         out["hist_img_probs"] = torch.from_numpy(probs)
 
     if device != "cpu":
