@@ -66,6 +66,8 @@ typedef struct {
   int prec;                                 /* hamt_prec  */
   int epilogue;                             /* HAMT_EPI_* */
   float alpha;
+  int ka_rows, kb_rows; /* K-strided operands only: number of valid reduction rows actually stored in A / B when K was
+                           rounded up for the other operand (0 = K).  Rows beyond are never dereferenced. */
 } hamt_gemm_desc;
 int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
               void* aux, void* stream);
@@ -77,10 +79,10 @@ int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* B, void* C,
                  void* aux, void* ws, size_t ws_bytes, void* stream);
 
 /* operand preparation for the bf16 fast path (both GEMM operands bf16, K-contiguous, K % 64 == 0):
- *   cast_pad_bf16:   y[R][Cpad] (bf16) = x[R][C] (fp32), columns >= C zero filled
+ *   cast_pad_bf16:   y[Rpad][Cpad] (bf16) = x[R][C] (fp32), rows >= R and columns >= C zero filled
  *   cast_transpose:  y[C][Rpad] (bf16) = x[R][C]^T (fp32 or bf16 source), rows >= R zero filled
  * (dgrad uses the transposed weight, wgrad the transposed activations / gradients.) */
-int hamt_cast_pad_bf16(int R, int C, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream);
+int hamt_cast_pad_bf16(int R, int C, int Rpad, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream);
 int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dtype_x, void* y, int ldy, int Rpad, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */

@@ -82,6 +82,25 @@ def test_gemm_bf16(layout, shape, dts):
     close(out, A.double() @ B.double(), 2e-2, f"gemm bf16(fp32 ref) {layout} {shape}")
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn"])
+@pytest.mark.parametrize("shape", [(300, 200, 768), (129, 1000, 128), (768, 768, 5120), (70, 3072, 640), (200, 30522 // 8, 256)])
+def test_gemm_fast_kstrided_layouts(layout, shape):
+    """bf16 x bf16 NN / TN through the glds + ds_read_b64_tr_b16 fast kernel (incl. ragged reduction rows)."""
+    ops = _ops()
+    M, N, K = shape
+    A, B, a_st, b_st, a_km, b_km = _mk(layout, M, N, K, 11)
+    ref = bf16_round(A).double() @ bf16_round(B).double()
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(a_st.to(DEV).to(torch.bfloat16), b_st.to(DEV).to(torch.bfloat16), out, a_kmajor=a_km, b_kmajor=b_km, prec="bf16")
+    close(out, ref, 2e-5 * math.sqrt(K) / 4, f"fast {layout} {shape}")
+    # ragged reduction: K-strided B stores only K-5 rows while the (zero padded) A defines K
+    if layout == "nn":
+        Az = A.clone()
+        Az[:, K - 5:] = 0
+        ops.gemm(Az.to(DEV).to(torch.bfloat16), b_st[:K - 5].contiguous().to(DEV).to(torch.bfloat16), out, b_kmajor=True, prec="bf16", k_red=K)
+        close(out, bf16_round(Az).double() @ bf16_round(B).double(), 2e-5 * math.sqrt(K) / 4, "fast nn ragged K")
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_gemm_epilogues(prec):
     ops = _ops()
@@ -144,7 +163,8 @@ def test_cast_pad_and_transpose_exact():
     ops = _ops()
     x = rnd(77, 100, seed=1)
     y = ops.cast_pad16(x.to(DEV))
-    assert y.shape == (77, 128) and torch.equal(y[:, :100].float().cpu(), bf16_round(x)) and float(y[:, 100:].float().abs().max()) == 0
+    assert y.shape == (128, 128) and torch.equal(y[:77, :100].float().cpu(), bf16_round(x))
+    assert float(y[:, 100:].float().abs().max()) == 0 and float(y[77:].float().abs().max()) == 0
     buf = torch.zeros(77, 104, device=DEV)
     buf[:, 1:101] = x.to(DEV)                                   # odd column offset: unaligned rows take the scalar path
     assert torch.equal(ops.cast_pad16(buf[:, 1:101]).cpu(), y.cpu())

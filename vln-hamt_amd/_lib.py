@@ -22,7 +22,7 @@ vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 class GemmDesc(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldaux", i32),
                 ("a_kmajor", i32), ("b_kmajor", i32), ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
-                ("dtype_aux", i32), ("prec", i32), ("epilogue", i32), ("alpha", f32)]
+                ("dtype_aux", i32), ("prec", i32), ("epilogue", i32), ("alpha", f32), ("ka_rows", i32), ("kb_rows", i32)]
 
 
 class AttnDesc(C.Structure):
@@ -42,7 +42,7 @@ SIGNATURES = {
     "hamt_gemm": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp],
     "hamt_gemm_ksplit": [C.POINTER(GemmDesc)],
     "hamt_gemm_ws": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, sz, vp],
-    "hamt_cast_pad_bf16": [i32, i32, i32, vp, i32, vp, i32, vp],
+    "hamt_cast_pad_bf16": [i32, i32, i32, i32, vp, i32, vp, i32, vp],
     "hamt_cast_transpose": [i32, i32, vp, i32, i32, vp, i32, i32, vp],
     "hamt_colsum": [i32, i32, vp, i32, i32, vp, i32, vp, vp],
     "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],

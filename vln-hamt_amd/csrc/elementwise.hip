@@ -136,13 +136,14 @@ __global__ void cast_bf16_kernel(size_t n8, size_t n, const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[n8 * 8 + threadIdx.x] = f2bf(x[n8 * 8 + threadIdx.x]);
 }
 // fp32 [R][C] -> bf16 [R][Cpad], columns >= C zero filled (reduction-dimension padding for the fast GEMM)
-__global__ void cast_pad_kernel(int R, int C, int Cpad, const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy) {
+__global__ void cast_pad_kernel(int R, int C, int Rpad, int Cpad, const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy) {
   const int c8 = Cpad >> 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * c8; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)Rpad * c8; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / c8), c = (int)(i % c8) * 8;
     const float* xr = x + (size_t)r * ldx + c;
     uint4 o;
-    if (c + 8 <= C && (((uintptr_t)xr) & 15) == 0) {
+    if (r >= R) o = make_uint4(0u, 0u, 0u, 0u);
+    else if (c + 8 <= C && (((uintptr_t)xr) & 15) == 0) {
       const float4 a = *(const float4*)xr, b = *(const float4*)(xr + 4);
       o = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
     } else {
@@ -281,10 +282,10 @@ extern "C" int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* strea
   HAMT_CHECK_LAUNCH("hamt_cast_f32_bf16");
   return HAMT_OK;
 }
-extern "C" int hamt_cast_pad_bf16(int R, int C, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream) {
-  HAMT_CHECK_ARG(x && y && Cpad % 8 == 0 && Cpad >= C && ldy >= Cpad && ldy % 8 == 0, "hamt_cast_pad_bf16: bad argument");
-  if (R == 0 || Cpad == 0) return HAMT_OK;
-  hipLaunchKernelGGL(cast_pad_kernel, dim3(nblocks((size_t)R * Cpad / 8)), dim3(256), 0, as_stream(stream), R, C, Cpad, x, ldx, (bf16_t*)y, ldy);
+extern "C" int hamt_cast_pad_bf16(int R, int C, int Rpad, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream) {
+  HAMT_CHECK_ARG(x && y && Cpad % 8 == 0 && Cpad >= C && Rpad >= R && ldy >= Cpad && ldy % 8 == 0, "hamt_cast_pad_bf16: bad argument");
+  if (Rpad == 0 || Cpad == 0) return HAMT_OK;
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(nblocks((size_t)Rpad * Cpad / 8)), dim3(256), 0, as_stream(stream), R, C, Rpad, Cpad, x, ldx, (bf16_t*)y, ldy);
   HAMT_CHECK_LAUNCH("hamt_cast_pad_bf16");
   return HAMT_OK;
 }

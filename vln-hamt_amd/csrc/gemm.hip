@@ -18,7 +18,9 @@
 namespace {
 
 struct GemmArgs {
-  int M, N, K, lda, ldb, ldc, ldaux;
+  int M, N, K, lda, ldb;
+  int ka_lim, kb_lim;   // valid reduction extent of A / B (<= K); beyond it the staging loads return zeros
+  int ldc, ldaux;
   int dtype_c, dtype_aux, epi;
   float alpha;
   const void* A;
@@ -115,16 +117,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   float ra[4], rb[4];
   const int nk = (g.K + F_BK - 1) / F_BK;
-  f32_stage_load<A_KM>(A, g.lda, m0, g.M, 0, g.K, t, ra);
-  f32_stage_load<B_KM>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
+  f32_stage_load<A_KM>(A, g.lda, m0, g.M, 0, g.ka_lim, t, ra);
+  f32_stage_load<B_KM>(B, g.ldb, n0, g.N, 0, g.kb_lim, t, rb);
   f32_stage_write<A_KM>(lds[0][0], t, ra);
   f32_stage_write<B_KM>(lds[0][1], t, rb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      f32_stage_load<A_KM>(A, g.lda, m0, g.M, (kt + 1) * F_BK, g.K, t, ra);
-      f32_stage_load<B_KM>(B, g.ldb, n0, g.N, (kt + 1) * F_BK, g.K, t, rb);
+      f32_stage_load<A_KM>(A, g.lda, m0, g.M, (kt + 1) * F_BK, g.ka_lim, t, ra);
+      f32_stage_load<B_KM>(B, g.ldb, n0, g.N, (kt + 1) * F_BK, g.kb_lim, t, rb);
     }
     const float* As = lds[cur][0];
     const float* Bs = lds[cur][1];
@@ -249,9 +251,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   uint4 ra[CA], rb[CB];
   const int nk = (g.K + H_BK - 1) / H_BK;
 #pragma unroll
-  for (int c = 0; c < CA; ++c) ra[c] = h_stage_load<TA, A_KM, BM>(A, g.lda, m0, g.M, 0, g.K, t + c * 256);
+  for (int c = 0; c < CA; ++c) ra[c] = h_stage_load<TA, A_KM, BM>(A, g.lda, m0, g.M, 0, g.ka_lim, t + c * 256);
 #pragma unroll
-  for (int c = 0; c < CB; ++c) rb[c] = h_stage_load<TB, B_KM, BN>(B, g.ldb, n0, g.N, 0, g.K, t + c * 256);
+  for (int c = 0; c < CB; ++c) rb[c] = h_stage_load<TB, B_KM, BN>(B, g.ldb, n0, g.N, 0, g.kb_lim, t + c * 256);
 #pragma unroll
   for (int c = 0; c < CA; ++c) h_stage_write<A_KM, BM>(lds, t + c * 256, ra[c]);
 #pragma unroll
@@ -262,9 +264,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     const bf16_t* Bs = As + A_SZ;
     if (kt + 1 < nk) {
 #pragma unroll
-      for (int c = 0; c < CA; ++c) ra[c] = h_stage_load<TA, A_KM, BM>(A, g.lda, m0, g.M, (kt + 1) * H_BK, g.K, t + c * 256);
+      for (int c = 0; c < CA; ++c) ra[c] = h_stage_load<TA, A_KM, BM>(A, g.lda, m0, g.M, (kt + 1) * H_BK, g.ka_lim, t + c * 256);
 #pragma unroll
-      for (int c = 0; c < CB; ++c) rb[c] = h_stage_load<TB, B_KM, BN>(B, g.ldb, n0, g.N, (kt + 1) * H_BK, g.K, t + c * 256);
+      for (int c = 0; c < CB; ++c) rb[c] = h_stage_load<TB, B_KM, BN>(B, g.ldb, n0, g.N, (kt + 1) * H_BK, g.kb_lim, t + c * 256);
     }
     bf16x8 af[FM], bf[FN];
 #pragma unroll
@@ -358,7 +360,7 @@ void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumul
 }
 
 extern "C" int hamt_gemm_ksplit(const hamt_gemm_desc* d) {
-  if (!d || d->prec != HAMT_PREC_BF16 || d->dtype_a != HAMT_BF16 || d->dtype_b != HAMT_BF16 || d->a_kmajor || d->b_kmajor ||
+  if (!d || d->prec != HAMT_PREC_BF16 || d->dtype_a != HAMT_BF16 || d->dtype_b != HAMT_BF16 || (d->a_kmajor && !d->b_kmajor) ||
       d->K < 64 || d->K % 64)
     return 1;
   return hamt_gemm_fast_ksplit(d, (size_t)-1);
@@ -379,7 +381,8 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
   HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
   HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
   HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) || aux, "hamt_gemm: epilogue needs aux");
-  GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
+  const int ka = (d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K, kb = (d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K;
+  GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, ka, kb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
   hipStream_t s = as_stream(stream);
   static const bool no_fast = getenv("HAMT_NO_FAST") != nullptr;
   if (!no_fast && hamt_gemm_fast_eligible(d, A, B)) {  // bf16 x bf16, K-contiguous operands, K % 64 == 0

@@ -32,6 +32,7 @@ struct GemmArgsF {
   void* aux;
   int ksplit;      // number of K slices (grid.y); > 1 => raw fp32 partials to `part`
   float* part;
+  int ka_max, kb_max;   // last valid reduction row of a K-strided A / B (rows beyond are clamped to it)
 };
 
 namespace {
@@ -41,32 +42,75 @@ typedef __attribute__((address_space(3))) void lptr_t;
 
 constexpr int BN = 128, BK = 64, NSTAGE = 3;
 
-// DMA `rows` rows x 64 k of an operand into LDS; every wave-instruction moves 8 rows (64 lanes x 16 B).
-template <int ROWS>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, bf16_t* lds, int w,
-                                           int lane) {
-  constexpr int PER_WAVE = ROWS / 4;            // rows per wave
+__device__ __forceinline__ void glds16(const bf16_t* src, unsigned dst_uniform) {
+  // Issued through inline asm on purpose: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first ds_read
+  // that follows a __builtin_amdgcn_global_load_lds it can see, which drains the prefetch of tile kt+2 before tile kt
+  // is multiplied.  The DMA is ordered by the counted vmcnt + s_barrier in the main loop instead.
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const bf16_t* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)p); }
+
+// XOR applied to the 16-byte chunk index of a k-strided ("col") tile row kk: keeps 32-byte pairs together (a tr-read
+// quad reads 32 contiguous bytes) and sends the 4 rows of a tr-read (and, for 256-byte rows, the sibling 16-lane
+// group 8 rows further) to different bank groups.
+template <int R> __device__ __forceinline__ int col_swz(int kk) {
+  return R == 128 ? (((kk & 3) | (((kk >> 3) & 1) << 2)) << 1) : ((kk & 3) << 1);
+}
+
+// DMA one operand tile into LDS; every wave-instruction moves 1 KiB (64 lanes x 16 B).
+//   KM == false: operand stored [rows][K] (K contiguous): tile image [R][64], 8 rows per instruction, chunk ^= row & 7
+//   KM == true : operand stored [K][cols] (K strided):    tile image [64][R], 1 KiB = 1024/(2R) k-rows per instruction
+// Out-of-range rows are clamped (re-read a valid row); see the callers for why that is harmless.
+template <bool KM, int R>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, int kmax, bf16_t* lds,
+                                           int w, int lane) {
+  if constexpr (!KM) {
+    constexpr int PER_WAVE = R / 4;              // tile rows per wave
 #pragma unroll
-  for (int j = 0; j < PER_WAVE / 8; ++j) {
-    const int rbase = w * PER_WAVE + j * 8;      // wave-uniform
-    const int r = rbase + (lane >> 3);           // tile row of this lane
-    const int chunk = (lane & 7) ^ (r & 7);      // source k-chunk that lands in LDS slot (lane & 7)
-    int gr = r0 + r;
-    gr = gr < rmax ? gr : rmax;                  // clamp: rows past the edge re-read the last valid row
-    const bf16_t* src = P + (size_t)gr * ld + k0 + chunk * 8;
-    // Issued through inline asm on purpose: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first
-    // ds_read that follows a __builtin_amdgcn_global_load_lds it can see, which drains the prefetch of tile kt+2
-    // before tile kt is multiplied.  The DMA is ordered by the counted vmcnt + s_barrier in the main loop instead.
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)(lds + rbase * BK));
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    for (int j = 0; j < PER_WAVE / 8; ++j) {
+      const int rbase = w * PER_WAVE + j * 8;    // wave-uniform
+      const int r = rbase + (lane >> 3);
+      const int chunk = (lane & 7) ^ (r & 7);    // source k-chunk that lands in LDS slot (lane & 7)
+      int gr = r0 + r;
+      gr = gr < rmax ? gr : rmax;
+      glds16(P + (size_t)gr * ld + k0 + chunk * 8, lds_addr(lds + rbase * BK));
+    }
+  } else {
+    constexpr int CH = R / 8;                    // 16-byte chunks per k-row (16 or 8)
+    constexpr int ROWS_PER_INSTR = 64 / CH;      // 4 or 8
+    constexpr int PER_WAVE = BK / 4;             // 16 k-rows per wave
+#pragma unroll
+    for (int j = 0; j < PER_WAVE / ROWS_PER_INSTR; ++j) {
+      const int kbase = w * PER_WAVE + j * ROWS_PER_INSTR;   // wave-uniform
+      const int kk = kbase + lane / CH;
+      const int chunk = (lane % CH) ^ col_swz<R>(kk);
+      int gk = k0 + kk;
+      gk = gk < kmax ? gk : kmax;
+      int c = r0 + chunk * 8;
+      c = c < ld - 8 ? c : ld - 8;               // stay inside the row's allocation; masked at the store
+      glds16(P + (size_t)gk * ld + c, lds_addr(lds + kbase * R));
+    }
   }
 }
 
-__device__ __forceinline__ bf16x8 frag(const bf16_t* lds, int r, int chunk) {
-  union { uint4 u; bf16x8 v; } f;
-  f.u = *(const uint4*)(lds + r * BK + ((chunk ^ (r & 7)) << 3));
+// MFMA fragment (8 bf16 along k for one row/column) of the 16 rows/columns starting at r16, k-step s (32 k)
+template <bool KM, int R>
+__device__ __forceinline__ bf16x8 frag(const bf16_t* lds, int r16, int s, int lane) {
+  union { uint4 u; bf16x8 v; s16x4 h[2]; } f;
+  if constexpr (!KM) {
+    const int r = r16 + (lane & 15), chunk = 4 * s + (lane >> 4);
+    f.u = *(const uint4*)(lds + r * BK + ((chunk ^ (r & 7)) << 3));
+  } else {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int i = lane & 15, col = r16 + (i & 3) * 4;
+    const int k0 = 32 * s + 8 * (lane >> 4) + (i >> 2), k1 = k0 + 4;
+    const bf16_t* p0 = lds + k0 * R + ((((col >> 3) ^ col_swz<R>(k0)) << 3) | (col & 7));
+    const bf16_t* p1 = lds + k1 * R + ((((col >> 3) ^ col_swz<R>(k1)) << 3) | (col & 7));
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+  }
   return f.v;
 }
 
@@ -117,8 +161,8 @@ __device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col,
   }
 }
 
-template <int BM, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmArgsF g) {
+template <int BM, int EPI, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
   constexpr int FM = BM / 32;                    // 16-row fragments per wave along M (wave tile = BM/2 x 64)
   constexpr int NLD = (BM + BN) / 32;            // glds instructions per wave per stage (8 or 6)
@@ -145,8 +189,8 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmArgsF g) {
 
   auto stage = [&](int kt, int slot) {
     bf16_t* dst = lds + slot * STAGE;
-    stage_tile<BM>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, dst, w, lane);
-    stage_tile<BN>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, dst + A_ELEMS, w, lane);
+    stage_tile<A_KM, BM>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, g.ka_max, dst, w, lane);
+    stage_tile<B_KM, BN>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + A_ELEMS, w, lane);
   };
   if (nk > 0) stage(0, 0);
   if (nk > 1) stage(1, 1);
@@ -160,11 +204,10 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmArgsF g) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[FM], bfr[4];
-      const int chunk = 4 * s + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = frag(As, wm * (BM / 2) + i * 16 + (lane & 15), chunk);
+      for (int i = 0; i < FM; ++i) af[i] = frag<A_KM, BM>(As, wm * (BM / 2) + i * 16, s, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+      for (int j = 0; j < 4; ++j) bfr[j] = frag<B_KM, BN>(Bs, wn * 64 + j * 16, s, lane);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -216,10 +259,10 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(int R, int C, const
   }
 }
 
-template <int BM>
+template <int BM, bool A_KM, bool B_KM>
 void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   const int e = g.epi;
-#define HAMT_L(E) hipLaunchKernelGGL((gemm_nt_fast_kernel<BM, E>), grid, dim3(256), 0, s, g)
+#define HAMT_L(E) hipLaunchKernelGGL((gemm_fast_kernel<BM, E, A_KM, B_KM>), grid, dim3(256), 0, s, g)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
@@ -231,10 +274,19 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+// Layouts: NT (forward), NN (dgrad: B = W stored [K][N]), TN (wgrad: A = dY stored [K][M], B = X stored [K][N]).
+// K-contiguous operands need K % 64 == 0 (the caller pads with zeros); K-strided operands are clamped to row K-1,
+// so for a ragged K the OTHER operand must hold zeros there (NN: zero-padded dY columns; TN: zero-padded dY rows).
 bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void* B) {
-  return d->prec == HAMT_PREC_BF16 && d->dtype_a == HAMT_BF16 && d->dtype_b == HAMT_BF16 && !d->a_kmajor && !d->b_kmajor &&
-         d->K >= 64 && d->K % 64 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 &&
-         d->M >= 1 && d->N >= 1;
+  if (d->prec != HAMT_PREC_BF16 || d->dtype_a != HAMT_BF16 || d->dtype_b != HAMT_BF16) return false;
+  if (d->a_kmajor && !d->b_kmajor) return false;
+  if (d->K < 64 || d->M < 1 || d->N < 1) return false;
+  if ((!d->a_kmajor || !d->b_kmajor) && d->K % 64 != 0) return false;
+  if (d->a_kmajor && d->K % 64 != 0) return false;   // TN: the caller pads the reduction rows of A with zeros
+  if (d->lda % 8 || d->ldb % 8 || ((uintptr_t)A % 16) || ((uintptr_t)B % 16)) return false;
+  if (d->a_kmajor && d->lda < 64) return false;
+  if (d->b_kmajor && d->ldb < 128) return false;
+  return true;
 }
 
 // K slices to use for this problem given `ws_bytes` of workspace (1 = no split).
@@ -254,15 +306,18 @@ int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes) {
 void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
                            float* ws, size_t ws_bytes, hipStream_t s) {
   GemmArgsF g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha,
-              (const bf16_t*)A, (const bf16_t*)B, C, bias, aux, 1, nullptr};
+              (const bf16_t*)A, (const bf16_t*)B, C, bias, aux, 1, nullptr,
+              ((d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K) - 1, ((d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K) - 1};
   const int ks = ws ? hamt_gemm_fast_ksplit(d, ws_bytes) : 1;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   static const int force_bm = getenv("HAMT_FAST_BM") ? atoi(getenv("HAMT_FAST_BM")) : 0;
   const bool bm64 = force_bm ? force_bm == 64 : (t128 * ks < 384);   // fewer than 1.5 blocks per CU: halve the tile height
   g.ksplit = ks;
   g.part = ks > 1 ? ws : nullptr;
-  if (bm64) launch_bm<64>(g, dim3(((d->M + 63) / 64) * ((d->N + BN - 1) / BN), ks), s);
-  else launch_bm<128>(g, dim3(((d->M + 127) / 128) * ((d->N + BN - 1) / BN), ks), s);
+  const dim3 g64(((d->M + 63) / 64) * ((d->N + BN - 1) / BN), ks), g128(((d->M + 127) / 128) * ((d->N + BN - 1) / BN), ks);
+  if (!d->a_kmajor && !d->b_kmajor) { if (bm64) launch_bm<64, false, false>(g, g64, s); else launch_bm<128, false, false>(g, g128, s); }
+  else if (!d->a_kmajor) { if (bm64) launch_bm<64, false, true>(g, g64, s); else launch_bm<128, false, true>(g, g128, s); }
+  else { if (bm64 && d->lda >= 64) launch_bm<64, true, true>(g, g64, s); else launch_bm<128, true, true>(g, g128, s); }
   if (ks > 1) hamt_reduce_partials(ks, d->M * d->N, ws, (float*)C, (d->epilogue & HAMT_EPI_ACCUM) ? 1 : 0, s);
 }
 

@@ -102,22 +102,27 @@ def _operand(t: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ raw GEMM
-def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, aux=None, prec="bf16", alpha=1.0):
+def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, aux=None, prec="bf16", alpha=1.0,
+         k_red=None):
     """out[M,N] = epi(alpha * op(a) @ op(b)); 2-D views with unit inner stride (strided rows allowed)."""
     _chk(a, "gemm")
     a, b = _operand(a), _operand(b)
     M, N = out.shape
-    K = a.shape[0] if a_kmajor else a.shape[1]
-    assert (a.shape == (K, M)) if a_kmajor else (a.shape == (M, K)), (a.shape, out.shape)
-    assert (b.shape == (K, N)) if b_kmajor else (b.shape == (N, K)), (b.shape, out.shape, K)
+    # reduction length: K-contiguous operands define it; K-strided operands may store fewer rows (ka/kb_rows)
+    ka = a.shape[0] if a_kmajor else a.shape[1]
+    kb = b.shape[0] if b_kmajor else b.shape[1]
+    K = k_red if k_red is not None else max(ka, kb)
+    assert (a.shape[1] == M if a_kmajor else a.shape == (M, K)), (a.shape, out.shape, K)
+    assert (b.shape[1] == N if b_kmajor else b.shape == (N, K)), (b.shape, out.shape, K)
+    assert ka <= K and kb <= K and (a_kmajor or ka == K) and (b_kmajor or kb == K)
     if _prec(prec) == L.PREC_F32:
         assert a.dtype == torch.float32 and b.dtype == torch.float32
     d = L.GemmDesc(M, N, K, _ld(a), _ld(b), _ld(out), _ld(aux) if aux is not None else 0, int(a_kmajor), int(b_kmajor),
                    _dt(a), _dt(b), _dt(out), _dt(aux) if aux is not None else 0, _prec(prec),
-                   epilogue | (L.EPI_BIAS if bias is not None else 0), alpha)
+                   epilogue | (L.EPI_BIAS if bias is not None else 0), alpha, ka if ka < K else 0, kb if kb < K else 0)
     lib = L.load()
     ks = 1
-    if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and not (a_kmajor or b_kmajor):
+    if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16:
         ks = lib.hamt_gemm_ksplit(C.byref(d))
     if ks > 1:      # deterministic split-K: fp32 partial tiles in a scratch buffer, summed in slice order
         ws = torch.empty(ks * M * N, dtype=torch.float32, device=out.device)
@@ -171,14 +176,15 @@ def _rup(n: int, m: int = 64) -> int:
     return (n + m - 1) // m * m
 
 
-def cast_pad16(x2: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
-    """fp32 [R,C] (strided rows ok) -> bf16 [R,Cpad] with zero-filled padding columns."""
+def cast_pad16(x2: torch.Tensor, cpad: Optional[int] = None, rpad: Optional[int] = None) -> torch.Tensor:
+    """fp32 [R,C] (strided rows ok) -> bf16 [Rpad,Cpad], padding rows/columns zero-filled (defaults: multiples of 64)."""
     R, Cc = x2.shape
     cpad = _rup(Cc) if cpad is None else cpad
+    rpad = _rup(R) if rpad is None else rpad
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
-    y = torch.empty(R, cpad, dtype=torch.bfloat16, device=x2.device)
-    L.check(L.load().hamt_cast_pad_bf16(R, Cc, cpad, _p(x2), _ld(x2), _p(y), cpad, _stream()), "hamt_cast_pad_bf16")
+    y = torch.empty(rpad, cpad, dtype=torch.bfloat16, device=x2.device)
+    L.check(L.load().hamt_cast_pad_bf16(R, Cc, rpad, cpad, _p(x2), _ld(x2), _p(y), cpad, _stream()), "hamt_cast_pad_bf16")
     return y
 
 
@@ -219,45 +225,52 @@ def _fast_ok(K: int) -> bool:
     return K % 64 == 0 and K >= 64
 
 
-def _linear_fwd(x2, w_op, bias, out, act, prec, pre=None, x16=None):
-    """out = act(x2 @ W^T + b).  bf16 mode with K % 64 == 0: x is cast once (x16 may be passed in to share it)
-    and the GEMM takes the glds fast path; otherwise the generic kernel converts while staging."""
+def prep_x16(x2: torch.Tensor, prec: str):
+    """bf16 operand image of the activations [M,K] for the fast GEMMs: rows padded to a multiple of 64 with zeros so
+    the same buffer serves as A of the forward (first M rows) and as the K-strided B of the weight gradient."""
+    if prec != "bf16" or not _fast_ok(x2.shape[1]):
+        return None
+    if x2.dtype == torch.bfloat16 and x2.shape[0] % 64 == 0 and x2.is_contiguous():
+        return x2
+    assert x2.dtype == torch.float32
+    return cast_pad16(x2, x2.shape[1])
+
+
+def _linear_fwd(x2, weight, bias, out, act, prec, pre=None, x16=None):
+    """out = act(x2 @ W^T + b).  bf16 mode with K % 64 == 0: x is cast once (x16 may be passed in to share it) and the
+    GEMM takes the glds fast path; otherwise the generic kernel converts while staging."""
     epi = 0
     if act == ACT_GELU:
         epi |= L.EPI_GELU | (L.EPI_SAVE_PRE if pre is not None else 0)
     elif act == ACT_RELU:
         epi |= L.EPI_RELU
-    a = x2
-    if prec == "bf16" and _fast_ok(x2.shape[1]) and w_op.dtype == torch.bfloat16:
-        a = x16 if x16 is not None else (x2 if x2.dtype == torch.bfloat16 else cast_pad16(x2, x2.shape[1]))
-    gemm(a, w_op, out, bias=bias, epilogue=epi, aux=pre if act == ACT_GELU else None, prec=prec)
+    a = x16[:x2.shape[0]] if x16 is not None else x2
+    gemm(a, weight_operand(weight, prec), out, bias=bias, epilogue=epi, aux=pre if act == ACT_GELU else None, prec=prec)
 
 
-def _linear_bwd(dy2, x2, weight, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False, dy16=None, dy16t=None,
-                x16t=None):
-    """dy2 [M,N] (strided rows ok), x2 [M,K], weight [N,K] parameter -> (dx [M,K], dW [N,K], db [N]).
-    bf16 mode routes both contractions through the NT fast kernel: dx = dy16[M,Np] * (W^T)16[K,Np]^T and
-    dW = (dy^T)16[N,Mp] * (x^T)16[K,Mp]^T, padding the reduction dimension with zeros to a multiple of 64."""
+def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False, dy16=None):
+    """dy2 [M,N] (strided rows ok), x [M,K] (x16 = its padded bf16 image or None), weight [N,K] parameter
+    -> (dx [M,K], dW [N,K], db [N]).  bf16 mode: ONE padded bf16 image of dY feeds both contractions of the fast kernel:
+    dX = dY16[M,Np] * W16 (W k-strided, "NN"), dW = dY16^T * X16 (both k-strided, "TN") -- no transposed copies."""
     M, N = dy2.shape
-    K = x2.shape[1]
+    K = weight.shape[1]
     dx = dw = db = None
-    fast = prec == "bf16"
+    fast = prec == "bf16" and x16 is not None and N >= 8
+    if fast and dy16 is None:
+        dy16 = cast_pad16(dy2)                                   # [Mp, Np], zero padded
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=torch.float32, device=dy2.device)
         epi = L.EPI_ACCUM if dx_accumulate else 0
-        if fast and N >= 64:
-            a = dy16 if dy16 is not None else cast_pad16(dy2)
-            gemm(a, weight_t16(weight), dx, epilogue=epi, prec=prec)
+        if fast:
+            gemm(dy16[:M], weight_operand(weight, prec), dx, b_kmajor=True, epilogue=epi, prec=prec, k_red=dy16.shape[1])
         else:
             gemm(dy2, weight_operand(weight, prec), dx, b_kmajor=True, epilogue=epi, prec=prec)
     if need_dw:
         dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
-        if fast and M >= 64 and N >= 8 and K >= 8:
-            a = dy16t if dy16t is not None else cast_t16(dy2)
-            b = x16t if x16t is not None else cast_t16(x2)
-            gemm(a, b, dw, prec=prec)
+        if fast:
+            gemm(dy16[:, :N], x16, dw, a_kmajor=True, b_kmajor=True, prec=prec)
         else:
-            gemm(dy2, x2, dw, a_kmajor=True, b_kmajor=True, prec=prec)
+            gemm(dy2, x2 if x2 is not None else x16[:M], dw, a_kmajor=True, b_kmajor=True, prec=prec)
     if need_db:
         db = colsum(dy2)
     return dx, dw, db
@@ -275,19 +288,21 @@ class LinearFn(torch.autograd.Function):
         if x2.stride(-1) != 1:
             x2 = x2.contiguous()
         N = weight.shape[0]
-        w_op = weight_operand(weight, prec)
+        M = x2.shape[0]
+        x16 = prep_x16(x2, prec)
         # wide odd-width outputs (the 30522-column MLM logits) get a padded row stride so that they can feed the
         # backward GEMMs as 16-byte aligned operands; everything else is plain contiguous
-        y = empty_rows(x2.shape[0], N, x.device) if (N % 4 and N >= 256) else torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device)
-        pre = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device) if act == ACT_GELU else None
-        _linear_fwd(x2, w_op, bias.detach() if bias is not None else None, y, act, prec, pre)
-        ctx.save_for_backward(x2, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
-        ctx.act, ctx.prec, ctx.has_bias, ctx.xshape = act, prec, bias is not None, x.shape
+        y = empty_rows(M, N, x.device) if (N % 4 and N >= 256) else torch.empty(M, N, dtype=torch.float32, device=x.device)
+        pre = torch.empty(M, N, dtype=torch.float32, device=x.device) if act == ACT_GELU else None
+        _linear_fwd(x2, weight, bias.detach() if bias is not None else None, y, act, prec, pre, x16)
+        # the bf16 image is all backward needs of x (weight gradient operand); keep fp32 x only on the generic path
+        ctx.save_for_backward(x2 if x16 is None else None, x16, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
+        ctx.act, ctx.prec, ctx.has_bias, ctx.xshape, ctx.M = act, prec, bias is not None, x.shape, M
         return y if x.dim() == 2 else y.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight, h = ctx.saved_tensors
+        x2, x16, weight, h = ctx.saved_tensors
         N = weight.shape[0]
         dy2 = dy.reshape(-1, N)
         if ctx.act != ACT_NONE:
@@ -297,8 +312,8 @@ class LinearFn(torch.autograd.Function):
             L.check(L.load().hamt_act_bwd(dy2.numel(), _p(dy2), _p(h), ctx.act, _p(dh), _stream()), "hamt_act_bwd")
             dy2 = dh
         dy2 = _operand(dy2)
-        dx, dw, db = _linear_bwd(dy2, x2, weight, ctx.prec, ctx.needs_input_grad[0],
-                                 ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dw, db = _linear_bwd(dy2, x2, x16, weight, ctx.prec, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                 ctx.has_bias and ctx.needs_input_grad[2])
         return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None, None
 
 
@@ -321,31 +336,29 @@ class PackedLinearFn(torch.autograd.Function):
         ws, bs = wb[0::2], wb[1::2]
         ns = [w.shape[0] for w in ws]
         out = torch.empty(x2.shape[0], sum(ns), dtype=torch.float32, device=x.device)
-        x16 = cast_pad16(x2, K) if (prec == "bf16" and _fast_ok(K) and x2.dtype == torch.float32) else None
+        x16 = prep_x16(x2, prec)
         c = 0
         for w, b, n in zip(ws, bs, ns):
-            _linear_fwd(x2, weight_operand(w, prec), b.detach(), out[:, c:c + n], ACT_NONE, prec, x16=x16)
+            _linear_fwd(x2, w, b.detach(), out[:, c:c + n], ACT_NONE, prec, x16=x16)
             c += n
-        ctx.save_for_backward(x2, *ws)
-        ctx.prec, ctx.ns, ctx.xshape = prec, ns, x.shape
+        ctx.save_for_backward(x2 if x16 is None else None, x16, *ws)
+        ctx.prec, ctx.ns, ctx.xshape, ctx.M = prec, ns, x.shape, x2.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x2, *ws = ctx.saved_tensors
+        x2, x16, *ws = ctx.saved_tensors
         dout = dout.contiguous()
         grads = []
-        dx = torch.empty(x2.shape, dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[0] else None
-        M = x2.shape[0]
-        fast = ctx.prec == "bf16" and all(n % 64 == 0 for n in ctx.ns) and M >= 64
-        d16 = cast_pad16(dout, dout.shape[1]) if fast else None          # [M, sum n]
-        d16t = cast_t16(dout) if fast else None                           # [sum n, Mpad]
-        x16t = cast_t16(x2) if fast else None                             # [K, Mpad]
+        M = ctx.M
+        K = ws[0].shape[1]
+        dx = torch.empty(M, K, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        fast = ctx.prec == "bf16" and x16 is not None and all(n % 64 == 0 for n in ctx.ns)
+        d16 = cast_pad16(dout) if fast else None                  # [Mp, sum n]: column slices are the per-layer dY16
         c = 0
         for i, (w, n) in enumerate(zip(ws, ctx.ns)):
-            dy2 = dout[:, c:c + n]
-            _, dw, db = _linear_bwd(dy2, x2, w, ctx.prec, dx is not None, True, True, dx_out=dx, dx_accumulate=i > 0,
-                                    dy16=d16[:, c:c + n] if fast else None, dy16t=d16t[c:c + n] if fast else None, x16t=x16t)
+            _, dw, db = _linear_bwd(dout[:, c:c + n], x2, x16, w, ctx.prec, dx is not None, True, True, dx_out=dx,
+                                    dx_accumulate=i > 0, dy16=d16[:, c:c + n] if fast else None)
             grads += [dw, db]
             c += n
         return (dx.view(ctx.xshape) if dx is not None else None), None, *grads
