@@ -288,7 +288,10 @@ def test_finetune_navcmt_modes_vs_reference_goldens(tag, extra, prec):
 
 def test_graph_replay_matches_eager_steps(tiny):
     """hipGraph-captured training steps (vln_hamt_amd.graph) == the same steps launched eagerly (dropout off so that
-    masks cannot differ; the rest is the same kernels, the optimizer table refreshed on the host per replay)."""
+    masks cannot differ; the rest is the same kernels, the optimizer table refreshed on the host per replay).
+    eps = 1.0 makes the Adam update ~linear in the gradient: with the default 1e-6 a parameter whose gradient is
+    rounding noise around 0 moves by +-lr, and two EAGER runs already differ by 4e-4 after 4 steps (atomic-add order
+    in the embedding scatter), which would make the comparison meaningless."""
     from vln_hamt_amd.graph import GraphedTrainStep
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
@@ -303,7 +306,7 @@ def test_graph_replay_matches_eager_steps(tiny):
         named = list(m.named_parameters())
         groups = [{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
                   {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}]
-        return m, AdamW(groups, lr=1e-3, betas=(0.9, 0.98))
+        return m, AdamW(groups, lr=1e-3, betas=(0.9, 0.98), eps=1.0)
 
     seq = ["sap", "mlm", "itm", "sap", "mlm", "itm", "mrc", "sap", "mrc"]
     batches = {}
@@ -330,4 +333,4 @@ def test_graph_replay_matches_eager_steps(tiny):
     for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
         worst = max(worst, float((a - b).abs().max()))
     print(f"[graph vs eager] worst parameter difference after {len(seq)} steps: {worst:.2e}")
-    assert worst < 1e-5, worst
+    assert worst < 2e-6, worst
