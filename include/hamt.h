@@ -104,6 +104,7 @@ typedef struct {
   int dtype_qkv, dtype_o; /* hamt_dtype */
   float scale, p_drop;
   uint32_t call_id;
+  int prec; /* hamt_prec: HAMT_PREC_BF16 = bf16 MFMA products with fp32 softmax; HAMT_PREC_F32 = exact fp32 MFMA */
 } hamt_attn_desc;
 int hamt_attn_small_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v,
                         const float* add_mask, void* o, float* lse, const uint64_t* rng, void* stream);

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     """field order/count of the descriptor structs (plain ints/floats, no padding surprises)."""
     from vln_hamt_amd import _lib
     assert ctypes.sizeof(_lib.GemmDesc) == 18 * 4
-    assert ctypes.sizeof(_lib.AttnDesc) == 14 * 4
+    assert ctypes.sizeof(_lib.AttnDesc) == 15 * 4
     assert ctypes.sizeof(_lib.LnDesc) == 6 * 4
 
 

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("B", i32), ("heads", i32), ("Sq", i32), ("Sk", i32), ("d_head", i32), ("ldq", i32), ("ldk", i32),
                 ("ldv", i32), ("ldo", i32), ("dtype_qkv", i32), ("dtype_o", i32), ("scale", f32), ("p_drop", f32),
-                ("call_id", u32)]
+                ("call_id", u32), ("prec", i32)]
 
 
 class LnDesc(C.Structure):

@@ -330,12 +330,22 @@ int check_desc(const hamt_attn_desc* d, const char* who) {
 
 }  // namespace
 
+void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
+                            float* lse, const uint64_t* rng, hipStream_t s);
+void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
+                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s);
+
 extern "C" int hamt_attn_small_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v,
                                    const float* add_mask, void* o, float* lse, const uint64_t* rng, void* stream) {
   int rc = check_desc(d, "hamt_attn_small_fwd");
   if (rc) return rc;
   HAMT_CHECK_ARG(q && k && v && o && lse, "hamt_attn_small_fwd: null pointer");
   if (d->B == 0) return HAMT_OK;
+  if (d->prec == HAMT_PREC_BF16) {
+    hamt_attn16_fwd_launch(d, q, k, v, add_mask, o, lse, rng, as_stream(stream));
+    HAMT_CHECK_LAUNCH("hamt_attn_small_fwd(bf16)");
+    return HAMT_OK;
+  }
   AttnArgs a{*d, q, k, v, nullptr, nullptr, add_mask, o, nullptr, nullptr, nullptr, lse, rng};
   dim3 grid((d->Sq + AT - 1) / AT, d->heads, d->B), block(256);
   hipStream_t s = as_stream(stream);
@@ -356,6 +366,11 @@ extern "C" int hamt_attn_small_bwd(const hamt_attn_desc* d, const void* q, const
   if (rc) return rc;
   HAMT_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv, "hamt_attn_small_bwd: null pointer");
   if (d->B == 0) return HAMT_OK;
+  if (d->prec == HAMT_PREC_BF16) {
+    hamt_attn16_bwd_launch(d, q, k, v, add_mask, o, d_o, lse, dq, dk, dv, rng, as_stream(stream));
+    HAMT_CHECK_LAUNCH("hamt_attn_small_bwd(bf16)");
+    return HAMT_OK;
+  }
   AttnArgs a{*d, q, k, v, o, d_o, add_mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng};
   dim3 grid(d->heads, d->B), block(256);
   hipStream_t s = as_stream(stream);

@@ -1,0 +1,371 @@
+// attn_small, bf16-MFMA version (HAMT_PREC_BF16): the cross-modal / self attention core of HAMT on
+// v_mfma_f32_16x16x32_bf16 with fp32 softmax statistics.
+//
+//   S = Q K^T * scale + mask[b,key];  P = softmax(S);  P~ = dropout(P);  O = P~ V        (d_head = 64)
+//
+// Forward: one workgroup per (batch, head, 64-query tile), wave w owns query rows [16w, 16w+16).  K/V are walked in
+// 64-key tiles staged as bf16 in LDS (row stride 72: ds_read_b64_tr_b16 quads conflict free, ds_read_b128 2-way).
+// Every product is issued "swapped" so that a lane always owns ONE query row:
+//     S^T = K Q^T   (A = K rows from LDS, B = Q rows held in registers)  -> lane (q = lane&15) holds 16 keys
+//     O^T = V^T P^T (A = V through the hardware transpose read, B = P straight from the softmax registers)
+// so the online-softmax rescale is a per-lane scalar, P never goes through LDS, and the 64 keys of a row need only two
+// cross-lane butterflies (xor 16, 32).  The k-order of the P V product is defined by the S^T accumulator layout
+// (keys 4g..4g+3 of two adjacent 16-key blocks) and the transpose reads of V fetch exactly those rows.
+// Backward (flash-style recompute from the saved log-sum-exp): one workgroup per (batch, head), key tiles outer, query
+// tiles inner; P~ and dS go through LDS once (bf16, [key][q]) because dK/dV reduce over queries while dQ reduces over
+// keys; all three gradients are again produced transposed so each lane stores 4 consecutive head-dim elements.
+//
+// Replaces BertSelfAttention.forward core (vilmodel.py:101-126) and BertOutAttention.forward core (:327-348).
+#include "common.h"
+
+namespace {
+
+constexpr int T64 = 64;    // tile edge (queries / keys) == d_head
+constexpr int AST = 72;    // LDS row stride in bf16 elements (144 B)
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct Attn16Args {
+  hamt_attn_desc d;
+  const void *q, *k, *v, *o, *d_o;
+  const float* mask;
+  void *out, *dq, *dk, *dv;
+  float* lse;
+  const uint64_t* rng;
+};
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&f)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&f)[8]) {
+  const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&f)[8]) {
+  const uint4 x = *(const uint4*)p;
+  const uint32_t u[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(u[j] << 16); f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void st4<float>(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) { *(uint2*)p = make_uint2(pack_bf2(a, b), pack_bf2(c, d)); }
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+  const uint2 x = *(const uint2*)p;
+  return make_float4(__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u), __uint_as_float(x.y << 16), __uint_as_float(x.y & 0xffff0000u));
+}
+
+// Stage rows [r0, r0+64) x 64 columns (one head) into lds[64][AST] as bf16; rows >= rlim are zero.
+// thread t: row t>>2, columns (t&3)*16 .. +15.  `keep` returns the 16 fp32 values (for the delta computation).
+template <typename T>
+__device__ __forceinline__ void stage16(const T* base, int ld, int r0, int rlim, bf16_t* lds, int t, float (&keep)[16]) {
+  const int r = t >> 2, c = (t & 3) * 16;
+  float a[8], b[8];
+  if (r0 + r < rlim) {
+    ld8<T>(base + (size_t)(r0 + r) * ld + c, a);
+    ld8<T>(base + (size_t)(r0 + r) * ld + c + 8, b);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = 0.f; b[i] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { keep[i] = a[i]; keep[8 + i] = b[i]; }
+  *(uint4*)(lds + r * AST + c) = pack8(a);
+  *(uint4*)(lds + r * AST + c + 8) = pack8(b);
+}
+
+// row fragment: 8 consecutive k (columns) of row r: A[i=r][k] or B[k][j=r] for K-contiguous operands
+__device__ __forceinline__ bf16x8 rfrag(const bf16_t* lds, int r, int k8) {
+  union { uint4 u; bf16x8 v; } f;
+  f.u = *(const uint4*)(lds + r * AST + k8);
+  return f.v;
+}
+// transposed fragment: column (c16 + lane&15), rows ra..ra+3 and rb..rb+3 (the lane group's 8 k values)
+__device__ __forceinline__ bf16x8 tfrag(const bf16_t* lds, int ra, int rb, int c16, int lane) {
+  union { bf16x8 v; s16x4 h[2]; } f;
+  const int i = lane & 15, col = c16 + (i & 3) * 4, dr = i >> 2;
+  f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (ra + dr) * AST + col));
+  f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (rb + dr) * AST + col));
+  return f.v;
+}
+__device__ __forceinline__ bf16x8 pack_frag(const float (&lo)[4], const float (&hi)[4]) {
+  union { uint4 u; bf16x8 v; } f;
+  f.u = make_uint4(pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3]));
+  return f.v;
+}
+__device__ __forceinline__ float xg_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xg_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// =================================================================================================
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void attn16_fwd_kernel(Attn16Args a) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[T64 * AST], Vs[T64 * AST];
+  const hamt_attn_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * T64, h = blockIdx.y, b = blockIdx.z;
+  const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
+  const bool active = q0 + 16 * w < d.Sq;
+  const int qrow = q0 + 16 * w + l15;                  // the ONE query row this lane owns
+  const bool qok = qrow < d.Sq;
+  // Q fragments for both 32-wide k-steps, straight from global (B operand: lane (j = q, g) holds Q[q][32s+8g..+7])
+  bf16x8 qf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float f[8];
+    if (active && qok) ld8<TI>(Q + (size_t)qrow * d.ldq + 32 * s + 8 * g, f);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = 0.f;
+    }
+    union { uint4 u; bf16x8 v; } c;
+    c.u = pack8(f);
+    qf[s] = c.v;
+  }
+  const RngKey key = rng_key(a.rng, d.call_id);
+  const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 of[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) of[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float keep[16];
+
+  for (int k0 = 0; k0 < d.Sk; k0 += T64) {
+    __syncthreads();
+    stage16<TI>(K, d.ldk, k0, d.Sk, Ks, t, keep);
+    stage16<TI>(V, d.ldv, k0, d.Sk, Vs, t, keep);
+    __syncthreads();
+    const int nkb = (min(T64, d.Sk - k0) + 15) >> 4;
+    if (active) {
+      f32x4 sf[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        sf[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kb < nkb) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) sf[kb] = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf[kb]);
+        }
+      }
+      // sf[kb][r] = S[q = qrow][key = k0 + 16kb + 4g + r]
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = k0 + 16 * kb + 4 * g + r;
+          const bool kval = kb < nkb && kk < d.Sk;
+          const float mk = (kval && a.mask) ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
+          sf[kb][r] = kval ? sf[kb][r] * d.scale + mk : -INFINITY;
+          mx = fmaxf(mx, sf[kb][r]);
+        }
+      const float mn = fmaxf(m_run, xg_max(mx));
+      const float alpha = __expf(m_run - mn);
+      m_run = mn;
+      float rs = 0.f;
+      float p[4][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = (kb < nkb) ? expf(sf[kb][r] - mn) : 0.f;
+          rs += e;
+          if (d.p_drop > 0.f)
+            e *= drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + qrow) * d.Sk + (k0 + 16 * kb + 4 * g + r), d.p_drop, inv_keep);
+          p[kb][r] = e;
+        }
+      l_run = l_run * alpha + xg_sum(rs);
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) of[db][r] *= alpha;
+      // O^T += V^T P^T : k-step s covers key blocks 2s, 2s+1; this lane group's k = keys 4g..4g+3 of each block
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (2 * s < nkb) {
+          const bf16x8 pf = pack_frag(p[2 * s], p[2 * s + 1]);
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+            of[db] = MFMA16(tfrag(Vs, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, lane), pf, of[db]);
+        }
+      }
+    }
+  }
+  if (active && qok) {
+    TO* O = (TO*)a.out + (size_t)b * d.Sq * d.ldo + h * 64 + (size_t)qrow * d.ldo;
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) st4<TO>(O + 16 * db + 4 * g, of[db][0] * inv, of[db][1] * inv, of[db][2] * inv, of[db][3] * inv);
+    if (g == 0) a.lse[((size_t)b * d.heads + h) * d.Sq + qrow] = m_run + logf(l_run);
+  }
+}
+
+// =================================================================================================
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void attn16_bwd_kernel(Attn16Args a) {
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[T64 * AST], Ks[T64 * AST], Vs[T64 * AST], dOs[T64 * AST], Pt[T64 * AST], dSt[T64 * AST];
+  __shared__ float dpart[4][T64], lse_s[T64], delta_s[T64];
+  const hamt_attn_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
+  const TO* O = (const TO*)a.o + (size_t)b * d.Sq * d.ldo + h * 64;
+  const TO* dO = (const TO*)a.d_o + (size_t)b * d.Sq * d.ldo + h * 64;
+  TI* dQ = (TI*)a.dq + (size_t)b * d.Sq * d.ldq + h * 64;
+  TI* dK = (TI*)a.dk + (size_t)b * d.Sk * d.ldk + h * 64;
+  TI* dV = (TI*)a.dv + (size_t)b * d.Sk * d.ldv + h * 64;
+  const RngKey key = rng_key(a.rng, d.call_id);
+  const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  float keep[16], okeep[16];
+
+  for (int k0 = 0; k0 < d.Sk; k0 += T64) {
+    const int nkb = (min(T64, d.Sk - k0) + 15) >> 4;
+    const bool kact = k0 + 16 * w < d.Sk;            // this wave owns key rows [16w, 16w+16) for dK / dV
+    f32x4 dkf[4], dvf[4];                            // transposed accumulators: [d = 16db+4g+r][key = 16w + l15]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dkf[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvf[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    __syncthreads();
+    stage16<TI>(K, d.ldk, k0, d.Sk, Ks, t, keep);
+    stage16<TI>(V, d.ldv, k0, d.Sk, Vs, t, keep);
+    for (int q0 = 0; q0 < d.Sq; q0 += T64) {
+      const int nqb = (min(T64, d.Sq - q0) + 15) >> 4;
+      const bool qact = q0 + 16 * w < d.Sq;
+      __syncthreads();
+      stage16<TI>(Q, d.ldq, q0, d.Sq, Qs, t, keep);
+      stage16<TO>(dO, d.ldo, q0, d.Sq, dOs, t, keep);
+      {  // delta = rowsum(dO * O) (fp32, from the un-rounded values) and the saved lse
+        const int r = t >> 2, c = (t & 3) * 16;
+        float acc = 0.f;
+        if (q0 + r < d.Sq) {
+          float a8[8], b8[8];
+          ld8<TO>(O + (size_t)(q0 + r) * d.ldo + c, a8);
+          ld8<TO>(O + (size_t)(q0 + r) * d.ldo + c + 8, b8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc += keep[i] * a8[i] + keep[8 + i] * b8[i];
+        }
+        dpart[t & 3][r] = acc;
+        if (t < T64) lse_s[t] = (q0 + t < d.Sq) ? a.lse[((size_t)b * d.heads + h) * d.Sq + q0 + t] : 0.f;
+      }
+      __syncthreads();
+      if (t < T64) delta_s[t] = (dpart[0][t] + dpart[1][t]) + (dpart[2][t] + dpart[3][t]);
+      __syncthreads();
+      if (qact) {   // phase A: this wave's 16 queries x the tile's keys; lane owns query ql = 16w + l15
+        const int ql = 16 * w + l15, qq = q0 + ql;
+        bf16x8 qf[2], df[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qf[s] = rfrag(Qs, ql, 32 * s + 8 * g); df[s] = rfrag(dOs, ql, 32 * s + 8 * g); }
+        const float lse_q = lse_s[ql], delta_q = delta_s[ql];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          if (kb >= nkb && kb < ((nkb + 1) & ~1)) {   // the 32-wide k-step of dQ also reads this (all-padding) key block
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Pt[(16 * kb + 4 * g + r) * AST + ql] = 0; dSt[(16 * kb + 4 * g + r) * AST + ql] = 0; }
+          }
+          if (kb < nkb) {
+            f32x4 sf = (f32x4){0.f, 0.f, 0.f, 0.f}, dpf = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              sf = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf);      // S^T[key][q]
+              dpf = MFMA16(rfrag(Vs, 16 * kb + l15, 32 * s + 8 * g), df[s], dpf);    // dP^T[key][q] = V dO^T
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kl = 16 * kb + 4 * g + r, kk = k0 + kl;
+              float pd = 0.f, ds = 0.f;
+              if (kk < d.Sk && qq < d.Sq) {
+                const float mk = a.mask ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
+                const float p = expf(sf[r] * d.scale + mk - lse_q);
+                float dsc = 1.0f;
+                if (d.p_drop > 0.f) dsc = drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + qq) * d.Sk + kk, d.p_drop, inv_keep);
+                pd = p * dsc;
+                ds = p * (dpf[r] * dsc - delta_q) * d.scale;
+              }
+              Pt[kl * AST + ql] = f2bf(pd);
+              dSt[kl * AST + ql] = f2bf(ds);
+            }
+          }
+        }
+      }
+      else if (w < ((nqb + 1) & ~1)) {   // idle query block inside the last 32-wide k-step of dK/dV: zero columns
+        const int ql = 16 * w + l15;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if (kb < ((nkb + 1) & ~1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Pt[(16 * kb + 4 * g + r) * AST + ql] = 0; dSt[(16 * kb + 4 * g + r) * AST + ql] = 0; }
+          }
+      }
+      __syncthreads();
+      if (kact) {   // dV^T[d][key] += dO^T P~ ; dK^T[d][key] += Q^T dS   (reduction over the tile's queries)
+        for (int s = 0; 2 * s < nqb; ++s) {
+          const bf16x8 pb = rfrag(Pt, 16 * w + l15, 32 * s + 8 * g), sb = rfrag(dSt, 16 * w + l15, 32 * s + 8 * g);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            dvf[db] = MFMA16(tfrag(dOs, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * db, lane), pb, dvf[db]);
+            dkf[db] = MFMA16(tfrag(Qs, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * db, lane), sb, dkf[db]);
+          }
+        }
+      }
+      if (qact) {   // dQ^T[d][q] (+)= K^T dS^T  (reduction over the tile's keys)
+        f32x4 dqf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dqf[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; 2 * s < nkb; ++s) {
+          const bf16x8 sb = tfrag(dSt, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * w, lane);   // B[k = key][j = q]
+#pragma unroll
+          for (int db = 0; db < 4; ++db) dqf[db] = MFMA16(tfrag(Ks, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * db, lane), sb, dqf[db]);
+        }
+        const int qq = q0 + 16 * w + l15;
+        if (qq < d.Sq) {
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            TI* p = dQ + (size_t)qq * d.ldq + 16 * db + 4 * g;
+            float4 v = make_float4(dqf[db][0], dqf[db][1], dqf[db][2], dqf[db][3]);
+            if (k0 != 0) { const float4 o = ld4<TI>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            st4<TI>(p, v.x, v.y, v.z, v.w);
+          }
+        }
+      }
+    }
+    if (kact) {
+      const int kk = k0 + 16 * w + l15;
+      if (kk < d.Sk) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          st4<TI>(dK + (size_t)kk * d.ldk + 16 * db + 4 * g, dkf[db][0], dkf[db][1], dkf[db][2], dkf[db][3]);
+          st4<TI>(dV + (size_t)kk * d.ldv + 16 * db + 4 * g, dvf[db][0], dvf[db][1], dvf[db][2], dvf[db][3]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
+                            float* lse, const uint64_t* rng, hipStream_t s) {
+  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng};
+  dim3 grid((d->Sq + T64 - 1) / T64, d->heads, d->B), block(256);
+  const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
+  if (!ib && !ob) hipLaunchKernelGGL((attn16_fwd_kernel<float, float>), grid, block, 0, s, a);
+  else if (ib && ob) hipLaunchKernelGGL((attn16_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
+  else if (ib) hipLaunchKernelGGL((attn16_fwd_kernel<bf16_t, float>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn16_fwd_kernel<float, bf16_t>), grid, block, 0, s, a);
+}
+
+void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
+                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s) {
+  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng};
+  dim3 grid(d->heads, d->B), block(256);
+  const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
+  if (!ib && !ob) hipLaunchKernelGGL((attn16_bwd_kernel<float, float>), grid, block, 0, s, a);
+  else if (ib && ob) hipLaunchKernelGGL((attn16_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
+  else if (ib) hipLaunchKernelGGL((attn16_bwd_kernel<bf16_t, float>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn16_bwd_kernel<float, bf16_t>), grid, block, 0, s, a);
+}

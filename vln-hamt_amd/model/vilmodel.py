@@ -93,7 +93,7 @@ class BertSelfAttention(nn.Module):
             raise NotImplementedError("head_mask is never used on the HAMT path (always None)")
         B, S, H = hidden_states.shape
         qkv = ops.packed_linear(hidden_states, self.prec, self.query, self.key, self.value)     # [B*S, 3H]
-        ctx = ops.attention(qkv, None, attention_mask, B, self.num_attention_heads, _p(self.dropout, self))
+        ctx = ops.attention(qkv, None, attention_mask, B, self.num_attention_heads, _p(self.dropout, self), self.prec)
         ctx = ctx.view(B, S, H)
         # the fused kernel never materialises the S x S probabilities; the reference only returns them when
         # config.output_attentions is set and no caller on the path reads them
@@ -263,7 +263,7 @@ class BertOutAttention(nn.Module):
         B, Sq, H = hidden_states.shape
         q = ops.linear(hidden_states.reshape(B * Sq, H), self.query.weight, self.query.bias, ops.ACT_NONE, self.prec)
         kv = ops.packed_linear(context, self.prec, self.key, self.value)                         # [B*Sk, 2H]
-        ctx = ops.attention(q, kv, attention_mask, B, self.num_attention_heads, _p(self.dropout, self))
+        ctx = ops.attention(q, kv, attention_mask, B, self.num_attention_heads, _p(self.dropout, self), self.prec)
         return ctx.view(B, Sq, H)
 
 

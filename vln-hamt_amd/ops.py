@@ -378,7 +378,7 @@ class AttnFn(torch.autograd.Function):
     [B*Sq, H] with `kv_src` = packed [B*Sk, 2H].  `add_mask` is the reference's additive (B,1,1,Sk) mask."""
 
     @staticmethod
-    def forward(ctx, q_src, kv_src, add_mask, B, heads, p_drop):
+    def forward(ctx, q_src, kv_src, add_mask, B, heads, p_drop, prec="fp32"):
         _chk(q_src, "AttnFn")
         packed = kv_src is None
         H = q_src.shape[1] // 3 if packed else q_src.shape[1]
@@ -395,17 +395,17 @@ class AttnFn(torch.autograd.Function):
         cid = next_call_id()
         rng = rng_state(q_src.device)
         d = L.AttnDesc(B, heads, Sq, Sk, H // heads, _ld(q), _ld(k), _ld(v), H, _dt(q), L.HAMT_F32,
-                       1.0 / math.sqrt(H // heads), float(p_drop), cid)
+                       1.0 / math.sqrt(H // heads), float(p_drop), cid, _prec(prec))
         L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(out), _p(lse), _p(rng), _stream()),
                 "hamt_attn_small_fwd")
         ctx.save_for_backward(q_src, kv_src, mask2, out, lse)
-        ctx.desc_args = (B, heads, Sq, Sk, H, float(p_drop), cid)
+        ctx.desc_args = (B, heads, Sq, Sk, H, float(p_drop), cid, prec)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q_src, kv_src, mask2, out, lse = ctx.saved_tensors
-        B, heads, Sq, Sk, H, p_drop, cid = ctx.desc_args
+        B, heads, Sq, Sk, H, p_drop, cid, prec = ctx.desc_args
         packed = kv_src is None
         dout = dout.contiguous()
         dq_src = torch.empty_like(q_src)
@@ -417,15 +417,15 @@ class AttnFn(torch.autograd.Function):
             q, k, v = q_src, kv_src[:, :H], kv_src[:, H:]
             dq, dk, dv = dq_src, dkv_src[:, :H], dkv_src[:, H:]
         d = L.AttnDesc(B, heads, Sq, Sk, H // heads, _ld(q), _ld(k), _ld(v), H, _dt(q), L.HAMT_F32,
-                       1.0 / math.sqrt(H // heads), p_drop, cid)
+                       1.0 / math.sqrt(H // heads), p_drop, cid, _prec(prec))
         L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(out), _p(dout), _p(lse), None,
                                              _p(dq), _p(dk), _p(dv), _p(rng_state(q_src.device)), _stream()),
                 "hamt_attn_small_bwd")
-        return dq_src, dkv_src, None, None, None, None
+        return dq_src, dkv_src, None, None, None, None, None
 
 
-def attention(q_src, kv_src, add_mask, B, heads, p_drop):
-    return AttnFn.apply(q_src, kv_src, add_mask, B, heads, p_drop)
+def attention(q_src, kv_src, add_mask, B, heads, p_drop, prec="fp32"):
+    return AttnFn.apply(q_src, kv_src, add_mask, B, heads, p_drop, prec)
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm family
