@@ -124,15 +124,17 @@ typedef struct {
   int M, H;
   float eps, p_pre, p_post;
   uint32_t call_id;
+  int Mpad16; /* rows of the optional bf16 images (y16 / dx16); rows [M, Mpad16) are written as zeros (0: no padding) */
 } hamt_ln_desc;
 int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
                 const float* beta, float* z, float* y, void* y16, float* mean, float* rstd,
                 const uint64_t* rng, void* stream);
-/* dz = d(pre-LN sum) (also the residual gradient); dx = dropout_pre-masked dz (NULL when p_pre == 0:
- * then dx == dz); dgamma/dbeta are ACCUMULATED (+=).  ws: >= 2*256*H floats. */
+/* dz = d(pre-LN sum) (also the residual gradient); dx = dropout_pre-masked dz (may be NULL); dx16 (optional) = the same
+ * as bf16 [Mpad16, H] -- the operand of the dgrad/wgrad GEMMs of the dense layer that produced x; dxsum (optional) +=
+ * column sums of dx = that layer's bias gradient; dgamma/dbeta are ACCUMULATED (+=).  ws: >= 3*256*H floats. */
 int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
-                const float* rstd, const float* gamma, float* dz, float* dx, float* dgamma,
-                float* dbeta, float* ws, const uint64_t* rng, void* stream);
+                const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
+                float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gather/scatter family (embedding lookups A1/A10/A11, boolean-mask compaction A15/A19

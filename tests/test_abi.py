@@ -46,7 +46,7 @@ def test_struct_layouts_match_header():
     from vln_hamt_amd import _lib
     assert ctypes.sizeof(_lib.GemmDesc) == 18 * 4
     assert ctypes.sizeof(_lib.AttnDesc) == 15 * 4
-    assert ctypes.sizeof(_lib.LnDesc) == 6 * 4
+    assert ctypes.sizeof(_lib.LnDesc) == 7 * 4
 
 
 def test_product_never_imports_oracle():

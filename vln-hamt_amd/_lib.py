@@ -32,7 +32,7 @@ class AttnDesc(C.Structure):
 
 
 class LnDesc(C.Structure):
-    _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32)]
+    _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32), ("Mpad16", i32)]
 
 
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
@@ -48,7 +48,7 @@ SIGNATURES = {
     "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_attn_small_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
     "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
     "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],

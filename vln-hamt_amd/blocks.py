@@ -1,0 +1,312 @@
+"""Block-level autograd Functions for the bf16 path: one Function per transformer sub-block, so that every tensor
+between two kernels of a block has exactly the dtype/layout the next kernel wants and nothing is cast, transposed or
+re-added by a separate pass:
+
+    BertAttention      (vilmodel.py:146-156)  -> SelfAttnBlockFn   = LN(dropout(W_o attn(W_qkv x)) + x)
+    BertXAttention     (vilmodel.py:351-360)  -> CrossAttnBlockFn  = LN(dropout(W_o attn(W_q x, W_kv c)) + x)
+    BertIntermediate + BertOutput (:159-185)  -> FfnBlockFn        = LN(dropout(W_2 gelu(W_1 x)) + x)
+
+Data flow inside a block (M rows padded to a multiple of 64 only in the bf16 images):
+  * GEMM inputs are bf16 images written by their producers: LayerNorm kernels emit y16 next to the fp32 residual
+    stream, the QKV / GELU epilogues and the attention kernel write bf16 directly;
+  * backward: the LayerNorm-backward kernel emits the dropout-masked gradient as a bf16 image plus its column sums
+    (= the dense layer's bias gradient); dgrad GEMMs run in "NN" form on the bf16 weight arena, wgrad GEMMs in "TN"
+    form on the saved bf16 images -- no transposes; GELU' is applied in the dgrad epilogue; the residual gradient is
+    accumulated by the last dgrad's epilogue (C += ...), not by a separate add.
+  * query/key/value (key/value) weights that sit back to back in the optimizer's arena are used as ONE [3H,H]
+    ([2H,H]) operand: one projection GEMM, one dgrad, one wgrad.
+The fine-grained Functions in ops.py remain the fp32-mode path and the stand-alone module path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import _ln_bwd, _ln_fwd, _p, _rup, _stream, cast_pad16, colsum, gemm, next_call_id, rng_state, shadow16, weight_operand
+
+ENABLED = os.environ.get("HAMT_NO_FUSED_BLOCKS") is None
+
+
+def _zeros_or_empty(rows_total, rows_valid, cols, device, dtype=torch.bfloat16):
+    """buffer whose rows >= rows_valid must read as finite zeros (reduction padding of the k-strided GEMM operands)"""
+    if rows_total != rows_valid:
+        return torch.zeros(rows_total, cols, dtype=dtype, device=device)
+    return torch.empty(rows_total, cols, dtype=dtype, device=device)
+
+
+def _x16_of(x, x2):
+    s = shadow16(x)
+    if s is not None and s.shape[1] == x2.shape[1]:
+        return s
+    return cast_pad16(x2, x2.shape[1])
+
+
+def _packed(ws, bs):
+    """If the parameters `ws` (and biases `bs`) are adjacent in the optimizer's arena return ([sumN,K] bf16 view,
+    [sumN] fp32 bias view), else None."""
+    a0 = getattr(ws[0], "_hamt_arena16", None)
+    if a0 is None or a0[1]._version != a0[2]:
+        return None
+    flat_p = a0[1]
+    K = ws[0].shape[1]
+    for w0, w1 in zip(ws[:-1], ws[1:]):
+        if w0.data_ptr() + w0.numel() * 4 != w1.data_ptr() or w1.shape[1] != K:
+            return None
+    for b0, b1 in zip(bs[:-1], bs[1:]):
+        if b0.data_ptr() + b0.numel() * 4 != b1.data_ptr():
+            return None
+    base, n = flat_p.data_ptr(), flat_p.numel() * 4
+    if not (base <= ws[0].data_ptr() < base + n and base <= bs[0].data_ptr() < base + n):
+        return None
+    flat16 = a0[0]._base if a0[0]._base is not None else a0[0]
+    woff = (ws[0].data_ptr() - base) // 4
+    boff = (bs[0].data_ptr() - base) // 4
+    N = sum(w.shape[0] for w in ws)
+    return flat16[woff:woff + N * K].view(N, K), flat_p[boff:boff + N].detach()
+
+
+def _attn_desc(B, heads, Sq, Sk, H, ldq, ldk, ldv, p_drop, cid):
+    return L.AttnDesc(B, heads, Sq, Sk, H // heads, ldq, ldk, ldv, H, L.HAMT_BF16, L.HAMT_BF16, 1.0 / math.sqrt(H // heads),
+                      float(p_drop), cid, L.PREC_BF16)
+
+
+def _proj(x16, M, ws, bs, out16):
+    """out16[:M, :] = x16[:M] @ [W_0; W_1; ...]^T + [b_0; b_1; ...] (bf16 out), one GEMM when the weights are adjacent"""
+    pk = _packed(ws, bs)
+    if pk is not None:
+        gemm(x16[:M], pk[0], out16[:M], bias=pk[1])
+        return
+    c = 0
+    for w, b in zip(ws, bs):
+        n = w.shape[0]
+        gemm(x16[:M], weight_operand(w, "bf16"), out16[:M, c:c + n], bias=b.detach())
+        c += n
+
+
+def _proj_bwd(d16, M, x16, ws, bs, dx_accum_into=None, need_dx=True):
+    """gradients of _proj: d16 [Mp, sumN] bf16 (rows >= M zero).  Returns (dx fp32 [M,K] or None, [dW_i], [db_i]);
+    with dx_accum_into the input gradient is accumulated into that fp32 buffer (residual-gradient fusion)."""
+    K = ws[0].shape[1]
+    dev = d16.device
+    pk = _packed(ws, bs)
+    N = d16.shape[1]
+    dx = None
+    if need_dx:
+        dx = dx_accum_into if dx_accum_into is not None else torch.empty(M, K, dtype=torch.float32, device=dev)
+        acc = L.EPI_ACCUM if dx_accum_into is not None else 0
+        if pk is not None:
+            gemm(d16[:M], pk[0], dx, b_kmajor=True, epilogue=acc)
+        else:
+            c = 0
+            for i, w in enumerate(ws):
+                n = w.shape[0]
+                gemm(d16[:M, c:c + n], weight_operand(w, "bf16"), dx, b_kmajor=True, epilogue=acc if i == 0 else L.EPI_ACCUM)
+                c += n
+    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+    gemm(d16, x16, dW, a_kmajor=True, b_kmajor=True)
+    db = colsum(d16[:M])
+    dws, dbs, c = [], [], 0
+    for w in ws:
+        n = w.shape[0]
+        dws.append(dW[c:c + n])
+        dbs.append(db[c:c + n])
+        c += n
+    return dx, dws, dbs
+
+
+# ================================================================================================= self attention block
+class SelfAttnBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta):
+        B, S, H = x.shape
+        M = B * S
+        dev = x.device
+        x2 = x.reshape(M, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        x16 = _x16_of(x, x2)
+        Mp = x16.shape[0]
+        qkv16 = torch.empty(Mp, 3 * H, dtype=torch.bfloat16, device=dev)
+        _proj(x16, M, (wq, wk, wv), (bq, bk, bv), qkv16)
+        mask2 = add_mask.reshape(B, S).to(torch.float32).contiguous() if add_mask is not None else None
+        ctx16 = _zeros_or_empty(Mp, M, H, dev)
+        lse = torch.empty(B * heads * S, dtype=torch.float32, device=dev)
+        cid = next_call_id()
+        rng = rng_state(dev)
+        d = _attn_desc(B, heads, S, S, H, 3 * H, 3 * H, 3 * H, p_attn, cid)
+        q, k, v = qkv16[:, :H], qkv16[:, H:2 * H], qkv16[:, 2 * H:]
+        L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(lse), _p(rng), _stream()),
+                "hamt_attn_small_fwd")
+        o = torch.empty(M, H, dtype=torch.float32, device=dev)
+        gemm(ctx16[:M], weight_operand(wo, "bf16"), o, bias=bo.detach())
+        y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
+        ctx.save_for_backward(x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
+        ctx.meta = (B, S, H, M, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
+        ctx.mark_non_differentiable(y16)
+        return y.view(B, S, H), y16
+
+    @staticmethod
+    def backward(ctx, dy, _unused=None):
+        x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma = ctx.saved_tensors
+        B, S, H, M, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
+        dev = dy.device
+        Mp = x16.shape[0]
+        dz, _, dx16, dgamma, dbeta, dbo = _ln_bwd(dy.reshape(M, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
+                                                  cid_ln, False, True, True)
+        dctx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev)
+        gemm(dx16[:M], weight_operand(wo, "bf16"), dctx16[:M], b_kmajor=True)
+        dwo = torch.empty(H, H, dtype=torch.float32, device=dev)
+        gemm(dx16, ctx16, dwo, a_kmajor=True, b_kmajor=True)
+        dqkv16 = _zeros_or_empty(Mp, M, 3 * H, dev)
+        d = _attn_desc(B, heads, S, S, H, 3 * H, 3 * H, 3 * H, p_attn, cid)
+        q, k, v = qkv16[:, :H], qkv16[:, H:2 * H], qkv16[:, 2 * H:]
+        dq, dk, dv = dqkv16[:, :H], dqkv16[:, H:2 * H], dqkv16[:, 2 * H:]
+        L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(dctx16), _p(lse), None,
+                                             _p(dq), _p(dk), _p(dv), _p(rng_state(dev)), _stream()), "hamt_attn_small_bwd")
+        dx, dws, dbs = _proj_bwd(dqkv16, M, x16, (wq, wk, wv), (bq, bk, bv), dx_accum_into=dz)
+        return (dx.view(B, S, H), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dgamma, dbeta)
+
+
+# ================================================================================================= cross attention block
+class CrossAttnBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta):
+        B, Sq, H = x.shape
+        Sk = c.shape[1]
+        Mq, Mk = B * Sq, B * Sk
+        dev = x.device
+        x2 = x.reshape(Mq, H)
+        c2 = c.reshape(Mk, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        if not c2.is_contiguous():
+            c2 = c2.contiguous()
+        x16, c16 = _x16_of(x, x2), _x16_of(c, c2)
+        Mqp, Mkp = x16.shape[0], c16.shape[0]
+        q16 = torch.empty(Mqp, H, dtype=torch.bfloat16, device=dev)
+        gemm(x16[:Mq], weight_operand(wq, "bf16"), q16[:Mq], bias=bq.detach())
+        kv16 = torch.empty(Mkp, 2 * H, dtype=torch.bfloat16, device=dev)
+        _proj(c16, Mk, (wk, wv), (bk, bv), kv16)
+        mask2 = add_mask.reshape(B, Sk).to(torch.float32).contiguous() if add_mask is not None else None
+        ctx16 = _zeros_or_empty(Mqp, Mq, H, dev)
+        lse = torch.empty(B * heads * Sq, dtype=torch.float32, device=dev)
+        cid = next_call_id()
+        d = _attn_desc(B, heads, Sq, Sk, H, H, 2 * H, 2 * H, p_attn, cid)
+        L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(lse),
+                                             _p(rng_state(dev)), _stream()), "hamt_attn_small_fwd")
+        o = torch.empty(Mq, H, dtype=torch.float32, device=dev)
+        gemm(ctx16[:Mq], weight_operand(wo, "bf16"), o, bias=bo.detach())
+        y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
+        ctx.save_for_backward(x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
+        ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
+        ctx.mark_non_differentiable(y16)
+        return y.view(B, Sq, H), y16
+
+    @staticmethod
+    def backward(ctx, dy, _unused=None):
+        x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma = ctx.saved_tensors
+        B, Sq, Sk, H, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
+        Mq, Mk = B * Sq, B * Sk
+        Mqp, Mkp = x16.shape[0], c16.shape[0]
+        dev = dy.device
+        dz, _, dx16, dgamma, dbeta, dbo = _ln_bwd(dy.reshape(Mq, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
+                                                  cid_ln, False, True, True)
+        dctx16 = torch.empty(Mqp, H, dtype=torch.bfloat16, device=dev)
+        gemm(dx16[:Mq], weight_operand(wo, "bf16"), dctx16[:Mq], b_kmajor=True)
+        dwo = torch.empty(H, H, dtype=torch.float32, device=dev)
+        gemm(dx16, ctx16, dwo, a_kmajor=True, b_kmajor=True)
+        dq16 = _zeros_or_empty(Mqp, Mq, H, dev)
+        dkv16 = _zeros_or_empty(Mkp, Mk, 2 * H, dev)
+        d = _attn_desc(B, heads, Sq, Sk, H, H, 2 * H, 2 * H, p_attn, cid)
+        L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(dctx16),
+                                             _p(lse), None, _p(dq16), _p(dkv16[:, :H]), _p(dkv16[:, H:]), _p(rng_state(dev)), _stream()),
+                "hamt_attn_small_bwd")
+        dx, dwqs, dbqs = _proj_bwd(dq16, Mq, x16, (wq,), (bq,), dx_accum_into=dz)
+        dc, dwkv, dbkv = _proj_bwd(dkv16, Mk, c16, (wk, wv), (bk, bv), need_dx=ctx.needs_input_grad[1])
+        return (dx.view(B, Sq, H), dc.view(B, Sk, H) if dc is not None else None, None, None, None, None, None,
+                dwqs[0], dbqs[0], dwkv[0], dbkv[0], dwkv[1], dbkv[1], dwo, dbo, dgamma, dbeta)
+
+
+# ================================================================================================= feed-forward block
+class FfnBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p_hidden, eps, w1, b1, w2, b2, gamma, beta):
+        shp = x.shape
+        H = shp[-1]
+        x2 = x.reshape(-1, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        dev = x.device
+        I = w1.shape[0]
+        x16 = _x16_of(x, x2)
+        Mp = x16.shape[0]
+        g16 = _zeros_or_empty(Mp, M, I, dev)
+        pre = torch.empty(M, I, dtype=torch.float32, device=dev)
+        gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU | L.EPI_SAVE_PRE, aux=pre)
+        o = torch.empty(M, H, dtype=torch.float32, device=dev)
+        gemm(g16[:M], weight_operand(w2, "bf16"), o, bias=b2.detach())
+        y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
+        ctx.save_for_backward(x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma)
+        ctx.meta = (shp, M, H, I, float(p_hidden), float(eps), cid_ln)
+        ctx.mark_non_differentiable(y16)
+        return y.view(shp), y16
+
+    @staticmethod
+    def backward(ctx, dy, _unused=None):
+        x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma = ctx.saved_tensors
+        shp, M, H, I, p_hidden, eps, cid_ln = ctx.meta
+        dev = dy.device
+        Mp = x16.shape[0]
+        dz, _, dx16, dgamma, dbeta, db2 = _ln_bwd(dy.reshape(M, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
+                                                  cid_ln, False, True, True)
+        dh16 = _zeros_or_empty(Mp, M, I, dev)
+        gemm(dx16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_DGELU, aux=pre)   # dG * gelu'(pre)
+        dw2 = torch.empty(H, I, dtype=torch.float32, device=dev)
+        gemm(dx16, g16, dw2, a_kmajor=True, b_kmajor=True)
+        gemm(dh16[:M], weight_operand(w1, "bf16"), dz, b_kmajor=True, epilogue=L.EPI_ACCUM)                     # dx = dz + dH W1
+        dw1 = torch.empty(I, H, dtype=torch.float32, device=dev)
+        gemm(dh16, x16, dw1, a_kmajor=True, b_kmajor=True)
+        db1 = colsum(dh16[:M])
+        return dz.view(shp), None, None, dw1, db1, dw2, db2, dgamma, dbeta
+
+
+# ================================================================================================= module-facing wrappers
+def _tag(y, y16):
+    y._hamt_bf16 = (y16, y._version, y.data_ptr())
+    return y
+
+
+def usable(prec: str, x: torch.Tensor) -> bool:
+    return ENABLED and prec == "bf16" and x.is_cuda and x.shape[-1] % 64 == 0
+
+
+def self_attn_block(x, add_mask, att_self, att_out, training):
+    pa = float(att_self.dropout.p) if training else 0.0
+    ph = float(att_out.dropout.p) if training else 0.0
+    y, y16 = SelfAttnBlockFn.apply(x, add_mask, att_self.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
+                                   att_self.query.weight, att_self.query.bias, att_self.key.weight, att_self.key.bias,
+                                   att_self.value.weight, att_self.value.bias, att_out.dense.weight, att_out.dense.bias,
+                                   att_out.LayerNorm.weight, att_out.LayerNorm.bias)
+    return _tag(y, y16)
+
+
+def cross_attn_block(x, c, add_mask, att, att_out, training):
+    pa = float(att.dropout.p) if training else 0.0
+    ph = float(att_out.dropout.p) if training else 0.0
+    y, y16 = CrossAttnBlockFn.apply(x, c, add_mask, att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
+                                    att.query.weight, att.query.bias, att.key.weight, att.key.bias, att.value.weight, att.value.bias,
+                                    att_out.dense.weight, att_out.dense.bias, att_out.LayerNorm.weight, att_out.LayerNorm.bias)
+    return _tag(y, y16)
+
+
+def ffn_block(x, inter, out, training):
+    ph = float(out.dropout.p) if training else 0.0
+    y, y16 = FfnBlockFn.apply(x, ph, out.LayerNorm.eps, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias,
+                              out.LayerNorm.weight, out.LayerNorm.bias)
+    return _tag(y, y16)

@@ -268,6 +268,7 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_RELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_RELU);
+  else if (e == HAMT_EPI_MUL_DGELU) HAMT_L(HAMT_EPI_MUL_DGELU);
   else HAMT_L(-1);
 #undef HAMT_L
 }

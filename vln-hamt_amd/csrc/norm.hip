@@ -22,8 +22,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
                                                      const uint64_t* __restrict__ rng) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
-  if (row >= d.M) return;
   const int H = d.H;
+  if (row >= d.M) {   // rows [M, Mpad16) of the bf16 image are zero (they are reduction padding for the fast GEMMs)
+    if (y16 && row < d.Mpad16)
+      for (int c = lane * 4; c < H; c += 256) *(uint2*)(y16 + (size_t)row * H + c) = make_uint2(0u, 0u);
+    return;
+  }
   const RngKey kpre = rng_key(rng, d.call_id), kpost = rng_key(rng, d.call_id ^ POST_SALT);
   const float ik_pre = d.p_pre > 0.f ? 1.0f / (1.0f - d.p_pre) : 1.0f, ik_post = d.p_post > 0.f ? 1.0f / (1.0f - d.p_post) : 1.0f;
   float4 v[NV];
@@ -79,19 +83,23 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float* __restrict__ dy,
                                                      const float* __restrict__ z, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
-                                                     float* __restrict__ dz, float* __restrict__ dx,
+                                                     float* __restrict__ dz, float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                      float* __restrict__ ws, const uint64_t* __restrict__ rng) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int H = d.H;
+  if (dx16 && blockIdx.x == 0)      // zero the reduction-padding rows [M, Mpad16) of the bf16 gradient image
+    for (int row = d.M + w; row < d.Mpad16; row += 4)
+      for (int c = lane * 4; c < H; c += 256) *(uint2*)(dx16 + (size_t)row * H + c) = make_uint2(0u, 0u);
   const RngKey kpre = rng_key(rng, d.call_id), kpost = rng_key(rng, d.call_id ^ POST_SALT);
   const float ik_pre = d.p_pre > 0.f ? 1.0f / (1.0f - d.p_pre) : 1.0f, ik_post = d.p_post > 0.f ? 1.0f / (1.0f - d.p_post) : 1.0f;
-  float4 gam[NV], dg[NV], db[NV];
+  float4 gam[NV], dg[NV], db[NV], dxs[NV];   // dxs: column sums of dx = bias gradient of the dense layer that produced x
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     gam[i] = c < H ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dxs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int row = blockIdx.x * 4 + w; row < d.M; row += gridDim.x * 4) {
     const float mean = mean_i[row], rstd = rstd_i[row];
@@ -128,44 +136,46 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
         r.x = rstd * (g[i].x - c1 - xh[i].x * c2); r.y = rstd * (g[i].y - c1 - xh[i].y * c2);
         r.z = rstd * (g[i].z - c1 - xh[i].z * c2); r.w = rstd * (g[i].w - c1 - xh[i].w * c2);
         *(float4*)(dz + o) = r;
-        if (dx) {
+        if (d.p_pre > 0.f) {
           r.x *= drop_scale(kpre, o, d.p_pre, ik_pre); r.y *= drop_scale(kpre, o + 1, d.p_pre, ik_pre);
           r.z *= drop_scale(kpre, o + 2, d.p_pre, ik_pre); r.w *= drop_scale(kpre, o + 3, d.p_pre, ik_pre);
-          *(float4*)(dx + o) = r;
         }
+        if (dx) *(float4*)(dx + o) = r;
+        if (dx16) *(uint2*)(dx16 + o) = make_uint2(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w));
+        dxs[i].x += r.x; dxs[i].y += r.y; dxs[i].z += r.z; dxs[i].w += r.w;
       }
     }
   }
-  // block partials: ws[block][0][H] = dgamma, ws[block][1][H] = dbeta
-  __shared__ float4 red[4][2][NV * 64];
+  // block partials: ws[block][0][H] = dgamma, ws[block][1][H] = dbeta, ws[block][2][H] = sum dx
+  __shared__ float4 red[4][3][NV * 64];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { red[w][0][i * 64 + lane] = dg[i]; red[w][1][i * 64 + lane] = db[i]; }
+  for (int i = 0; i < NV; ++i) { red[w][0][i * 64 + lane] = dg[i]; red[w][1][i * 64 + lane] = db[i]; red[w][2][i * 64 + lane] = dxs[i]; }
   __syncthreads();
-  if (w < 2) {
+  if (w < 3) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
         float4 a = red[0][w][i * 64 + lane], b = red[1][w][i * 64 + lane], cc = red[2][w][i * 64 + lane], e = red[3][w][i * 64 + lane];
-        *(float4*)(ws + ((size_t)blockIdx.x * 2 + w) * H + c) = make_float4(a.x + b.x + cc.x + e.x, a.y + b.y + cc.y + e.y, a.z + b.z + cc.z + e.z, a.w + b.w + cc.w + e.w);
+        *(float4*)(ws + ((size_t)blockIdx.x * 3 + w) * H + c) = make_float4(a.x + b.x + cc.x + e.x, a.y + b.y + cc.y + e.y, a.z + b.z + cc.z + e.z, a.w + b.w + cc.w + e.w);
       }
     }
   }
 }
 
-// ws[block][2][H] -> dgamma[H], dbeta[H] (accumulate).  block = 64 columns x 4 partial-row phases.
+// ws[block][3][H] -> dgamma[H], dbeta[H], dxsum[H] (each accumulated).  block = 64 columns x 4 partial-row phases.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            float* __restrict__ dbeta, float* __restrict__ dxsum) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   const int which = c / H, col = c % H;
   float s = 0.f;
-  if (c < 2 * H)
-    for (int b = ph; b < nb; b += 4) s += ws[((size_t)b * 2 + which) * H + col];
+  if (c < 3 * H)
+    for (int b = ph; b < nb; b += 4) s += ws[((size_t)b * 3 + which) * H + col];
   __shared__ float red[4][64];
   red[ph][threadIdx.x & 63] = s;
   __syncthreads();
-  if (ph == 0 && c < 2 * H) {
-    float* o = which ? dbeta : dgamma;
+  if (ph == 0 && c < 3 * H) {
+    float* o = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
     if (o) o[col] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
@@ -180,7 +190,8 @@ extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* r
   HAMT_CHECK_ARG(d->p_pre >= 0.f && d->p_pre < 1.f && d->p_post >= 0.f && d->p_post < 1.f, "hamt_ln_fwd: bad dropout p");
   if (d->M == 0) return HAMT_OK;
   const int nv = (d->H + 255) / 256;
-  dim3 grid((d->M + 3) / 4), block(256);
+  const int rows = (y16 && d->Mpad16 > d->M) ? d->Mpad16 : d->M;
+  dim3 grid((rows + 3) / 4), block(256);
   hipStream_t s = as_stream(stream);
 #define LAUNCH(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV>), grid, block, 0, s, *d, x, residual, gamma, beta, z, y, (bf16_t*)y16, mean, rstd, rng)
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
@@ -190,22 +201,22 @@ extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* r
 }
 
 extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
-                           const float* rstd, const float* gamma, float* dz, float* dx, float* dgamma,
-                           float* dbeta, float* ws, const uint64_t* rng, void* stream) {
+                           const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
+                           float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream) {
   HAMT_CHECK_ARG(d && dy && z && mean && rstd && gamma && dz && ws, "hamt_ln_bwd: null pointer");
   HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_bwd: H=%d unsupported", d->H);
-  HAMT_CHECK_ARG(!(d->p_pre > 0.f) || dx, "hamt_ln_bwd: p_pre > 0 needs dx");
+  HAMT_CHECK_ARG(!(d->p_pre > 0.f) || dx || dx16, "hamt_ln_bwd: p_pre > 0 needs dx or dx16");
   if (d->M == 0) return HAMT_OK;
   const int nv = (d->H + 255) / 256;
   int nb = (d->M + 3) / 4;
   if (nb > 256) nb = 256;
   hipStream_t s = as_stream(stream);
   float* dxx = d->p_pre > 0.f ? dx : nullptr;
-#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, ws, rng)
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, (bf16_t*)dx16, ws, rng)
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
-  if (dgamma || dbeta)
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta);
+  if (dgamma || dbeta || dxsum)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
   return HAMT_OK;
 }

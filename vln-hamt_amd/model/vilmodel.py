@@ -17,7 +17,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import ops
+from .. import blocks, ops
 from ..modeling import HamtPreTrainedModel, precision_of
 
 BertLayerNorm = torch.nn.LayerNorm
@@ -67,7 +67,7 @@ class BertEmbeddings(nn.Module):
             z = ops.gather_rows(self.word_embeddings.weight, input_ids)
             z = ops.gather_rows(self.position_embeddings.weight, position_ids.expand(B, L), base=z)
             z = ops.gather_rows(self.token_type_embeddings.weight, token_type_ids, base=z).view(B, L, H)
-        return ops.layer_norm(z, None, self.LayerNorm, p_post=_p(self.dropout, self))
+        return ops.layer_norm(z, None, self.LayerNorm, p_post=_p(self.dropout, self), want16=blocks.ENABLED and H % 64 == 0)
 
 
 class BertSelfAttention(nn.Module):
@@ -124,6 +124,10 @@ class BertAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, attention_mask, head_mask=None):
+        if head_mask is None and input_tensor.dim() == 3 and blocks.usable(self.self.prec, input_tensor):
+            # bf16 path: the whole sub-block is one autograd Function (vln_hamt_amd/blocks.py)
+            y = blocks.self_attn_block(input_tensor, attention_mask, self.self, self.output, self.training)
+            return (y, None) if self.self.output_attentions else (y,)
         so = self.self(input_tensor, attention_mask, head_mask)
         return (self.output(so[0], input_tensor),) + so[1:]
 
@@ -167,7 +171,10 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask, head_mask=None):
         att = self.attention(hidden_states, attention_mask, head_mask)
-        out = self.output(self.intermediate(att[0]), att[0])
+        if blocks.usable(self.output.prec, att[0]) and self.intermediate.act == ops.ACT_GELU:
+            out = blocks.ffn_block(att[0], self.intermediate, self.output, self.training)
+        else:
+            out = self.output(self.intermediate(att[0]), att[0])
         return (out,) + att[1:]
 
 
@@ -276,7 +283,16 @@ class BertXAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None):
+        if input_tensor.dim() == 3 and blocks.usable(self.att.prec, input_tensor):
+            return blocks.cross_attn_block(input_tensor, ctx_tensor, ctx_att_mask, self.att, self.output, self.training)
         return self.output(self.att(input_tensor, ctx_tensor, ctx_att_mask), input_tensor)
+
+
+def _ffn(inter, out, x, training):
+    """BertIntermediate + BertOutput, fused into one block Function on the bf16 path."""
+    if blocks.usable(out.prec, x) and inter.act == ops.ACT_GELU:
+        return blocks.ffn_block(x, inter, out, training)
+    return out(inter(x), x)
 
 
 class LXRTXLayer(nn.Module):
@@ -303,8 +319,7 @@ class LXRTXLayer(nn.Module):
                 self.visn_self_att(visn_input, visn_attention_mask))
 
     def output_fc(self, lang_input, visn_input):
-        return (self.lang_output(self.lang_inter(lang_input), lang_input),
-                self.visn_output(self.visn_inter(visn_input), visn_input))
+        return _ffn(self.lang_inter, self.lang_output, lang_input, self.training), _ffn(self.visn_inter, self.visn_output, visn_input, self.training)
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
         lang, visn = self.cross_att(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)

@@ -14,7 +14,7 @@ import copy
 import torch
 from torch import nn
 
-from .. import ops
+from .. import blocks, ops
 from ..model import vilmodel as V
 from ..model.pretrain_cmt import _MlpHead
 from ..modeling import HamtPreTrainedModel, precision_of
@@ -36,6 +36,8 @@ class BertXAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None):
+        if input_tensor.dim() == 3 and blocks.usable(self.att.prec, input_tensor):
+            return blocks.cross_attn_block(input_tensor, ctx_tensor, ctx_att_mask, self.att, self.output, self.training), None
         return self.output(self.att(input_tensor, ctx_tensor, ctx_att_mask), input_tensor), None
 
 
@@ -67,8 +69,8 @@ class LXRTXLayer(nn.Module):
         return lang_att, self.visn_self_att(visn_input, visn_attention_mask)
 
     def output_fc(self, lang_input, visn_input):
-        lang_out = lang_input if self.no_lang_ca else self.lang_output(self.lang_inter(lang_input), lang_input)
-        return lang_out, self.visn_output(self.visn_inter(visn_input), visn_input)
+        lang_out = lang_input if self.no_lang_ca else V._ffn(self.lang_inter, self.lang_output, lang_input, self.training)
+        return lang_out, V._ffn(self.visn_inter, self.visn_output, visn_input, self.training)
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
         lang, visn = self.cross_att(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
@@ -182,7 +184,7 @@ class NavCMT(BertPreTrainedModel):
                 outs = [txt]
                 for layer in self.encoder.x_layers:
                     att = layer.lang_self_att(txt, txt_m)[0]
-                    outs.append(layer.lang_output(layer.lang_inter(att), att))
+                    outs.append(V._ffn(layer.lang_inter, layer.lang_output, att, self.training))
                 return outs
             return txt
 

@@ -429,49 +429,79 @@ def attention(q_src, kv_src, add_mask, B, heads, p_drop, prec="fp32"):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm family
+def shadow16(x: torch.Tensor):
+    """bf16 image [Mpad64, H] of an activation tensor if its producer emitted one (LayerNorm kernels do), else None."""
+    s = getattr(x, "_hamt_bf16", None)
+    if s is not None and s[1] == x._version and s[2] == x.data_ptr():
+        return s[0]
+    return None
+
+
+def _ln_fwd(x2, r2, gamma, beta, eps, p_pre, p_post, want16):
+    M, H = x2.shape
+    dev = x2.device
+    z = torch.empty(M, H, dtype=torch.float32, device=dev)
+    y = torch.empty(M, H, dtype=torch.float32, device=dev)
+    mean = torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    Mp = _rup(M) if want16 else 0
+    y16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want16 else None
+    cid = next_call_id() if (p_pre > 0 or p_post > 0) else 0
+    d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp)
+    L.check(L.load().hamt_ln_fwd(C.byref(d), _p(x2), _p(r2), _p(gamma), _p(beta), _p(z), _p(y), _p(y16),
+                                 _p(mean), _p(rstd), _p(rng_state(dev)), _stream()), "hamt_ln_fwd")
+    return y, y16, z, mean, rstd, cid
+
+
+def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_dx16, want_dxsum):
+    """-> (dz, dx32 | None, dx16 | None, dgamma, dbeta, dxsum | None)"""
+    M, H = dy2.shape
+    dev = dy2.device
+    dz = torch.empty(M, H, dtype=torch.float32, device=dev)
+    dx = torch.empty(M, H, dtype=torch.float32, device=dev) if (want_dx32 and p_pre > 0) else None
+    Mp = _rup(M) if want_dx16 else 0
+    dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want_dx16 else None
+    red = torch.zeros(3, H, dtype=torch.float32, device=dev)
+    ws = torch.empty(3 * 256 * H, dtype=torch.float32, device=dev)
+    d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp)
+    L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dx16),
+                                 _p(red[0]), _p(red[1]), _p(red[2]) if want_dxsum else None, _p(ws), _p(rng_state(dev)), _stream()),
+            "hamt_ln_bwd")
+    return dz, dx, dx16, red[0], red[1], (red[2] if want_dxsum else None)
+
+
 class LnFn(torch.autograd.Function):
-    """y = dropout_post(LayerNorm(dropout_pre(x) + residual)) -- see hamt_ln_fwd in include/hamt.h."""
+    """y = dropout_post(LayerNorm(dropout_pre(x) + residual)) -- see hamt_ln_fwd in include/hamt.h.
+    Second output: the bf16 image of y (rows padded to a multiple of 64) for the next GEMM, or None."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, p_pre, p_post):
+    def forward(ctx, x, residual, gamma, beta, eps, p_pre, p_post, want16):
         _chk(x, "LnFn")
         H = x.shape[-1]
         x2 = x.reshape(-1, H).contiguous()
         r2 = residual.reshape(-1, H).contiguous() if residual is not None else None
-        M = x2.shape[0]
-        dev = x.device
-        z = torch.empty(M, H, dtype=torch.float32, device=dev)
-        y = torch.empty(M, H, dtype=torch.float32, device=dev)
-        mean = torch.empty(M, dtype=torch.float32, device=dev)
-        rstd = torch.empty(M, dtype=torch.float32, device=dev)
-        cid = next_call_id() if (p_pre > 0 or p_post > 0) else 0
-        d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid)
-        L.check(L.load().hamt_ln_fwd(C.byref(d), _p(x2), _p(r2), _p(gamma.detach()), _p(beta.detach()), _p(z), _p(y), None,
-                                     _p(mean), _p(rstd), _p(rng_state(dev)), _stream()), "hamt_ln_fwd")
+        y, y16, z, mean, rstd, cid = _ln_fwd(x2, r2, gamma.detach(), beta.detach(), eps, p_pre, p_post, want16)
         ctx.save_for_backward(z, mean, rstd, gamma)
-        ctx.args = (M, H, float(eps), float(p_pre), float(p_post), cid, residual is not None, x.shape)
-        return y.view(x.shape)
+        ctx.args = (float(eps), float(p_pre), float(p_post), cid, residual is not None, x.shape)
+        if y16 is not None:
+            ctx.mark_non_differentiable(y16)
+        return y.view(x.shape), y16
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _d16=None):
         z, mean, rstd, gamma = ctx.saved_tensors
-        M, H, eps, p_pre, p_post, cid, has_res, xshape = ctx.args
-        dev = dy.device
-        dy2 = dy.reshape(M, H).contiguous()
-        dz = torch.empty(M, H, dtype=torch.float32, device=dev)
-        dx = torch.empty(M, H, dtype=torch.float32, device=dev) if p_pre > 0 else None
-        dgamma = torch.zeros(H, dtype=torch.float32, device=dev)
-        dbeta = torch.zeros(H, dtype=torch.float32, device=dev)
-        ws = torch.empty(2 * 256 * H, dtype=torch.float32, device=dev)
-        d = L.LnDesc(M, H, eps, p_pre, p_post, cid)
-        L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma.detach()), _p(dz), _p(dx),
-                                     _p(dgamma), _p(dbeta), _p(ws), _p(rng_state(dev)), _stream()), "hamt_ln_bwd")
+        eps, p_pre, p_post, cid, has_res, xshape = ctx.args
+        dy2 = dy.reshape(z.shape).contiguous()
+        dz, dx, _, dgamma, dbeta, _ = _ln_bwd(dy2, z, mean, rstd, gamma.detach(), eps, p_pre, p_post, cid, True, False, False)
         gx = (dx if dx is not None else dz).view(xshape)
-        return gx, (dz.view(xshape) if has_res else None), dgamma, dbeta, None, None, None
+        return gx, (dz.view(xshape) if has_res else None), dgamma, dbeta, None, None, None, None
 
 
-def layer_norm(x, residual, ln_module, p_pre=0.0, p_post=0.0, eps=None):
-    return LnFn.apply(x, residual, ln_module.weight, ln_module.bias, ln_module.eps if eps is None else eps, p_pre, p_post)
+def layer_norm(x, residual, ln_module, p_pre=0.0, p_post=0.0, eps=None, want16=False):
+    y, y16 = LnFn.apply(x, residual, ln_module.weight, ln_module.bias, ln_module.eps if eps is None else eps, p_pre, p_post, want16)
+    if y16 is not None:
+        y._hamt_bf16 = (y16, y._version, y.data_ptr())
+    return y
 
 
 # ------------------------------------------------------------------------------------------ gathers / embeddings
