@@ -30,6 +30,8 @@ from . import ops
 from .ops import _ln_bwd, _ln_fwd, _p, _rup, _stream, cast_pad16, colsum, gemm, next_call_id, rng_state, shadow16, weight_operand
 
 ENABLED = os.environ.get("HAMT_NO_FUSED_BLOCKS") is None
+NO_PACKED = os.environ.get("HAMT_NO_PACKED") is not None      # ablation switches
+NO_SHADOW = os.environ.get("HAMT_NO_SHADOW") is not None
 
 
 def _zeros_or_empty(rows_total, rows_valid, cols, device, dtype=torch.bfloat16):
@@ -40,7 +42,7 @@ def _zeros_or_empty(rows_total, rows_valid, cols, device, dtype=torch.bfloat16):
 
 
 def _x16_of(x, x2):
-    s = shadow16(x)
+    s = None if NO_SHADOW else shadow16(x)
     if s is not None and s.shape[1] == x2.shape[1]:
         return s
     return cast_pad16(x2, x2.shape[1])
@@ -50,7 +52,7 @@ def _packed(ws, bs):
     """If the parameters `ws` (and biases `bs`) are adjacent in the optimizer's arena return ([sumN,K] bf16 view,
     [sumN] fp32 bias view), else None."""
     a0 = getattr(ws[0], "_hamt_arena16", None)
-    if a0 is None or a0[1]._version != a0[2]:
+    if NO_PACKED or a0 is None or a0[1]._version != a0[2]:
         return None
     flat_p = a0[1]
     K = ws[0].shape[1]

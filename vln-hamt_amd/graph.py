@@ -18,6 +18,10 @@ class GraphedTrainStep:
         self.model, self.opt, self.max_norm = model, optimizer, float(max_grad_norm)
         self.graphs = {}
         self.pool = None
+        # ONE dedicated stream for warm-up and for every capture: autograd's per-parameter AccumulateGrad nodes remember
+        # the stream they were created on; if a later capture ran on a different stream their accumulation kernels
+        # would execute outside the capture (run once, never replayed).
+        self.stream = torch.cuda.Stream()
         self.opt.materialize()
 
     def _eager(self, batch, task):
@@ -33,10 +37,10 @@ class GraphedTrainStep:
     def _capture(self, key, batch, task):
         dev = next(self.model.parameters()).device
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        side = self.stream
         side.wait_stream(cur)
-        with torch.cuda.stream(side):          # one real step on a side stream first (allocator / cache warm-up)
-            loss = self._eager(batch, task)
+        with torch.cuda.stream(side):          # one real step on the capture stream first (allocator / cache warm-up)
+            loss = self._eager(batch, task).detach()      # .detach(): do not keep this step's autograd graph alive
         cur.wait_stream(side)
         torch.cuda.synchronize()
         ops.invalidate_weight_caches()
@@ -44,13 +48,14 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self.pool):
+        with torch.cuda.graph(g, pool=self.pool, stream=side):
             loss_c = self.model(batch, task, True).mean()
             loss_c.backward()
             gsq = self.opt.global_grad_sumsq()
             self.opt._pending_clip = (gsq, self.max_norm)
             self.opt.launch_step()
             ops.advance_rng_epoch(dev)
+            loss_c = loss_c.detach()           # drop the captured step's autograd graph (its buffers live in the pool)
         active = list(self.opt.active_mask)
         self.opt._pending_clip = None
         self.opt._packed = False
