@@ -56,7 +56,10 @@ int hamt_last_error(char* buf, size_t n);
  * ---------------------------------------------------------------------------------------------- */
 enum {
   HAMT_EPI_BIAS = 1, HAMT_EPI_GELU = 2, HAMT_EPI_RELU = 4, HAMT_EPI_ACCUM = 8,
-  HAMT_EPI_MUL_DGELU = 16, HAMT_EPI_MUL_DRELU = 32, HAMT_EPI_SAVE_PRE = 64
+  HAMT_EPI_MUL_DGELU = 16, HAMT_EPI_MUL_DRELU = 32, HAMT_EPI_SAVE_PRE = 64,
+  /* bf16 training path: forward stores gelu(v) to C and gelu'(v) to aux in ONE erf/exp evaluation (A&S 7.1.26 erf,
+   * |err| <= 1.5e-7, far below bf16 resolution); backward just multiplies by aux. */
+  HAMT_EPI_GELU_GRAD = 128, HAMT_EPI_MUL_AUX = 256
 };
 typedef struct {
   int M, N, K;
@@ -84,6 +87,11 @@ int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* B, void* C,
  * (dgrad uses the transposed weight, wgrad the transposed activations / gradients.) */
 int hamt_cast_pad_bf16(int R, int C, int Rpad, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream);
 int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dtype_x, void* y, int ldy, int Rpad, void* stream);
+
+/* dW[n][k] (+)= sum_m dy[m][n] * x[m][k] for K <= 8 (weight gradient of the 4-wide angle-feature linears, vilmodel.py:498,
+ * 550, 558): exact fp32, K weighted column sums.  ws: >= 64*N*K floats */
+int hamt_smallk_wgrad(int M, int N, int K, const float* dy, int lddy, const float* x, int ldx, float* dW,
+                      int accumulate, float* ws, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
 int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate,

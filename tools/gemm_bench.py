@@ -1,25 +1,43 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of hamt_gemm (bf16 fast path) on the shapes of the HAMT step; HIP-event timing on the launch stream."""
+"""Micro-benchmark of hamt_gemm (bf16 fast path) on the shapes of the HAMT step; HIP-event timing on the launch stream.
+usage: gemm_bench.py [layout:MxNxK[:epi[:cdtype]] ...]   layout in nt|nn|tn, epi in none|bias|gelu|dgelu|acc"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vln_hamt_amd import ops
+from vln_hamt_amd import _lib as L
 
 
-def bench(M, N, K, out_dtype=torch.float32, bias=True, iters=50):
-    a = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
-    b = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
-    bs = torch.randn(N, device="cuda") if bias else None
-    out = torch.empty(M, N, device="cuda", dtype=out_dtype)
-    for _ in range(5):
-        ops.gemm(a, b, out, bias=bs, prec="bf16")
+def bench(layout, M, N, K, epi="bias", cdt="f32", iters=30):
+    dev = "cuda"
+    A = torch.randn(M, K, device=dev)
+    B = torch.randn(K, N, device=dev) * 0.05
+    a = (A.t().contiguous() if layout == "tn" else A).to(torch.bfloat16)
+    b = (B.t().contiguous() if layout == "nt" else B).to(torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=torch.float32 if cdt == "f32" else torch.bfloat16)
+    kw = dict(a_kmajor=layout == "tn", b_kmajor=layout in ("nn", "tn"), prec="bf16")
+    if epi == "bias":
+        kw["bias"] = torch.randn(N, device=dev)
+    elif epi == "gelu":
+        kw.update(bias=torch.randn(N, device=dev), epilogue=L.EPI_GELU | L.EPI_SAVE_PRE, aux=torch.empty(M, N, device=dev))
+    elif epi == "gelu16":
+        kw.update(bias=torch.randn(N, device=dev), epilogue=L.EPI_GELU | L.EPI_SAVE_PRE, aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+    elif epi == "dgelu":
+        kw.update(epilogue=L.EPI_MUL_DGELU, aux=torch.randn(M, N, device=dev))
+    elif epi == "dgelu16":
+        kw.update(epilogue=L.EPI_MUL_DGELU, aux=torch.randn(M, N, device=dev).to(torch.bfloat16))
+    elif epi == "acc":
+        kw.update(epilogue=L.EPI_ACCUM)
+        out.zero_()
+    for _ in range(3):
+        ops.gemm(a, b, out, **kw)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
-        ops.gemm(a, b, out, bias=bs, prec="bf16")
+        ops.gemm(a, b, out, **kw)
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) / iters * 1e3
@@ -27,13 +45,20 @@ def bench(M, N, K, out_dtype=torch.float32, bias=True, iters=50):
 
 
 if __name__ == "__main__":
-    shapes = [(5120, 768, 64), (5120, 768, 256), (5120, 768, 768), (5120, 768, 3072), (5120, 3072, 768), (5120, 2304, 768),
-              (11520, 768, 768), (11520, 3072, 768), (11520, 768, 3072), (2752, 768, 768), (768, 768, 5120), (3072, 768, 5120),
-              (768, 3072, 5120), (768, 768, 11520), (768, 30522, 768), (4096, 4096, 4096), (8192, 8192, 1024)]
-    if len(sys.argv) > 1:
-        shapes = [tuple(int(x) for x in s.split("x")) for s in sys.argv[1:]]
-    print(f"{'M':>6} {'N':>6} {'K':>6} {'us':>9} {'TFLOP/s':>9}   (fp32 C)      us   TF (bf16 C)")
-    for (M, N, K) in shapes:
-        us, tf = bench(M, N, K)
-        us2, tf2 = bench(M, N, K, torch.bfloat16)
-        print(f"{M:6d} {N:6d} {K:6d} {us:9.1f} {tf:9.1f}            {us2:9.1f} {tf2:7.1f}")
+    specs = sys.argv[1:] or [
+        "nt:5120x768x768:bias", "nt:5120x2304x768:bias:bf16", "nt:5120x3072x768:gelu:bf16", "nt:5120x3072x768:gelu16:bf16",
+        "nt:5120x768x3072:bias", "nt:11520x3072x768:gelu:bf16", "nt:11520x768x3072:bias",
+        "nn:5120x768x768:none:bf16", "nn:5120x768x2304:acc", "nn:5120x3072x768:dgelu:bf16", "nn:5120x3072x768:dgelu16:bf16",
+        "nn:5120x768x3072:acc", "nn:11520x3072x768:dgelu:bf16",
+        "tn:768x768x5120:none", "tn:2304x768x5120:none", "tn:3072x768x5120:none", "tn:768x3072x5120:none",
+        "tn:768x768x11520:none", "tn:3072x768x11520:none", "tn:768x768x2752:none", "tn:30522x768x768:none",
+        "nt:4096x4096x4096:none", "nn:4096x4096x4096:none", "tn:4096x4096x4096:none"]
+    print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} {'epi':>8} {'C':>5} {'us':>9} {'TFLOP/s':>9}")
+    for sp in specs:
+        parts = sp.split(":")
+        layout = parts[0]
+        M, N, K = (int(x) for x in parts[1].split("x"))
+        epi = parts[2] if len(parts) > 2 else "none"
+        cdt = parts[3] if len(parts) > 3 else "f32"
+        us, tf = bench(layout, M, N, K, epi, cdt)
+        print(f"{layout:6} {M:6d} {N:6d} {K:6d} {epi:>8} {cdt:>5} {us:9.1f} {tf:9.1f}")

@@ -249,8 +249,8 @@ class FfnBlockFn(torch.autograd.Function):
         x16 = _x16_of(x, x2)
         Mp = x16.shape[0]
         g16 = _zeros_or_empty(Mp, M, I, dev)
-        pre = torch.empty(M, I, dtype=torch.float32, device=dev)
-        gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU | L.EPI_SAVE_PRE, aux=pre)
+        pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(W1 x + b1), from the same erf/exp as gelu
+        gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre)
         o = torch.empty(M, H, dtype=torch.float32, device=dev)
         gemm(g16[:M], weight_operand(w2, "bf16"), o, bias=b2.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
@@ -268,7 +268,7 @@ class FfnBlockFn(torch.autograd.Function):
         dz, _, dx16, dgamma, dbeta, db2 = _ln_bwd(dy.reshape(M, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
                                                   cid_ln, False, True, True)
         dh16 = _zeros_or_empty(Mp, M, I, dev)
-        gemm(dx16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_DGELU, aux=pre)   # dG * gelu'(pre)
+        gemm(dx16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_AUX, aux=pre)     # dG * gelu'(pre)
         dw2 = torch.empty(H, I, dtype=torch.float32, device=dev)
         gemm(dx16, g16, dw2, a_kmajor=True, b_kmajor=True)
         gemm(dh16[:M], weight_operand(w1, "bf16"), dz, b_kmajor=True, epilogue=L.EPI_ACCUM)                     # dx = dz + dH W1

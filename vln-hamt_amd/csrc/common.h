@@ -83,4 +83,16 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
+// gelu(x) and gelu'(x) from one exp: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+__device__ __forceinline__ void gelu_and_grad(float x, float& g, float& dg) {
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float e = __expf(-u * u);                                   // exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * u);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_u = 1.0f - poly * e;                              // erf(|x|/sqrt2)
+  const float phi = 0.5f * (1.0f + copysignf(erf_u, x));            // Phi(x)
+  g = x * phi;
+  dg = phi + x * 0.39894228040143267794f * e;
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

@@ -15,6 +15,8 @@
 // 182, 263, 284, 323-325, 497-498, 549-558; pretrain_cmt.py:16-68).
 #include "common.h"
 
+void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s);
+
 namespace {
 
 struct GemmArgs {
@@ -40,6 +42,13 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int row, int col, f
     if (g.dtype_aux == HAMT_BF16) ((bf16_t*)g.aux)[ia] = f2bf(v); else ((float*)g.aux)[ia] = v;
   }
   if (g.epi & HAMT_EPI_GELU) v = gelu_erf(v);
+  if (g.epi & HAMT_EPI_GELU_GRAD) {
+    float gg, dg;
+    gelu_and_grad(v, gg, dg);
+    v = gg;
+    if (g.dtype_aux == HAMT_BF16) ((bf16_t*)g.aux)[ia] = f2bf(dg); else ((float*)g.aux)[ia] = dg;
+  }
+  if (g.epi & HAMT_EPI_MUL_AUX) v *= (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
   if (g.epi & HAMT_EPI_RELU) v = fmaxf(v, 0.0f);
   if (g.epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
     float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
@@ -348,7 +357,46 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int R, int N, cons
   }
 }
 
+// dW[n][k] = sum_m dy[m][n] * x[m][k] for tiny K (the 4-wide angle features): K weighted column sums of dy, exact fp32.
+template <int KMAX>
+__global__ __launch_bounds__(256) void smallk_wgrad_partial_kernel(int M, int N, int K, const float* __restrict__ dy, int lddy,
+                                                                   const float* __restrict__ x, int ldx, float* __restrict__ ws,
+                                                                   int rows_per_chunk) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  if (col < N)
+    for (int r = r0 + ph; r < r1; r += 4) {
+      const float g = dy[(size_t)r * lddy + col];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K) acc[k] += g * x[(size_t)r * ldx + k];
+    }
+  __shared__ float red[4][64][KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) red[ph][threadIdx.x & 63][k] = acc[k];
+  __syncthreads();
+  if (ph == 0 && col < N)
+    for (int k = 0; k < K; ++k)
+      ws[((size_t)blockIdx.y * N + col) * K + k] = (red[0][threadIdx.x][k] + red[1][threadIdx.x][k]) + (red[2][threadIdx.x][k] + red[3][threadIdx.x][k]);
+}
+
 }  // namespace
+
+extern "C" int hamt_smallk_wgrad(int M, int N, int K, const float* dy, int lddy, const float* x, int ldx, float* dW, int accumulate,
+                                 float* ws, void* stream) {
+  HAMT_CHECK_ARG(dy && x && dW && ws && K >= 1 && K <= 8 && N >= 1 && M >= 0, "hamt_smallk_wgrad: bad argument (K <= 8)");
+  hipStream_t s = as_stream(stream);
+  int chunks = M >= 64 * 64 ? 64 : (M + 63) / 64;
+  if (chunks < 1) chunks = 1;
+  int rpc = (M + chunks - 1) / chunks;
+  if (rpc < 1) rpc = 1;
+  hipLaunchKernelGGL((smallk_wgrad_partial_kernel<8>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, M, N, K, dy, lddy, x, ldx, ws, rpc);
+  hamt_reduce_partials(chunks, N * K, ws, dW, accumulate, s);
+  HAMT_CHECK_LAUNCH("hamt_smallk_wgrad");
+  return HAMT_OK;
+}
 
 bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void* B);
 int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes);
@@ -380,7 +428,7 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
   HAMT_CHECK_ARG((d->lda * sa) % 16 == 0 && (d->ldb * sb) % 16 == 0, "hamt_gemm: lda/ldb rows must be 16-byte aligned (lda=%d ldb=%d)", d->lda, d->ldb);
   HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
   HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
-  HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) || aux, "hamt_gemm: epilogue needs aux");
+  HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) || aux, "hamt_gemm: epilogue needs aux");
   const int ka = (d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K, kb = (d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K;
   GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, ka, kb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
   hipStream_t s = as_stream(stream);

@@ -137,6 +137,26 @@ __device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col,
     else for (int j = 0; j < 4; ++j) if (col + j < g.N) ((float*)g.aux)[ia + j] = v[j];
   }
   if (epi & HAMT_EPI_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]); }
+  if (epi & HAMT_EPI_GELU_GRAD) {
+    float dg[4];
+    for (int j = 0; j < 4; ++j) gelu_and_grad(v[j], v[j], dg[j]);
+    if (g.dtype_aux == HAMT_BF16) {
+      if (full && (g.ldaux & 3) == 0) *(uint2*)((bf16_t*)g.aux + ia) = make_uint2(pack_bf2(dg[0], dg[1]), pack_bf2(dg[2], dg[3]));
+      else for (int j = 0; j < 4; ++j) if (col + j < g.N) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]);
+    } else {
+      for (int j = 0; j < 4; ++j) if (col + j < g.N) ((float*)g.aux)[ia + j] = dg[j];
+    }
+  }
+  if (epi & HAMT_EPI_MUL_AUX) {
+    if (g.dtype_aux == HAMT_BF16 && full && (g.ldaux & 3) == 0) {
+      const uint2 a2 = *(const uint2*)((const bf16_t*)g.aux + ia);
+      v[0] *= __uint_as_float(a2.x << 16); v[1] *= __uint_as_float(a2.x & 0xffff0000u);
+      v[2] *= __uint_as_float(a2.y << 16); v[3] *= __uint_as_float(a2.y & 0xffff0000u);
+    } else {
+      for (int j = 0; j < 4; ++j) if (col + j < g.N)
+        v[j] *= (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j];
+    }
+  }
   if (epi & HAMT_EPI_RELU) { for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f); }
   if (epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
     for (int j = 0; j < 4; ++j) if (col + j < g.N) {
@@ -269,6 +289,8 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_RELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_RELU);
   else if (e == HAMT_EPI_MUL_DGELU) HAMT_L(HAMT_EPI_MUL_DGELU);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
+  else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
   else HAMT_L(-1);
 #undef HAMT_L
 }

@@ -163,20 +163,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
   }
 }
 
-// ws[block][3][H] -> dgamma[H], dbeta[H], dxsum[H] (each accumulated).  block = 64 columns x 4 partial-row phases.
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ dxsum) {
+// ws[block][3][H] -> dgamma[H], dbeta[H], dxsum[H] (each accumulated).  block = 64 columns x 16 partial-row phases.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dxsum) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   const int which = c / H, col = c % H;
   float s = 0.f;
   if (c < 3 * H)
-    for (int b = ph; b < nb; b += 4) s += ws[((size_t)b * 3 + which) * H + col];
-  __shared__ float red[4][64];
+    for (int b = ph; b < nb; b += 16) s += ws[((size_t)b * 3 + which) * H + col];
+  __shared__ float red[16][64];
   red[ph][threadIdx.x & 63] = s;
   __syncthreads();
   if (ph == 0 && c < 3 * H) {
     float* o = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
-    if (o) o[col] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (o) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+      o[col] += t;
+    }
   }
 }
 
@@ -216,7 +221,7 @@ extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* 
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
   if (dgamma || dbeta || dxsum)
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(1024), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
   return HAMT_OK;
 }

@@ -269,6 +269,9 @@ def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=No
         dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
         if fast:
             gemm(dy16[:, :N], x16, dw, a_kmajor=True, b_kmajor=True, prec=prec)
+        elif K <= 8 and x2 is not None and dy2.dtype == torch.float32 and x2.dtype == torch.float32:
+            ws = torch.empty(64 * N * K, dtype=torch.float32, device=dy2.device)
+            L.check(L.load().hamt_smallk_wgrad(M, N, K, _p(dy2), _ld(dy2), _p(x2), _ld(x2), _p(dw), 0, _p(ws), _stream()), "hamt_smallk_wgrad")
         else:
             gemm(dy2, x2 if x2 is not None else x16[:M], dw, a_kmajor=True, b_kmajor=True, prec=prec)
     if need_db:
