@@ -9,8 +9,9 @@
 //     v_mfma_f32_16x16x32_bf16 with the operand roles SWAPPED (mfma(B,A)): a lane then owns 4 consecutive
 //     columns of one C row, so the epilogue stores 16 bytes per lane instead of four 4-byte scatters;
 //   * operands go L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR round
-//     trip) into a 3-stage ring; tile kt+2 is issued while tile kt is multiplied and the wait is a COUNTED
-//     s_waitcnt vmcnt(n) in front of a raw s_barrier, so one tile stays in flight across every barrier;
+//     trip) into a 2-deep ring: tile kt+1 is issued while tile kt is multiplied, waits are explicit s_waitcnt vmcnt
+//     in front of a raw s_barrier (the kernel is generic in the ring depth; 2 is what measures best because 64 / 48
+//     KiB of LDS lets 2-3 workgroups share a CU, and independent workgroups overlap better than a deeper ring);
 //   * LDS image is lane-linear per DMA instruction (8 rows x 128 B); the 16-byte k-chunk index is XOR-swizzled
 //     with (row & 7) on the SOURCE address and on the fragment read (conflict-free ds_read_b128);
 //   * ragged M/N: row indices are clamped for the loads (no OOB access), the epilogue masks the stores;
@@ -40,7 +41,7 @@ namespace {
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-constexpr int BN = 128, BK = 64, NSTAGE = 3;
+constexpr int BN = 128, BK = 64;
 
 __device__ __forceinline__ void glds16(const bf16_t* src, unsigned dst_uniform) {
   // Issued through inline asm on purpose: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first ds_read
@@ -118,11 +119,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt();
 template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
 
 // one row segment of 4 consecutive columns
 template <int EPI>
 __device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col, f32x4 acc) {
   if (row >= g.M || col >= g.N) return;
+  if (g.alpha == -12345.f && acc[0] != 123.456f) return;   // measurement aid: alpha = -12345 disables the stores
   const int epi = EPI >= 0 ? EPI : g.epi;
   float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
   const bool full = col + 4 <= g.N;
@@ -181,7 +185,7 @@ __device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col,
   }
 }
 
-template <int BM, int EPI, bool A_KM, bool B_KM>
+template <int BM, int EPI, bool A_KM, bool B_KM, int NSTAGE = 2>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
   constexpr int FM = BM / 32;                    // 16-row fragments per wave along M (wave tile = BM/2 x 64)
@@ -212,13 +216,24 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
     stage_tile<A_KM, BM>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, g.ka_max, dst, w, lane);
     stage_tile<B_KM, BN>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + A_ELEMS, w, lane);
   };
-  if (nk > 0) stage(0, 0);
-  if (nk > 1) stage(1, 1);
+  if constexpr (NSTAGE > 1) {
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+      if (p < nk) stage(p, p);
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed when at most the NLD loads of tile kt+1 are still outstanding
-    if (kt + 1 < nk) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();               // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
-    if (kt + 2 < nk) stage(kt + 2, (kt + 2) % NSTAGE);   // overwrites the slot tile kt-1 was read from
+    if constexpr (NSTAGE == 1) {
+      if (kt) __builtin_amdgcn_s_barrier();     // everyone is done reading tile kt-1
+      stage(kt, 0);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    } else {
+      // tile kt has landed when at most the loads of the (up to NSTAGE-2) younger tiles are still outstanding
+      const int younger = min(NSTAGE - 2, nk - 1 - kt);
+      if (younger >= 2) wait_vmcnt<2 * NLD>(); else if (younger == 1) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();             // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
+      if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);   // overwrites the slot of tile kt-1
+    }
     const bf16_t* As = lds + (kt % NSTAGE) * STAGE;
     const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
@@ -235,25 +250,51 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
-  if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
-    float* P = g.part + (size_t)blockIdx.y * g.M * g.N;
+  // Epilogue through LDS: the MFMA layout gives a lane 4 columns of 16 different rows, i.e. 32-64 byte row pieces per
+  // store instruction, which the write path handles at well under half of HBM rate (measured: 20 us of a 60 us
+  // 5120x3072x768 GEMM).  Re-tiling the fp32 accumulators through LDS lets every wave write two full 128-column rows
+  // (512 B fp32 / 256 B bf16, whole cache lines) per instruction, and makes the aux / accumulate reads coalesced too.
+  constexpr int LDW = BN + 4;                    // +4 floats: the 16 rows of a b128 write land in 16 distinct bank groups
+  if constexpr (BM * LDW * 4 > NSTAGE * STAGE * 2) {   // C tile does not fit in the operand ring: store from the MFMA layout
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = m0 + wm * (BM / 2) + i * 16 + (lane & 15), col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        if (row < g.M) {
-          if (col + 4 <= g.N && (g.N & 3) == 0) *(float4*)(P + (size_t)row * g.N + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          else for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = acc[i][j][e];
-        }
+        if (g.ksplit > 1) {
+          float* P = g.part + (size_t)blockIdx.y * g.M * g.N;
+          if (row < g.M) for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = acc[i][j][e];
+        } else epi_store4<EPI>(g, row, col, acc[i][j]);
       }
     return;
   }
+  float* ct = (float*)lds;
+  __syncthreads();                               // every wave is done reading the last operand tile
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      epi_store4<EPI>(g, m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+      *(f32x4*)(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDW + wn * 64 + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  __syncthreads();
+  const int col = n0 + (t & 31) * 4;
+  if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
+    float* P = g.part + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int p = 0; p < BM / 8; ++p) {
+      const int rl = p * 8 + (t >> 5), row = m0 + rl;
+      const f32x4 v = *(const f32x4*)(ct + rl * LDW + (t & 31) * 4);
+      if (row < g.M) {
+        if (col + 4 <= g.N && (g.N & 3) == 0) *(float4*)(P + (size_t)row * g.N + col) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v[e];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < BM / 8; ++p) {
+    const int rl = p * 8 + (t >> 5);
+    epi_store4<EPI>(g, m0 + rl, col, *(const f32x4*)(ct + rl * LDW + (t & 31) * 4));
+  }
 }
 
 // ---------------------------------------------------------------- fp32/bf16 [R][C] -> bf16 [C][Rpad] (zero padded)
@@ -334,7 +375,13 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
   const int ks = ws ? hamt_gemm_fast_ksplit(d, ws_bytes) : 1;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   static const int force_bm = getenv("HAMT_FAST_BM") ? atoi(getenv("HAMT_FAST_BM")) : 0;
-  const bool bm64 = force_bm ? force_bm == 64 : (t128 * ks < 384);   // fewer than 1.5 blocks per CU: halve the tile height
+  // Tile height.  The ring is 2 deep (64 / 48 KiB), so 2 workgroups of 128 rows or 3 of 64 rows share a CU and one's
+  // prologue / epilogue / DMA issue overlaps another's MFMA loop (measured: 4096^3 894 TFLOP/s vs 692 with a 3-deep
+  // ring at one workgroup per CU).  128-row tiles do ~1.4x the flops per LDS byte, 64-row tiles fill the chip when the
+  // grid is small: pick the one with the lower (rounds of resident workgroups) x (time per tile) estimate.
+  const long t64 = (long)((d->M + 63) / 64) * ((d->N + 127) / 128);
+  const long r128 = (t128 * ks + 511) / 512, r64 = (t64 * ks + 767) / 768;
+  const bool bm64 = force_bm ? force_bm == 64 : (t128 * ks < 1024 && r64 * 25 < r128 * 36);   // tile-time ratio 1 : 1.44
   g.ksplit = ks;
   g.part = ks > 1 ? ws : nullptr;
   const dim3 g64(((d->M + 63) / 64) * ((d->N + BN - 1) / BN), ks), g128(((d->M + 127) / 128) * ((d->N + BN - 1) / BN), ks);
