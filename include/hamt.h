@@ -93,6 +93,25 @@ int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dtype_x, void*
 int hamt_smallk_wgrad(int M, int N, int K, const float* dy, int lddy, const float* x, int ldx, float* dW,
                       int accumulate, float* ws, void* stream);
 
+/* Grouped weight gradients: n independent problems in as few launches as the kernarg table allows,
+ *     dW_p[M_p][N_p] (+)= dY_p^T X_p      and, when db != NULL,      db_p[M_p] (+)= column sums of dY_p,
+ * with dY_p bf16 [K_p][ldy] (its M_p columns = the layer's output features) and X_p bf16 [K_p][ldx] (the layer's input
+ * image), both exactly as the forward / dgrad GEMMs left them (K_p = rows padded to a multiple of 64 with ZERO rows).
+ * This is what torch.autograd does one nn.Linear at a time in the reference (vilmodel.py: every nn.Linear backward);
+ * weight gradients are not on the backward critical path, so the host queues them and hands the whole list over once per
+ * backward pass: 768x768 outputs that alone fill 36 CUs become one chip-filling grid without split-K.
+ * `probs` is a HOST array.  Requirements per problem: K % 64 == 0, ldy % 8 == 0 && ldy >= 64, ldx % 8 == 0 && ldx >= 128,
+ * dy / x 16-byte aligned.  Deterministic (fixed summation order per output element). */
+typedef struct {
+  const void* dy;
+  const void* x;
+  float* dw;
+  float* db; /* may be NULL */
+  int M, N, K, ldy, ldx, ldw;
+  int accum_dw, accum_db; /* 0: store, 1: += */
+} hamt_wgrad_desc;
+int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* stream);
+
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
 int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate,
                 float* ws, void* stream);

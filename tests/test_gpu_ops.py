@@ -159,6 +159,82 @@ torch.save((o1.cpu(), o2.cpu()), sys.argv[1])
         assert torch.equal(x, y)
 
 
+def test_wgrad_grouped_matches_per_problem_reference():
+    """hamt_wgrad_grouped: heterogeneous problems in one call (ragged M/N, column-slice operands, short and long K,
+    store and accumulate, fused bias sums) against fp64 matmuls of the same bf16 operands."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as L
+    ops = _ops()
+    lib = L.load()
+    specs = [  # (K rows, M out, N in, accum_dw, with_db, accum_db)
+        (5120, 768, 768, 0, True, 0), (5120, 768, 3072, 0, False, 0), (5120, 3072, 768, 1, True, 1), (384, 768, 768, 0, True, 0),
+        (2368 + 64 - 2368 % 64, 104, 136, 0, True, 0), (64, 8, 128, 1, False, 0), (11520, 768, 768, 0, True, 1), (640, 2304, 768, 0, True, 0),
+    ]
+    specs = specs * 6      # > one kernarg table (40 problems) => several launches
+    keep, refs = [], []
+    descs = (L.WgradDesc * len(specs))()
+    for i, (K, M, N, aw, wdb, ab) in enumerate(specs):
+        valid = K - (i % 3) * 7                    # rows >= valid are zero padding
+        dyf = rnd(K, max(M + 8, 64), seed=3 * i, scale=0.5)
+        dyf[valid:] = 0
+        dy = dyf.to(torch.bfloat16).to(DEV)[:, 8 * (i % 2):8 * (i % 2) + M]   # column slice of a wider buffer
+        x = rnd(K, N, seed=3 * i + 1).to(torch.bfloat16).to(DEV)
+        dw0 = rnd(M, N, seed=3 * i + 2)
+        db0 = rnd(M, seed=3 * i + 5)
+        dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
+        keep += [dy, x, dw, db]
+        d = descs[i]
+        d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if wdb else None)
+        d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = M, N, K, dy.stride(0), x.stride(0), N, aw, ab
+        rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
+        rb = (dy.double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
+        refs.append((dw, db, rw, rb))
+    L.check(lib.hamt_wgrad_grouped(len(specs), descs, ops._stream()), "hamt_wgrad_grouped")
+    torch.cuda.synchronize()
+    for i, (dw, db, rw, rb) in enumerate(refs):
+        close(dw, rw, 3e-5, f"dW[{i}] {specs[i]}")
+        close(db, rb, 3e-5, f"db[{i}] {specs[i]}")
+    # argument validation is loud
+    descs[0].K = 100
+    with pytest.raises(L.HamtError):
+        L.check(lib.hamt_wgrad_grouped(1, descs, ops._stream()), "hamt_wgrad_grouped")
+
+
+def test_deferred_wgrad_queue_semantics():
+    """wgrad.py: queued gradients are published as .grad at the end of backward; a parameter used twice in one pass and
+    gradient accumulation over two passes sum like autograd's AccumulateGrad; results equal the immediate path."""
+    from vln_hamt_amd import wgrad
+    ops = _ops()
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 192).to(DEV)
+    x1 = rnd(130, 256, seed=1).to(DEV).requires_grad_()
+    x2 = rnd(70, 256, seed=2).to(DEV)
+
+    def run(enabled):
+        wgrad.ENABLED = enabled
+        try:
+            lin.weight.grad = lin.bias.grad = None
+            x1.grad = None
+            y = ops.linear(x1, lin.weight, lin.bias, prec="bf16").square().sum() + ops.linear(x2, lin.weight, lin.bias, prec="bf16").sum()
+            y.backward()
+            assert wgrad.pending() == 0
+            g1 = (lin.weight.grad.clone(), lin.bias.grad.clone(), x1.grad.clone())
+            (ops.linear(x2, lin.weight, lin.bias, prec="bf16").sum() * 2).backward()      # accumulate over a second pass
+            return g1, (lin.weight.grad.clone(), lin.bias.grad.clone())
+        finally:
+            wgrad.ENABLED = True
+
+    n0 = wgrad.stats["problems"]
+    (w_d, b_d, dx_d), (w_d2, b_d2) = run(True)
+    assert wgrad.stats["problems"] - n0 == 3
+    (w_i, b_i, dx_i), (w_i2, b_i2) = run(False)
+    close(w_d, w_i, 2e-5, "dW deferred vs immediate")
+    close(b_d, b_i, 2e-3, "db deferred vs immediate")   # queued db sums the bf16 image of dY, the immediate path fp32 dY
+    close(dx_d, dx_i, 0.0, "dx")
+    close(w_d2, w_i2, 2e-5, "dW after a second pass")
+    close(b_d2, b_i2, 2e-3, "db after a second pass")
+
+
 def test_cast_pad_and_transpose_exact():
     ops = _ops()
     x = rnd(77, 100, seed=1)

@@ -27,6 +27,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from . import wgrad
 from .ops import _ln_bwd, _ln_fwd, _p, _rup, _stream, cast_pad16, colsum, gemm, next_call_id, rng_state, shadow16, weight_operand
 
 ENABLED = os.environ.get("HAMT_NO_FUSED_BLOCKS") is None
@@ -109,6 +110,13 @@ def _proj_bwd(d16, M, x16, ws, bs, dx_accum_into=None, need_dx=True):
                 n = w.shape[0]
                 gemm(d16[:M, c:c + n], weight_operand(w, "bf16"), dx, b_kmajor=True, epilogue=acc if i == 0 else L.EPI_ACCUM)
                 c += n
+    if all(wgrad.eligible(w, d16[:, :w.shape[0]], x16) for w in ws):
+        c = 0
+        for w, b in zip(ws, bs):                 # queued: one grouped launch per backward pass (wgrad.py)
+            n = w.shape[0]
+            wgrad.defer(w, b, d16[:, c:c + n], x16)
+            c += n
+        return dx, [None] * len(ws), [None] * len(ws)
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
     gemm(d16, x16, dW, a_kmajor=True, b_kmajor=True)
     db = colsum(d16[:M])
@@ -119,6 +127,16 @@ def _proj_bwd(d16, M, x16, ws, bs, dx_accum_into=None, need_dx=True):
         dbs.append(db[c:c + n])
         c += n
     return dx, dws, dbs
+
+
+def _wgrad(w, b, dy16, x16, M):
+    """(dW, db) now, or (None, None) after queueing them for the grouped end-of-pass launch"""
+    if wgrad.eligible(w, dy16, x16):
+        wgrad.defer(w, b, dy16, x16)
+        return None, None
+    dw = torch.empty(w.shape, dtype=torch.float32, device=dy16.device)
+    gemm(dy16, x16, dw, a_kmajor=True, b_kmajor=True)
+    return dw, (colsum(dy16[:M]) if b is not None else None)
 
 
 # ================================================================================================= self attention block
@@ -162,8 +180,7 @@ class SelfAttnBlockFn(torch.autograd.Function):
                                                   cid_ln, False, True, True)
         dctx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev)
         gemm(dx16[:M], weight_operand(wo, "bf16"), dctx16[:M], b_kmajor=True)
-        dwo = torch.empty(H, H, dtype=torch.float32, device=dev)
-        gemm(dx16, ctx16, dwo, a_kmajor=True, b_kmajor=True)
+        dwo, _ = _wgrad(wo, None, dx16, ctx16, M)
         dqkv16 = _zeros_or_empty(Mp, M, 3 * H, dev)
         d = _attn_desc(B, heads, S, S, H, 3 * H, 3 * H, 3 * H, p_attn, cid)
         q, k, v = qkv16[:, :H], qkv16[:, H:2 * H], qkv16[:, 2 * H:]
@@ -220,8 +237,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
                                                   cid_ln, False, True, True)
         dctx16 = torch.empty(Mqp, H, dtype=torch.bfloat16, device=dev)
         gemm(dx16[:Mq], weight_operand(wo, "bf16"), dctx16[:Mq], b_kmajor=True)
-        dwo = torch.empty(H, H, dtype=torch.float32, device=dev)
-        gemm(dx16, ctx16, dwo, a_kmajor=True, b_kmajor=True)
+        dwo, _ = _wgrad(wo, None, dx16, ctx16, Mq)
         dq16 = _zeros_or_empty(Mqp, Mq, H, dev)
         dkv16 = _zeros_or_empty(Mkp, Mk, 2 * H, dev)
         d = _attn_desc(B, heads, Sq, Sk, H, H, 2 * H, 2 * H, p_attn, cid)
@@ -269,12 +285,9 @@ class FfnBlockFn(torch.autograd.Function):
                                                   cid_ln, False, True, True)
         dh16 = _zeros_or_empty(Mp, M, I, dev)
         gemm(dx16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_AUX, aux=pre)     # dG * gelu'(pre)
-        dw2 = torch.empty(H, I, dtype=torch.float32, device=dev)
-        gemm(dx16, g16, dw2, a_kmajor=True, b_kmajor=True)
+        dw2, _ = _wgrad(w2, None, dx16, g16, M)
         gemm(dh16[:M], weight_operand(w1, "bf16"), dz, b_kmajor=True, epilogue=L.EPI_ACCUM)                     # dx = dz + dH W1
-        dw1 = torch.empty(I, H, dtype=torch.float32, device=dev)
-        gemm(dh16, x16, dw1, a_kmajor=True, b_kmajor=True)
-        db1 = colsum(dh16[:M])
+        dw1, db1 = _wgrad(w1, b1, dh16, x16, M)
         return dz.view(shp), None, None, dw1, db1, dw2, db2, dgamma, dbeta
 
 

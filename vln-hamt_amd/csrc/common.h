@@ -30,6 +30,7 @@ void hamt_set_error(const char* fmt, ...);
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef unsigned short bf16_t;  // raw bf16 bits in memory
 
 // ---- bf16 <-> f32 (round to nearest even; NaN preserved)

@@ -19,6 +19,8 @@
 //     order) for the weight-gradient shapes: 768x768 outputs with K = B*L >= 5120 would otherwise use 36 CUs;
 //   * the epilogue is compiled per flag set (template) -- a dynamic one unrolled 64x overflowed the I-cache.
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s);
 
@@ -127,7 +129,7 @@ template <int EPI>
 __device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col, f32x4 acc) {
   if (row >= g.M || col >= g.N) return;
   if (g.alpha == -12345.f && acc[0] != 123.456f) return;   // measurement aid: alpha = -12345 disables the stores
-  const int epi = EPI >= 0 ? EPI : g.epi;
+  const int epi = EPI >= 0 ? EPI : (EPI == -2 ? (g.epi & HAMT_EPI_ACCUM) : g.epi);   // -2: plain store or C += only
   float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
   const bool full = col + 4 <= g.N;
   if (epi & HAMT_EPI_BIAS) {
@@ -185,25 +187,22 @@ __device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col,
   }
 }
 
-template <int BM, int EPI, bool A_KM, bool B_KM, int NSTAGE = 2>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
+// One BMx128 output tile over k-tiles [kt0, kt0 + nk).  COLSUM (weight-gradient form, A = dY stored [K][M]): the wave
+// column wn == 0 of the tiles with n0 == 0 also reduces A over k with one extra MFMA per fragment against a ones
+// operand (D'[n][m] = sum_k 1 * A[m][k]) -- the bias gradient, for free of any extra pass over dY.
+template <int BM, int EPI, bool A_KM, bool B_KM, int NSTAGE, bool COLSUM>
+__device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, int kt0, int nk, int slice, float* db, int db_accum) {
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
   constexpr int FM = BM / 32;                    // 16-row fragments per wave along M (wave tile = BM/2 x 64)
   constexpr int NLD = (BM + BN) / 32;            // glds instructions per wave per stage (8 or 6)
   __shared__ __attribute__((aligned(16))) bf16_t lds[NSTAGE * STAGE];
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-  // XCD-aware remap (blocks are dealt round-robin to the 8 XCDs): give each XCD a contiguous run of tile ids
-  int bid = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const bool do_cs = COLSUM && db != nullptr && n0 == 0 && wn == 0;   // wave-uniform
+  f32x4 cs[FM];
+  if constexpr (COLSUM) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-  // K range of this slice
-  const int nk_all = g.K / BK;
-  const int kt0 = (int)((long)nk_all * blockIdx.y / g.ksplit), kt1 = (int)((long)nk_all * (blockIdx.y + 1) / g.ksplit);
-  const int nk = kt1 - kt0;
 
   f32x4 acc[FM][4];
 #pragma unroll
@@ -248,6 +247,23 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)   // swapped roles: D[n][m] => lane owns C[m = lane&15][n = 4*(lane>>4) .. +3]
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      if constexpr (COLSUM) {
+        if (do_cs) {
+          const s16x8 one8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+          union { s16x8 s; bf16x8 v; } ones; ones.s = one8;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, af[i], cs[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if constexpr (COLSUM) {
+    if (do_cs && lane < 16) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = m0 + wm * (BM / 2) + i * 16 + lane;
+        if (row < g.M) db[row] = db_accum ? db[row] + cs[i][0] : cs[i][0];
+      }
     }
   }
   // Epilogue through LDS: the MFMA layout gives a lane 4 columns of 16 different rows, i.e. 32-64 byte row pieces per
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
       for (int j = 0; j < 4; ++j) {
         const int row = m0 + wm * (BM / 2) + i * 16 + (lane & 15), col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
         if (g.ksplit > 1) {
-          float* P = g.part + (size_t)blockIdx.y * g.M * g.N;
+          float* P = g.part + (size_t)slice * g.M * g.N;
           if (row < g.M) for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = acc[i][j][e];
         } else epi_store4<EPI>(g, row, col, acc[i][j]);
       }
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
   __syncthreads();
   const int col = n0 + (t & 31) * 4;
   if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
-    float* P = g.part + (size_t)blockIdx.y * g.M * g.N;
+    float* P = g.part + (size_t)slice * g.M * g.N;
 #pragma unroll
     for (int p = 0; p < BM / 8; ++p) {
       const int rl = p * 8 + (t >> 5), row = m0 + rl;
@@ -295,6 +311,46 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
     const int rl = p * 8 + (t >> 5);
     epi_store4<EPI>(g, m0 + rl, col, *(const f32x4*)(ct + rl * LDW + (t & 31) * 4));
   }
+}
+
+// tile id -> (m0, n0) with the XCD-aware remap (blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous
+// run of tile ids so that neighbouring tiles share operand rows in one L2)
+__device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int EPI, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int nk_all = g.K / BK;   // K range of this slice
+  const int kt0 = (int)((long)nk_all * blockIdx.y / g.ksplit), kt1 = (int)((long)nk_all * (blockIdx.y + 1) / g.ksplit);
+  gemm_tile<BM, EPI, A_KM, B_KM, 2, false>(g, (bid / tiles_n) * BM, (bid % tiles_n) * BN, kt0, kt1 - kt0, blockIdx.y, nullptr, 0);
+}
+
+// ---------------------------------------------------------------- grouped weight gradients
+// Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
+// of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
+// split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
+constexpr int WG_MAX = 40;
+struct WgradProb {
+  const bf16_t* dy; const bf16_t* x; float* dw; float* db;
+  int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
+};
+struct WgradArgs { int n, ntiles; WgradProb p[WG_MAX]; };
+
+template <int BM>
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(WgradArgs a) {
+  const int bid = xcd_remap(blockIdx.x, a.ntiles);
+  int pi = 0;
+  while (pi + 1 < a.n && bid >= a.p[pi].tile_end) ++pi;
+  const WgradProb& q = a.p[pi];
+  const int local = bid - (pi ? a.p[pi - 1].tile_end : 0);
+  const int tiles_n = (q.N + BN - 1) / BN;
+  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
+              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1};
+  gemm_tile<BM, -2, true, true, 2, true>(g, (local / tiles_n) * BM, (local % tiles_n) * BN, 0, q.K / BK, 0, q.db, q.flags & 2);
 }
 
 // ---------------------------------------------------------------- fp32/bf16 [R][C] -> bf16 [C][Rpad] (zero padded)
@@ -398,5 +454,42 @@ extern "C" int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dty
   if (dtype_x == HAMT_BF16) hipLaunchKernelGGL((cast_transpose_kernel<bf16_t>), grid, dim3(256), 0, as_stream(stream), R, C, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, Rpad);
   else hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, dim3(256), 0, as_stream(stream), R, C, (const float*)x, ldx, (bf16_t*)y, ldy, Rpad);
   HAMT_CHECK_LAUNCH("hamt_cast_transpose");
+  return HAMT_OK;
+}
+
+extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* stream) {
+  HAMT_CHECK_ARG(n >= 0 && (n == 0 || probs), "hamt_wgrad_grouped: bad argument");
+  std::vector<int> order;
+  for (int i = 0; i < n; ++i) {
+    const hamt_wgrad_desc& d = probs[i];
+    HAMT_CHECK_ARG(d.dy && d.x && d.dw && d.M >= 1 && d.N >= 1, "hamt_wgrad_grouped: problem %d: null pointer or empty output", i);
+    HAMT_CHECK_ARG(d.K >= 0 && d.K % 64 == 0, "hamt_wgrad_grouped: problem %d: K = %d is not a multiple of 64", i, d.K);
+    HAMT_CHECK_ARG(d.ldy % 8 == 0 && d.ldy >= 64 && d.ldy >= d.M && d.ldx % 8 == 0 && d.ldx >= 128 && d.ldx >= d.N && d.ldw >= d.N,
+                   "hamt_wgrad_grouped: problem %d: bad leading dimension (ldy %d, ldx %d, ldw %d)", i, d.ldy, d.ldx, d.ldw);
+    HAMT_CHECK_ARG((uintptr_t)d.dy % 16 == 0 && (uintptr_t)d.x % 16 == 0, "hamt_wgrad_grouped: problem %d: operands must be 16-byte aligned", i);
+    if (d.K > 0) order.push_back(i);
+    else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
+  }
+  // longest reductions first: the short tail tiles fill in behind them
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[a].K > probs[b].K; });
+  for (size_t c0 = 0; c0 < order.size(); c0 += WG_MAX) {
+    const int cn = (int)std::min<size_t>(WG_MAX, order.size() - c0);
+    long t128 = 0;
+    for (int i = 0; i < cn; ++i) { const hamt_wgrad_desc& d = probs[order[c0 + i]]; t128 += (long)((d.M + 127) / 128) * ((d.N + BN - 1) / BN); }
+    const int bm = t128 >= 1024 ? 128 : 64;      // same rule as hamt_gemm_fast_launch: fill the chip first
+    WgradArgs a;
+    a.n = cn;
+    int tiles = 0;
+    for (int i = 0; i < cn; ++i) {
+      const hamt_wgrad_desc& d = probs[order[c0 + i]];
+      tiles += ((d.M + bm - 1) / bm) * ((d.N + BN - 1) / BN);
+      a.p[i] = WgradProb{(const bf16_t*)d.dy, (const bf16_t*)d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy, d.ldx, d.ldw,
+                         (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles};
+    }
+    a.ntiles = tiles;
+    if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128>), dim3(tiles), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<64>), dim3(tiles), dim3(256), 0, as_stream(stream), a);
+    HAMT_CHECK_LAUNCH("hamt_wgrad_grouped");
+  }
   return HAMT_OK;
 }

@@ -248,9 +248,11 @@ def _linear_fwd(x2, weight, bias, out, act, prec, pre=None, x16=None):
     gemm(a, weight_operand(weight, prec), out, bias=bias, epilogue=epi, aux=pre if act == ACT_GELU else None, prec=prec)
 
 
-def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False, dy16=None):
+def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=None, dx_accumulate=False, dy16=None,
+                bias_param=False):
     """dy2 [M,N] (strided rows ok), x [M,K] (x16 = its padded bf16 image or None), weight [N,K] parameter
-    -> (dx [M,K], dW [N,K], db [N]).  bf16 mode: ONE padded bf16 image of dY feeds both contractions of the fast kernel:
+    -> (dx [M,K], dW [N,K], db [N]); `bias_param` = the bias parameter (or None) enables queueing dW/db (wgrad.py), in
+    which case dW and db come back as None.  bf16 mode: ONE padded bf16 image of dY feeds both contractions of the fast kernel:
     dX = dY16[M,Np] * W16 (W k-strided, "NN"), dW = dY16^T * X16 (both k-strided, "TN") -- no transposed copies."""
     M, N = dy2.shape
     K = weight.shape[1]
@@ -265,6 +267,11 @@ def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=No
             gemm(dy16[:M], weight_operand(weight, prec), dx, b_kmajor=True, epilogue=epi, prec=prec, k_red=dy16.shape[1])
         else:
             gemm(dy2, weight_operand(weight, prec), dx, b_kmajor=True, epilogue=epi, prec=prec)
+    if need_dw and fast and bias_param is not False:
+        from . import wgrad
+        if wgrad.eligible(weight, dy16[:, :N], x16):    # queued for the grouped end-of-pass launch (wgrad.py); db rides along
+            wgrad.defer(weight, bias_param if need_db else None, dy16[:, :N], x16)
+            return dx, None, None
     if need_dw:
         dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
         if fast:
@@ -301,6 +308,7 @@ class LinearFn(torch.autograd.Function):
         # the bf16 image is all backward needs of x (weight gradient operand); keep fp32 x only on the generic path
         ctx.save_for_backward(x2 if x16 is None else None, x16, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
         ctx.act, ctx.prec, ctx.has_bias, ctx.xshape, ctx.M = act, prec, bias is not None, x.shape, M
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf) else (None if bias is None else False)
         return y if x.dim() == 2 else y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -316,7 +324,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = dh
         dy2 = _operand(dy2)
         dx, dw, db = _linear_bwd(dy2, x2, x16, weight, ctx.prec, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                 ctx.has_bias and ctx.needs_input_grad[2])
+                                 ctx.has_bias and ctx.needs_input_grad[2], bias_param=ctx.bias_param)
         return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None, None
 
 
@@ -346,6 +354,7 @@ class PackedLinearFn(torch.autograd.Function):
             c += n
         ctx.save_for_backward(x2 if x16 is None else None, x16, *ws)
         ctx.prec, ctx.ns, ctx.xshape, ctx.M = prec, ns, x.shape, x2.shape[0]
+        ctx.bias_params = [b if b.is_leaf else False for b in bs]
         return out
 
     @staticmethod
@@ -361,7 +370,7 @@ class PackedLinearFn(torch.autograd.Function):
         c = 0
         for i, (w, n) in enumerate(zip(ws, ctx.ns)):
             _, dw, db = _linear_bwd(dout[:, c:c + n], x2, x16, w, ctx.prec, dx is not None, True, True, dx_out=dx,
-                                    dx_accumulate=i > 0, dy16=d16[:, c:c + n] if fast else None)
+                                    dx_accumulate=i > 0, dy16=d16[:, c:c + n] if fast else None, bias_param=ctx.bias_params[i])
             grads += [dw, db]
             c += n
         return (dx.view(ctx.xshape) if dx is not None else None), None, *grads

@@ -6,7 +6,8 @@ exp_avg / exp_avg_sq arenas and a bf16 shadow arena that the update kernel refre
 (the MFMA GEMMs read their weight operands from it, so no per-step cast of the weights is needed).
 
 ``step()`` = three launches, independent of the number of parameters:
-  1. gradients are packed into the arena (one fused multi-tensor copy);
+  1. gradients are packed into the arena (one fused multi-tensor copy) -- except the weight / bias gradients of the
+     bf16 GEMM path, which the grouped weight-gradient launch (wgrad.py) already wrote into their arena slots;
   2. ``clip_grad_norm_`` reduces the global L2 norm on device and defers the scaling into the update;
   3. ``hamt_adamw_table``: per-parameter {lr, bias-corrected step size, weight decay, active} come from a small
      device table refreshed by the host each step.  Parameters whose ``grad is None`` are skipped like the
@@ -89,7 +90,13 @@ class AdamW(Optimizer):
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._sync_shadow_views()
+        self._publish_grad_slots()
         self._built = True
+
+    def _publish_grad_slots(self):
+        """Let the grouped weight-gradient launch (wgrad.py) write straight into the flat gradient arena."""
+        for p, o in zip(self._params, self._offs):
+            p._hamt_grad_slot = self._flat_g[o:o + p.numel()].view(p.shape)
 
     def _sync_shadow_views(self):
         """Publish the bf16 shadow of every >=2-D parameter as the GEMM weight operand (see ops.weight_operand)."""
@@ -111,7 +118,7 @@ class AdamW(Optimizer):
         for p, o in zip(self._params, self._offs):
             a = p.grad is not None
             active.append(a)
-            if a:
+            if a and p.grad.data_ptr() != self._flat_g.data_ptr() + 4 * o:   # else: already written in place (wgrad.py)
                 src.append(p.grad.reshape(-1))
                 dst.append(self._flat_g[o:o + p.numel()])
         if src:

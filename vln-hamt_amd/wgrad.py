@@ -1,0 +1,140 @@
+"""Deferred, grouped weight gradients for the bf16 path.
+
+In the reference every ``nn.Linear`` backward computes dW = dY^T X (and db = column sums of dY) on the spot
+(vilmodel.py: all nn.Linear layers, through torch.autograd).  Weight gradients are not on the backward critical
+path -- only the optimizer reads them -- and one 768x768 output covers 36 of the 256 CUs, so here the block /
+linear backward functions only *queue* (W, b, dY16, X16) and the whole list is handed to ``hamt_wgrad_grouped``
+once, when the autograd engine finishes the pass (``queue_callback``): a handful of chip-filling launches with
+full-length K loops, bias sums fused in (one extra MFMA per fragment), no split-K scratch and no reduce pass.
+
+Where the result goes: a parameter that owns a slot in the optimizer's flat gradient arena (``_hamt_grad_slot``,
+set by optim.AdamW) gets its gradient written there directly and ``p.grad`` becomes that view, so the optimizer has
+nothing to pack; otherwise a fresh fp32 tensor.  A parameter that already has a ``.grad`` when the queue is flushed
+(several uses in one pass, the embedding table tied to the MLM decoder, or gradient accumulation over passes) is
+accumulated into in place -- the sum autograd's AccumulateGrad would have formed.
+
+Consequence for callers: for queued parameters the Function's backward returns None, i.e. AccumulateGrad hooks
+(torch DDP) do not fire for them; multi-GPU training all-reduces the flat arena instead (parallel.allreduce_grads).
+``torch.autograd.grad`` w.r.t. such parameters is not supported on the bf16 path (use ``.backward()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+
+ENABLED = os.environ.get("HAMT_NO_DEFER_WGRAD") is None     # ablation switch: compute every dW immediately
+
+_items: List[tuple] = []
+_scheduled = [False]
+stats = {"flushes": 0, "problems": 0}
+
+
+def eligible(w: torch.Tensor, dy16: torch.Tensor, x16: torch.Tensor) -> bool:
+    """Can dW = dy16^T x16 for parameter `w` go through the grouped kernel?"""
+    if not ENABLED:
+        return False
+    if w.dim() != 2 or w.dtype != torch.float32 or not w.is_leaf or not w.requires_grad:
+        return False
+    if dy16.dtype != torch.bfloat16 or x16.dtype != torch.bfloat16 or dy16.dim() != 2 or x16.dim() != 2:
+        return False
+    K = dy16.shape[0]
+    if K != x16.shape[0] or K % 64 or dy16.shape[1] != w.shape[0] or x16.shape[1] != w.shape[1]:
+        return False
+    if dy16.stride(1) != 1 or x16.stride(1) != 1:
+        return False
+    ldy, ldx = dy16.stride(0), x16.stride(0)
+    if ldy % 8 or ldx % 8 or ldy < 64 or ldx < 128 or dy16.data_ptr() % 16 or x16.data_ptr() % 16:
+        return False
+    return True
+
+
+def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: torch.Tensor):
+    """Queue dW (+ db when `b` is a parameter that needs a gradient).  Must be called from inside a backward pass."""
+    if b is not None and not b.requires_grad:
+        b = None
+    _items.append((w, b, dy16, x16))
+    if not _scheduled[0]:
+        _scheduled[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush)
+
+
+def pending() -> int:
+    return len(_items)
+
+
+def reset():
+    """Drop queued work (after an exception inside a backward pass left the queue behind)."""
+    _items.clear()
+    _scheduled[0] = False
+
+
+def _target(p: torch.Tensor, targets: dict, fresh: list):
+    t = targets.get(id(p))
+    if t is not None:
+        return t, 1
+    g = p.grad
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
+        targets[id(p)] = g
+        return g, 1
+    slot = getattr(p, "_hamt_grad_slot", None)
+    if slot is not None and slot.shape == p.shape and slot.device == p.device:
+        t = slot
+    else:
+        t = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+    targets[id(p)] = t
+    fresh.append((p, t))
+    return t, 0
+
+
+@torch.no_grad()
+def flush():
+    """Launch everything queued and publish the results as ``.grad``.  Runs as the autograd engine's end-of-pass
+    callback (on the caller's current stream); harmless to call when the queue is empty."""
+    from .ops import _stream
+    items = list(_items)
+    _items.clear()
+    _scheduled[0] = False
+    if not items:
+        return
+    targets: dict = {}
+    fresh: list = []
+    # Two problems that write the same buffer (a parameter used twice in the pass) must not share a launch: the k-th
+    # write to a buffer goes into the k-th launch group, and groups run in stream order.
+    seen: dict = {}
+    groups: List[list] = []
+    for (w, b, dy16, x16) in items:
+        tw, aw = _target(w, targets, fresh)
+        tb, ab = (None, 0)
+        if b is not None:
+            tb, ab = _target(b, targets, fresh)
+        k = seen.get(id(tw), 0)
+        if tb is not None:
+            k = max(k, seen.get(id(tb), 0))
+        seen[id(tw)] = k + 1
+        if tb is not None:
+            seen[id(tb)] = k + 1
+        while len(groups) <= k:
+            groups.append([])
+        groups[k].append((w, dy16, x16, tw, aw or k > 0, tb, ab or k > 0))
+    lib = L.load()
+    for grp in groups:
+        descs = (L.WgradDesc * len(grp))()
+        for i, (w, dy16, x16, tw, aw, tb, ab) in enumerate(grp):
+            d = descs[i]
+            d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), tw.data_ptr(), (tb.data_ptr() if tb is not None else None)
+            d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
+            d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), tw.stride(0)
+            d.accum_dw, d.accum_db = int(bool(aw)), int(bool(ab))
+        L.check(lib.hamt_wgrad_grouped(len(grp), descs, _stream()), "hamt_wgrad_grouped")
+    stats["flushes"] += 1
+    stats["problems"] += len(items)
+    for p, t in fresh:
+        if p.grad is None:
+            p.grad = t
+        else:                                   # an existing gradient of another dtype / layout
+            p.grad.add_(t.to(p.grad.dtype))
