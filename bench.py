@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU minibatch (ITM uses batch/2 originals, loader.py:130)")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--task", default="mix", help="mix (5:1:1:1:2:2 cycle) or one of mlm/sap/sar/sprel/mrc/itm")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1 only uses graphs)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -143,7 +143,8 @@ def main():
     from vln_hamt_amd import ops
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
-    from vln_hamt_amd.parallel import TaskSchedule, barrier, init_distributed, max_over_ranks, sum_over_ranks, wrap_ddp
+    from vln_hamt_amd.parallel import (TaskSchedule, allreduce_grads, barrier, broadcast_params, init_distributed, max_over_ranks,
+                                       sum_over_ranks)
     from vln_hamt_amd.synth import make_batch, make_itm_rng
 
     rank, local_rank, world = init_distributed()
@@ -159,8 +160,12 @@ def main():
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in NO_DECAY)], "weight_decay": 0.01},
               {"params": [p for n, p in named if any(nd in n for nd in NO_DECAY)], "weight_decay": 0.0}]
     opt = AdamW(groups, lr=5e-5, betas=(0.9, 0.98))
-    opt.materialize()                                   # flat arenas before DDP captures the parameters
-    net = wrap_ddp(model, local_rank) if world > 1 else model
+    opt.materialize()                                   # flat fp32 parameter / gradient / moment arenas + bf16 shadow
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if dist_on:
+        broadcast_params(opt)                           # every rank starts from rank 0's weights (DDP does this at wrap time)
+    grad_sync = allreduce_grads if dist_on else None    # flat-arena RCCL all-reduce between backward and the update
+    net = model
 
     sched = TaskSchedule(cyclic=True) if args.task == "mix" else None
     n_distinct = 12
@@ -183,11 +188,11 @@ def main():
         get_batch(s)
     log("batches resident in HBM")
     gstep = [0]
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     graphed = None
     if use_graph:
         from vln_hamt_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opt, max_grad_norm=5.0)
+        graphed = GraphedTrainStep(model, opt, max_grad_norm=5.0, grad_sync=grad_sync)
 
     def train_step(step):
         task, b = get_batch(step)
@@ -200,6 +205,8 @@ def main():
             return task, b["txt_ids"].shape[0]
         loss = net(b, task, True).mean()
         loss.backward()
+        if grad_sync is not None:
+            grad_sync(opt)
         gstep[0] += 1
         lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
         for g in opt.param_groups:
@@ -247,7 +254,8 @@ def main():
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
-                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if graphed is not None else "eager"},
+                       "parallelism": f"dp{world}" + (" (flat-arena RCCL all-reduce)" if dist_on else ""),
+                       "launch": "hipGraph replay" if graphed is not None else "eager"},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -258,8 +266,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         else:
             out["cpu_baseline"] = None
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL printf()s its library path into C stdio: keep the JSON the LAST line
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     barrier()
+    if dist_on:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -46,7 +46,8 @@ def _worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     from _util import tiny_cfg
     from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
-    from vln_hamt_amd.parallel import TaskSchedule, barrier, init_distributed, max_over_ranks, sum_over_ranks, wrap_ddp
+    from vln_hamt_amd.parallel import (TaskSchedule, allreduce_mean_, barrier, init_distributed, max_over_ranks, sum_over_ranks,
+                                       wrap_ddp)
     from vln_hamt_amd.synth import make_batch
     r, lr, w = init_distributed(backend="gloo")
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
@@ -78,6 +79,24 @@ def _worker(rank, world, port, out_dir):
             else:   # relative to the global gradient scale (some gradients are exactly 0 in exact arithmetic)
                 worst = max(worst, float((grads[k] - p.grad).abs().max()) / gmax)
         assert worst < 1e-5, worst
+    # 2b) the product's exchange: per-rank gradients laid out in ONE flat arena (zeros for unused heads, 8-element
+    #     aligned slots like optim.AdamW), chunked all-reduce average == DDP's result == the concatenated-batch gradient
+    local = OracleModule(sd, cfg)
+    local(batch, "sap").mean().backward()
+    offs, n = [], 0
+    for p in local.params:
+        offs.append(n)
+        n += (p.numel() + 7) // 8 * 8
+    flat = torch.zeros(n)
+    for p, o in zip(local.params, offs):
+        if p.grad is not None:
+            flat[o:o + p.numel()] = p.grad.reshape(-1)
+    allreduce_mean_(flat, chunk_elems=100_003)            # several ragged chunks
+    gscale = max(float(g.abs().max()) for g in grads.values() if g is not None)
+    for k, p, o in zip(local.names, local.params, offs):
+        got = flat[o:o + p.numel()].view(p.shape)
+        want = grads[k] if grads[k] is not None else torch.zeros_like(got)
+        assert float((got - want).abs().max()) <= 1e-6 * gscale, k
     # 3) reductions used by bench.py
     assert max_over_ranks(float(rank + 1), "cpu") == float(world)
     assert sum_over_ranks(2.0, "cpu") == 2.0 * world

@@ -8,14 +8,26 @@ before each replay), lazily cached weight shadows are invalidated before capture
 """
 from __future__ import annotations
 
+import time
+
 import torch
 
 from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_grad_norm: float = 5.0):
+    """`grad_sync` (multi-GPU): a callable run between backward and the optimizer, e.g. parallel.allreduce_grads.  The
+    step is then captured as TWO graphs -- forward/backward/packing per (task, shape) key, and one shared
+    norm + AdamW graph -- with the collective launched eagerly between the two replays on the same stream, so RCCL
+    never has to be captured."""
+
+    def __init__(self, model, optimizer, max_grad_norm: float = 5.0, grad_sync=None):
         self.model, self.opt, self.max_norm = model, optimizer, float(max_grad_norm)
+        self.grad_sync = grad_sync
+        # with a process group alive, RCCL's watchdog thread polls its events while we capture: only this thread's
+        # calls may be policed by the capture ("global" mode aborts the watchdog with hipErrorCapturedEvent)
+        self.capture_mode = "thread_local" if grad_sync is not None else "global"
+        self.update_graph = None
         self.graphs = {}
         self.pool = None
         # ONE dedicated stream for warm-up and for every capture: autograd's per-parameter AccumulateGrad nodes remember
@@ -27,12 +39,20 @@ class GraphedTrainStep:
     def _eager(self, batch, task):
         loss = self.model(batch, task, True).mean()
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.opt)
         from .optim import clip_grad_norm_
         clip_grad_norm_(self.model.parameters(), self.max_norm, optimizer=self.opt)
         self.opt.step()
         self.opt.zero_grad()
         ops.advance_rng_epoch(loss.device)
         return loss
+
+    def _update(self, dev):
+        gsq = self.opt.global_grad_sumsq()
+        self.opt._pending_clip = (gsq, self.max_norm)
+        self.opt.launch_step()
+        ops.advance_rng_epoch(dev)
 
     def _capture(self, key, batch, task):
         dev = next(self.model.parameters()).device
@@ -43,19 +63,30 @@ class GraphedTrainStep:
             loss = self._eager(batch, task).detach()      # .detach(): do not keep this step's autograd graph alive
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        if self.grad_sync is not None:
+            # RCCL's watchdog thread polls the events of collectives it has not reaped yet, and an event query from any
+            # thread while this process captures aborts it (hipErrorCapturedEvent, in "thread_local" mode too on
+            # ROCm 7.0 / torch 2.10).  Every collective has finished (synchronize above); give the watchdog (100 ms
+            # polling period) time to retire them so that it has nothing to query during the capture.
+            time.sleep(0.5)
         ops.invalidate_weight_caches()
         self.opt.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self.pool, stream=side):
+        with torch.cuda.graph(g, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
             loss_c = self.model(batch, task, True).mean()
             loss_c.backward()
-            gsq = self.opt.global_grad_sumsq()
-            self.opt._pending_clip = (gsq, self.max_norm)
-            self.opt.launch_step()
-            ops.advance_rng_epoch(dev)
+            if self.grad_sync is None:
+                self._update(dev)
+            else:
+                self.opt._pack_grads()
             loss_c = loss_c.detach()           # drop the captured step's autograd graph (its buffers live in the pool)
+        if self.grad_sync is not None:
+            if self.update_graph is None:      # norm + AdamW over the arena: the same launches for every key
+                self.update_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.update_graph, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
+                    self._update(dev)
         active = list(self.opt.active_mask)
         self.opt._pending_clip = None
         self.opt._packed = False
@@ -72,4 +103,9 @@ class GraphedTrainStep:
         g, loss_c, active = ent
         self.opt.prepare_step(active)
         g.replay()
+        if self.grad_sync is not None:
+            self.opt._packed = True            # the replay packed the gradients; only the collective is left
+            self.grad_sync(self.opt)
+            self.opt._packed = False
+            self.update_graph.replay()
         return loss_c

@@ -105,6 +105,12 @@ class AdamW(Optimizer):
             if p.dim() >= 2:
                 p._hamt_arena16 = (self._flat_p16[o:o + p.numel()].view(p.shape), self._flat_p, ver)
 
+    def refresh_shadow(self):
+        """Re-derive the bf16 shadow arena from the fp32 masters (after loading / broadcasting parameters in place)."""
+        L.check(L.load().hamt_cast_f32_bf16(self._n, _p(self._flat_p), _p(self._flat_p16), _stream()), "hamt_cast_f32_bf16")
+        torch.autograd.graph.increment_version(self._flat_p)
+        self._sync_shadow_views()
+
     def materialize(self):
         """Build the flat arenas now (re-homes p.data); call before wrapping the model in DDP / capturing a graph."""
         if not self._built:

@@ -1,11 +1,16 @@
 """Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
 
 The HAMT path shards by *samples* only: every rank runs the same task on its own minibatch and
-the only exchange is the gradient all-reduce, which torch DDP buckets and overlaps with backward
-(reference: pretrain_src/utils/misc.py:52-65 wraps the model the same way, find_unused_parameters=True because
-each proxy task leaves the other tasks' heads without gradient).  The reference also broadcasts the sampled task
-id every step (data/loader.py:56-59); here every rank derives it from a shared-seed host RNG instead, so no
-collective is needed for it.
+the only exchange is the gradient average.  The reference gets it from torch DDP (pretrain_src/utils/misc.py:52-65,
+find_unused_parameters=True because each proxy task leaves the other tasks' heads without gradient).  Here the
+gradients already sit in ONE flat fp32 arena (optim.AdamW; the GEMM weight gradients are written there directly by
+the grouped end-of-pass launch, wgrad.py, which bypasses the per-parameter autograd hooks DDP relies on), so the
+exchange is a few large RCCL all-reduces over that arena (`allreduce_grads`): ring collectives over xGMI are per-link
+bound, and 128 MiB messages run at the link rate without per-bucket bookkeeping or unused-parameter detection.
+Unused heads have all-zero slots on every rank, and stay "inactive" for AdamW exactly like `grad is None` in the
+reference.  `wrap_ddp` remains for models whose gradients all flow through autograd (the CPU oracle in the gloo
+test, fp32 mode).  The reference also broadcasts the sampled task id every step (data/loader.py:56-59); here every
+rank derives it from a shared-seed host RNG instead, so no collective is needed for it.
 """
 from __future__ import annotations
 
@@ -25,7 +30,8 @@ def dist_env():
 def init_distributed(backend: str | None = None):
     """Initialise the default process group from torchrun's env (MASTER_ADDR defaults to 127.0.0.1)."""
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("HAMT_FORCE_DIST") is not None     # exercise the multi-rank code path with one rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -73,6 +79,38 @@ def wrap_ddp(model, local_rank: int):
     if next(model.parameters()).is_cuda:
         return DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
     return DDP(model, find_unused_parameters=True)
+
+
+def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20) -> torch.Tensor:
+    """In-place average of a flat tensor over all ranks, in `chunk_elems`-element (128 MiB fp32) all-reduces."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    world = dist.get_world_size()
+    avg = dist.get_backend() == "nccl"          # RCCL reduces with the 1/world scale fused; gloo has no AVG
+    for o in range(0, flat.numel(), chunk_elems):
+        c = flat[o:o + chunk_elems]
+        if avg:
+            dist.all_reduce(c, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            c.mul_(1.0 / world)
+    return flat
+
+
+def allreduce_grads(optimizer) -> None:
+    """Average this step's gradients over the ranks: pack what autograd produced into the optimizer's flat arena
+    (the grouped weight gradients are already there) and all-reduce the arena.  Call between backward and clip/step."""
+    if not optimizer._packed:
+        optimizer._pack_grads()
+    allreduce_mean_(optimizer._flat_g)
+
+
+def broadcast_params(optimizer, src: int = 0) -> None:
+    """Every rank starts from rank `src`'s parameters (what DDP does at construction)."""
+    optimizer.materialize()
+    if dist.is_available() and dist.is_initialized():
+        dist.broadcast(optimizer._flat_p, src)
+        optimizer.refresh_shadow()
 
 
 def max_over_ranks(value: float, device) -> float:
