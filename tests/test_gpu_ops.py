@@ -273,7 +273,8 @@ def _attn_ref(q, k, v, mask, heads):
 
 @pytest.mark.parametrize("B,heads,Sq,Sk,packed,use_mask", [
     (2, 2, 80, 80, True, True), (3, 2, 36, 36, True, False), (2, 3, 43, 80, False, True),
-    (2, 2, 80, 43, False, True), (1, 2, 130, 150, False, True), (2, 1, 6, 20, False, True), (2, 2, 250, 250, True, True)])
+    (2, 2, 80, 43, False, True), (1, 2, 130, 150, False, True), (2, 1, 6, 20, False, True), (2, 2, 250, 250, True, True),
+    (2, 2, 128, 128, True, True), (2, 2, 80, 6, False, True), (3, 1, 1, 37, False, False), (2, 2, 100, 17, False, True), (2, 1, 128, 130, False, True)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_attention_fwd_bwd(B, heads, Sq, Sk, packed, use_mask, prec):
     """fp32: exact-MFMA kernels (attn.hip) <= 5e-5; bf16: bf16-MFMA kernels (attn16.hip), operands and P rounded to bf16

@@ -30,6 +30,10 @@ def bench(layout, M, N, K, epi="bias", cdt="f32", iters=30):
         kw.update(epilogue=L.EPI_MUL_DGELU, aux=torch.randn(M, N, device=dev))
     elif epi == "dgelu16":
         kw.update(epilogue=L.EPI_MUL_DGELU, aux=torch.randn(M, N, device=dev).to(torch.bfloat16))
+    elif epi == "gelugrad":
+        kw.update(bias=torch.randn(N, device=dev), epilogue=L.EPI_GELU_GRAD, aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+    elif epi == "mulaux":
+        kw.update(epilogue=L.EPI_MUL_AUX, aux=torch.randn(M, N, device=dev).to(torch.bfloat16))
     elif epi == "acc":
         kw.update(epilogue=L.EPI_ACCUM)
         out.zero_()

@@ -346,6 +346,295 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(Attn16Args a) {
   }
 }
 
+// =================================================================================================
+// Short-sequence kernels (Sq, Sk <= 128: every attention of HAMT -- 80 instruction tokens, <= 37 views, a handful of
+// history steps).  One workgroup per (batch, head) with one wave per 16 query rows (and, in the backward, per 16 key
+// rows): K/V (and Q/dO) are staged ONCE, the softmax is a single pass over all keys held in registers, and work is
+// counted in 16-row blocks instead of 64-row tiles -- for 80 tokens 5x5 blocks instead of the 8x8 the tiled kernels
+// above touch, and no second staging of K/V for the 16-row remainder tile.  Same products, same lane ownership, same
+// dropout indexing as the tiled kernels (they remain the path for longer sequences).
+__device__ __forceinline__ bf16x8 zero_frag() { union { uint4 u; bf16x8 v; } f; f.u = make_uint4(0, 0, 0, 0); return f.v; }
+// transposed fragment with a row limit: a 4-row group (ra.., rb..) outside [0, rlim) reads as zeros.  Every lane issues
+// the transpose read (it is a cross-lane operation: the address is clamped instead of branching around it) and the
+// out-of-range groups are zeroed afterwards.
+__device__ __forceinline__ bf16x8 tfrag_lim(const bf16_t* lds, int stride, int ra, int rb, int rlim, int c16, int lane) {
+  union { bf16x8 v; s16x4 h[2]; } f;
+  const int i = lane & 15, col = c16 + (i & 3) * 4, dr = i >> 2;
+  const bool oka = ra < rlim, okb = rb < rlim;
+  f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + ((oka ? ra : 0) + dr) * stride + col));
+  f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + ((okb ? rb : 0) + dr) * stride + col));
+  const s16x4 z = {0, 0, 0, 0};
+  if (!oka) f.h[0] = z;
+  if (!okb) f.h[1] = z;
+  return f.v;
+}
+__device__ __forceinline__ bf16x8 rfrag_lim(const bf16_t* lds, int stride, int r, int k8, int klim) {
+  union { uint4 u; bf16x8 v; } f;
+  f.u = make_uint4(0, 0, 0, 0);
+  if (k8 < klim) f.u = *(const uint4*)(lds + r * stride + k8);
+  return f.v;
+}
+// rows [0, rows16) of one head -> lds[rows16][AST] (bf16), rows >= rlim zero; 8 threads per row
+template <typename T>
+__device__ __forceinline__ void stage_rows(const T* base, int ld, int rlim, int rows16, bf16_t* lds, int t, int nt) {
+  const int c = (t & 7) * 8;
+  for (int r = t >> 3; r < rows16; r += nt >> 3) {
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (r < rlim) { float f[8]; ld8<T>(base + (size_t)r * ld + c, f); u = pack8(f); }
+    *(uint4*)(lds + r * AST + c) = u;
+  }
+}
+
+template <typename TI, typename TO, int KB>   // KB: compile-time bound on the number of 16-key blocks (2, 4, 8)
+__global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  const hamt_attn_desc& d = a.d;
+  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int nkb = (d.Sk + 15) >> 4, sk16 = nkb * 16;
+  bf16_t* Ks = sm;
+  bf16_t* Vs = sm + sk16 * AST;
+  const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
+  stage_rows<TI>(K, d.ldk, d.Sk, sk16, Ks, t, nt);
+  stage_rows<TI>(V, d.ldv, d.Sk, sk16, Vs, t, nt);
+  const int qrow = 16 * w + l15;                       // the ONE query row this lane owns
+  const bool qok = qrow < d.Sq;
+  bf16x8 qf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float f[8];
+    if (qok) ld8<TI>(Q + (size_t)qrow * d.ldq + 32 * s + 8 * g, f);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = 0.f;
+    }
+    union { uint4 u; bf16x8 v; } c;
+    c.u = pack8(f);
+    qf[s] = c.v;
+  }
+  __syncthreads();
+  f32x4 sf[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    sf[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kb < nkb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) sf[kb] = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf[kb]);
+    }
+  }
+  // sf[kb][r] = S[q = qrow][key = 16kb + 4g + r]
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = 16 * kb + 4 * g + r;
+      const bool kval = kk < d.Sk;
+      const float mk = (kval && a.mask) ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
+      sf[kb][r] = kval ? sf[kb][r] * d.scale + mk : -INFINITY;
+      mx = fmaxf(mx, sf[kb][r]);
+    }
+  const float mn = xg_max(mx);
+  const RngKey key = rng_key(a.rng, d.call_id);
+  const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  float rs = 0.f;
+  float p[KB][4];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float e = expf(sf[kb][r] - mn);                  // exp(-inf) = 0 for the padding keys
+      rs += e;
+      if (d.p_drop > 0.f && kb < nkb)
+        e *= drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + qrow) * d.Sk + (16 * kb + 4 * g + r), d.p_drop, inv_keep);
+      p[kb][r] = e;
+    }
+  const float l_run = xg_sum(rs);
+  f32x4 of[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) of[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // O^T = V^T P^T : k-step s covers key blocks 2s, 2s+1; this lane group's k = keys 4g..4g+3 of each block
+#pragma unroll
+  for (int s = 0; s < KB / 2; ++s) {
+    if (2 * s < nkb) {
+      const bf16x8 pf = pack_frag(p[2 * s], p[2 * s + 1]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+        of[db] = MFMA16(tfrag_lim(Vs, AST, 32 * s + 4 * g, 32 * s + 16 + 4 * g, sk16, 16 * db, lane), pf, of[db]);
+    }
+  }
+  if (qok) {
+    TO* O = (TO*)a.out + (size_t)b * d.Sq * d.ldo + h * 64 + (size_t)qrow * d.ldo;
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) st4<TO>(O + 16 * db + 4 * g, of[db][0] * inv, of[db][1] * inv, of[db][2] * inv, of[db][3] * inv);
+    if (g == 0) a.lse[((size_t)b * d.heads + h) * d.Sq + qrow] = mn + logf(l_run);
+  }
+}
+
+template <typename TI, typename TO, int NB>   // NB: compile-time bound on the 16-row blocks of queries and of keys
+__global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  const hamt_attn_desc& d = a.d;
+  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int nqb = (d.Sq + 15) >> 4, nkb = (d.Sk + 15) >> 4, sq16 = nqb * 16, sk16 = nkb * 16, PST = sq16 + 8;
+  bf16_t* Qs = sm;
+  bf16_t* dOs = Qs + sq16 * AST;
+  bf16_t* Ks = dOs + sq16 * AST;
+  bf16_t* Vs = Ks + sk16 * AST;
+  bf16_t* Pt = Vs + sk16 * AST;                        // [key][q] (row stride PST): P~ and dS of the whole head
+  bf16_t* dSt = Pt + sk16 * PST;
+  float* lse_s = (float*)(dSt + sk16 * PST);
+  float* delta_s = lse_s + sq16;
+  const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
+  const TO* O = (const TO*)a.o + (size_t)b * d.Sq * d.ldo + h * 64;
+  const TO* dO = (const TO*)a.d_o + (size_t)b * d.Sq * d.ldo + h * 64;
+  stage_rows<TI>(Q, d.ldq, d.Sq, sq16, Qs, t, nt);
+  stage_rows<TI>(K, d.ldk, d.Sk, sk16, Ks, t, nt);
+  stage_rows<TI>(V, d.ldv, d.Sk, sk16, Vs, t, nt);
+  {  // dO, with delta = rowsum(dO * O) in fp32 from the un-rounded values (8 threads per row) and the saved lse
+    const int c = (t & 7) * 8;
+    for (int r = t >> 3; r < sq16; r += nt >> 3) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      float acc = 0.f;
+      if (r < d.Sq) {
+        float f[8], o8[8];
+        ld8<TO>(dO + (size_t)r * d.ldo + c, f);
+        ld8<TO>(O + (size_t)r * d.ldo + c, o8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += f[i] * o8[i];
+        u = pack8(f);
+      }
+      *(uint4*)(dOs + r * AST + c) = u;
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+      if ((t & 7) == 0) { delta_s[r] = acc; lse_s[r] = r < d.Sq ? a.lse[((size_t)b * d.heads + h) * d.Sq + r] : 0.f; }
+    }
+  }
+  for (int i = t; i < sk16 * PST / 8; i += nt) { ((uint4*)Pt)[i] = make_uint4(0, 0, 0, 0); ((uint4*)dSt)[i] = make_uint4(0, 0, 0, 0); }
+  __syncthreads();
+  const RngKey key = rng_key(a.rng, d.call_id);
+  const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  if (w < nqb) {   // phase A: this wave's 16 queries x all keys; lane owns query ql = 16w + l15
+    const int ql = 16 * w + l15;
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { qf[s] = rfrag(Qs, ql, 32 * s + 8 * g); df[s] = rfrag(dOs, ql, 32 * s + 8 * g); }
+    const float lse_q = lse_s[ql], delta_q = delta_s[ql];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      if (kb < nkb) {
+        f32x4 sf = (f32x4){0.f, 0.f, 0.f, 0.f}, dpf = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          sf = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf);      // S^T[key][q]
+          dpf = MFMA16(rfrag(Vs, 16 * kb + l15, 32 * s + 8 * g), df[s], dpf);    // dP^T[key][q] = V dO^T
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = 16 * kb + 4 * g + r;
+          if (kk < d.Sk && ql < d.Sq) {                // everything else stays zero
+            const float mk = a.mask ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
+            const float pr = expf(sf[r] * d.scale + mk - lse_q);
+            float dsc = 1.0f;
+            if (d.p_drop > 0.f) dsc = drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + ql) * d.Sk + kk, d.p_drop, inv_keep);
+            Pt[kk * PST + ql] = f2bf(pr * dsc);
+            dSt[kk * PST + ql] = f2bf(pr * (dpf[r] * dsc - delta_q) * d.scale);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (w < nkb) {   // dV^T[d][key] = dO^T P~ ; dK^T[d][key] = Q^T dS   (reduction over the queries), key = 16w + l15
+    f32x4 dkf[4], dvf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dkf[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvf[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < NB / 2; ++s) {
+      if (2 * s < nqb) {
+        const bf16x8 pb = rfrag_lim(Pt, PST, 16 * w + l15, 32 * s + 8 * g, sq16), sb = rfrag_lim(dSt, PST, 16 * w + l15, 32 * s + 8 * g, sq16);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dvf[db] = MFMA16(tfrag_lim(dOs, AST, 32 * s + 8 * g, 32 * s + 8 * g + 4, sq16, 16 * db, lane), pb, dvf[db]);
+          dkf[db] = MFMA16(tfrag_lim(Qs, AST, 32 * s + 8 * g, 32 * s + 8 * g + 4, sq16, 16 * db, lane), sb, dkf[db]);
+        }
+      }
+    }
+    const int kk = 16 * w + l15;
+    if (kk < d.Sk) {
+      TI* dK = (TI*)a.dk + (size_t)b * d.Sk * d.ldk + h * 64 + (size_t)kk * d.ldk;
+      TI* dV = (TI*)a.dv + (size_t)b * d.Sk * d.ldv + h * 64 + (size_t)kk * d.ldv;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        st4<TI>(dK + 16 * db + 4 * g, dkf[db][0], dkf[db][1], dkf[db][2], dkf[db][3]);
+        st4<TI>(dV + 16 * db + 4 * g, dvf[db][0], dvf[db][1], dvf[db][2], dvf[db][3]);
+      }
+    }
+  }
+  if (w < nqb) {   // dQ^T[d][q] = K^T dS^T  (reduction over the keys), q = 16w + l15
+    f32x4 dqf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqf[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NB / 2; ++s) {
+      if (2 * s < nkb) {
+        const bf16x8 sb = tfrag_lim(dSt, PST, 32 * s + 8 * g, 32 * s + 8 * g + 4, sk16, 16 * w, lane);   // B[k = key][j = q]
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dqf[db] = MFMA16(tfrag_lim(Ks, AST, 32 * s + 8 * g, 32 * s + 8 * g + 4, sk16, 16 * db, lane), sb, dqf[db]);
+      }
+    }
+    const int qq = 16 * w + l15;
+    if (qq < d.Sq) {
+      TI* dQ = (TI*)a.dq + (size_t)b * d.Sq * d.ldq + h * 64 + (size_t)qq * d.ldq;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) st4<TI>(dQ + 16 * db + 4 * g, dqf[db][0], dqf[db][1], dqf[db][2], dqf[db][3]);
+    }
+  }
+}
+
+template <typename TI, typename TO>
+void launch_s128_fwd(const Attn16Args& a, hipStream_t s) {
+  const hamt_attn_desc& d = a.d;
+  const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16;
+  const dim3 grid(d.heads, d.B), block(64 * nqb);
+  const size_t lds = (size_t)2 * nkb * 16 * AST * sizeof(bf16_t);
+  if (nkb <= 2) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 2>), grid, block, lds, s, a);
+  else if (nkb <= 4) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 4>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 8>), grid, block, lds, s, a);
+}
+
+template <typename TI, typename TO, int NB>
+void launch_s128_bwd_nb(const Attn16Args& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  static bool raised = false;                      // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!raised) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_s128_bwd_kernel<TI, TO, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL((attn_s128_bwd_kernel<TI, TO, NB>), grid, block, lds, s, a);
+}
+
+template <typename TI, typename TO>
+void launch_s128_bwd(const Attn16Args& a, hipStream_t s) {
+  const hamt_attn_desc& d = a.d;
+  const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16, nb = nqb > nkb ? nqb : nkb;
+  const int sq16 = nqb * 16, sk16 = nkb * 16;
+  const dim3 grid(d.heads, d.B), block(64 * nb);
+  const size_t lds = ((size_t)2 * (sq16 + sk16) * AST + (size_t)2 * sk16 * (sq16 + 8)) * sizeof(bf16_t) + (size_t)2 * sq16 * sizeof(float);
+  if (nb <= 2) launch_s128_bwd_nb<TI, TO, 2>(a, grid, block, lds, s);
+  else if (nb <= 4) launch_s128_bwd_nb<TI, TO, 4>(a, grid, block, lds, s);
+  else launch_s128_bwd_nb<TI, TO, 8>(a, grid, block, lds, s);
+}
+
+bool use_s128(const hamt_attn_desc* d) {
+  static const bool off = getenv("HAMT_NO_ATTN_S128") != nullptr;
+  return !off && d->Sq <= 128 && d->Sk <= 128;
+}
+
 }  // namespace
 
 void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
@@ -353,6 +642,13 @@ void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* 
   Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng};
   dim3 grid((d->Sq + T64 - 1) / T64, d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
+  if (use_s128(d)) {
+    if (!ib && !ob) launch_s128_fwd<float, float>(a, s);
+    else if (ib && ob) launch_s128_fwd<bf16_t, bf16_t>(a, s);
+    else if (ib) launch_s128_fwd<bf16_t, float>(a, s);
+    else launch_s128_fwd<float, bf16_t>(a, s);
+    return;
+  }
   if (!ib && !ob) hipLaunchKernelGGL((attn16_fwd_kernel<float, float>), grid, block, 0, s, a);
   else if (ib && ob) hipLaunchKernelGGL((attn16_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
   else if (ib) hipLaunchKernelGGL((attn16_fwd_kernel<bf16_t, float>), grid, block, 0, s, a);
@@ -364,6 +660,13 @@ void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* 
   Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng};
   dim3 grid(d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
+  if (use_s128(d)) {
+    if (!ib && !ob) launch_s128_bwd<float, float>(a, s);
+    else if (ib && ob) launch_s128_bwd<bf16_t, bf16_t>(a, s);
+    else if (ib) launch_s128_bwd<bf16_t, float>(a, s);
+    else launch_s128_bwd<float, bf16_t>(a, s);
+    return;
+  }
   if (!ib && !ob) hipLaunchKernelGGL((attn16_bwd_kernel<float, float>), grid, block, 0, s, a);
   else if (ib && ob) hipLaunchKernelGGL((attn16_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
   else if (ib) hipLaunchKernelGGL((attn16_bwd_kernel<bf16_t, float>), grid, block, 0, s, a);

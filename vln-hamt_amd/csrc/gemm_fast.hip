@@ -124,66 +124,81 @@ template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_wa
 template <> __device__ __forceinline__ void wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
 
-// one row segment of 4 consecutive columns
-template <int EPI>
-__device__ __forceinline__ void epi_store4(const GemmArgsF& g, int row, int col, f32x4 acc) {
+// One row segment of W (4 or 8) consecutive columns: v = alpha * acc, then the epilogue flags, then the store.
+// Vector paths need the segment inside the row (full) and W-element alignment of the row stride and base.
+template <int W> __device__ __forceinline__ void ld_bf(const bf16_t* p, float* o) {   // W bf16 -> fp32
+  if constexpr (W == 8) {
+    const uint4 u = *(const uint4*)p;
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o[2 * q] = __uint_as_float(w[q] << 16); o[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+  } else {
+    const uint2 u = *(const uint2*)p;
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+  }
+}
+template <int W> __device__ __forceinline__ void st_bf(bf16_t* p, const float* v) {   // W fp32 -> bf16, one store
+  if constexpr (W == 8) *(uint4*)p = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  else *(uint2*)p = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+template <int W> __device__ __forceinline__ void ld_f(const float* p, float* o) {
+#pragma unroll
+  for (int q = 0; q < W / 4; ++q) { const float4 f = *(const float4*)(p + 4 * q); o[4 * q] = f.x; o[4 * q + 1] = f.y; o[4 * q + 2] = f.z; o[4 * q + 3] = f.w; }
+}
+template <int W> __device__ __forceinline__ void st_f(float* p, const float* v) {
+#pragma unroll
+  for (int q = 0; q < W / 4; ++q) *(float4*)(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int EPI, int W>
+__device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, const float* acc) {
   if (row >= g.M || col >= g.N) return;
-  if (g.alpha == -12345.f && acc[0] != 123.456f) return;   // measurement aid: alpha = -12345 disables the stores
   const int epi = EPI >= 0 ? EPI : (EPI == -2 ? (g.epi & HAMT_EPI_ACCUM) : g.epi);   // -2: plain store or C += only
-  float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
-  const bool full = col + 4 <= g.N;
-  if (epi & HAMT_EPI_BIAS) {
-    if (full) { const float4 b = *(const float4*)(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-    else for (int j = 0; j < 4; ++j) if (col + j < g.N) v[j] += g.bias[col + j];
-  }
+  float v[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) v[j] = acc[j] * g.alpha;
+  const bool full = col + W <= g.N;
   const size_t ia = (size_t)row * g.ldaux + col, ic = (size_t)row * g.ldc + col;
+  const bool aux16 = g.dtype_aux == HAMT_BF16;
+  // vector access to aux / C: whole segment in range, row stride and base aligned to the vector
+  const bool vaux = full && g.aux && (g.ldaux % W) == 0 && ((uintptr_t)g.aux % 16) == 0;
+  const bool vc = full && (g.ldc % W) == 0 && ((uintptr_t)g.C % 16) == 0;
+  if (epi & HAMT_EPI_BIAS) {
+    if (full && ((uintptr_t)g.bias % 16) == 0) { float b[W]; ld_f<W>(g.bias + col, b); for (int j = 0; j < W; ++j) v[j] += b[j]; }
+    else for (int j = 0; j < W; ++j) if (col + j < g.N) v[j] += g.bias[col + j];
+  }
   if (epi & HAMT_EPI_SAVE_PRE) {
-    if (g.dtype_aux == HAMT_BF16) { for (int j = 0; j < 4; ++j) if (col + j < g.N) ((bf16_t*)g.aux)[ia + j] = f2bf(v[j]); }
-    else if (full && (g.ldaux & 3) == 0) *(float4*)((float*)g.aux + ia) = make_float4(v[0], v[1], v[2], v[3]);
-    else for (int j = 0; j < 4; ++j) if (col + j < g.N) ((float*)g.aux)[ia + j] = v[j];
+    if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, v); else st_f<W>((float*)g.aux + ia, v); }
+    else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(v[j]); else ((float*)g.aux)[ia + j] = v[j]; }
   }
-  if (epi & HAMT_EPI_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]); }
+  if (epi & HAMT_EPI_GELU) { for (int j = 0; j < W; ++j) v[j] = gelu_erf(v[j]); }
   if (epi & HAMT_EPI_GELU_GRAD) {
-    float dg[4];
-    for (int j = 0; j < 4; ++j) gelu_and_grad(v[j], v[j], dg[j]);
-    if (g.dtype_aux == HAMT_BF16) {
-      if (full && (g.ldaux & 3) == 0) *(uint2*)((bf16_t*)g.aux + ia) = make_uint2(pack_bf2(dg[0], dg[1]), pack_bf2(dg[2], dg[3]));
-      else for (int j = 0; j < 4; ++j) if (col + j < g.N) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]);
-    } else {
-      for (int j = 0; j < 4; ++j) if (col + j < g.N) ((float*)g.aux)[ia + j] = dg[j];
-    }
+    float dg[W];
+    for (int j = 0; j < W; ++j) gelu_and_grad(v[j], v[j], dg[j]);
+    if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, dg); else st_f<W>((float*)g.aux + ia, dg); }
+    else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]); else ((float*)g.aux)[ia + j] = dg[j]; }
   }
-  if (epi & HAMT_EPI_MUL_AUX) {
-    if (g.dtype_aux == HAMT_BF16 && full && (g.ldaux & 3) == 0) {
-      const uint2 a2 = *(const uint2*)((const bf16_t*)g.aux + ia);
-      v[0] *= __uint_as_float(a2.x << 16); v[1] *= __uint_as_float(a2.x & 0xffff0000u);
-      v[2] *= __uint_as_float(a2.y << 16); v[3] *= __uint_as_float(a2.y & 0xffff0000u);
-    } else {
-      for (int j = 0; j < 4; ++j) if (col + j < g.N)
-        v[j] *= (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j];
-    }
+  if (epi & (HAMT_EPI_MUL_AUX | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
+    float h[W];
+    if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
+    else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
+    for (int j = 0; j < W; ++j)
+      v[j] *= (epi & HAMT_EPI_MUL_AUX) ? h[j] : ((epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h[j]) : (h[j] > 0.0f ? 1.0f : 0.0f));
   }
-  if (epi & HAMT_EPI_RELU) { for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f); }
-  if (epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
-    for (int j = 0; j < 4; ++j) if (col + j < g.N) {
-      const float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j];
-      v[j] *= (epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h) : (h > 0.0f ? 1.0f : 0.0f);
-    }
-  }
+  if (epi & HAMT_EPI_RELU) { for (int j = 0; j < W; ++j) v[j] = fmaxf(v[j], 0.0f); }
   if (g.dtype_c == HAMT_BF16) {
     bf16_t* c = (bf16_t*)g.C + ic;
-    if (epi & HAMT_EPI_ACCUM) { for (int j = 0; j < 4; ++j) if (col + j < g.N) v[j] += bf2f(c[j]); }
-    if (full && (g.ldc & 3) == 0) *(uint2*)c = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-    else for (int j = 0; j < 4; ++j) if (col + j < g.N) c[j] = f2bf(v[j]);
+    if (vc) {
+      if (epi & HAMT_EPI_ACCUM) { float p[W]; ld_bf<W>(c, p); for (int j = 0; j < W; ++j) v[j] += p[j]; }
+      st_bf<W>(c, v);
+    } else for (int j = 0; j < W; ++j) if (col + j < g.N) c[j] = f2bf((epi & HAMT_EPI_ACCUM) ? v[j] + bf2f(c[j]) : v[j]);
   } else {
     float* c = (float*)g.C + ic;
-    if (full && (g.ldc & 3) == 0) {
-      float4 o = make_float4(v[0], v[1], v[2], v[3]);
-      if (epi & HAMT_EPI_ACCUM) { const float4 p = *(const float4*)c; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-      *(float4*)c = o;
-    } else {
-      for (int j = 0; j < 4; ++j) if (col + j < g.N) c[j] = (epi & HAMT_EPI_ACCUM) ? c[j] + v[j] : v[j];
-    }
+    if (vc) {
+      if (epi & HAMT_EPI_ACCUM) { float p[W]; ld_f<W>(c, p); for (int j = 0; j < W; ++j) v[j] += p[j]; }
+      st_f<W>(c, v);
+    } else for (int j = 0; j < W; ++j) if (col + j < g.N) c[j] = (epi & HAMT_EPI_ACCUM) ? c[j] + v[j] : v[j];
   }
 }
 
@@ -266,21 +281,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       }
     }
   }
-  // Epilogue through LDS: the MFMA layout gives a lane 4 columns of 16 different rows, i.e. 32-64 byte row pieces per
-  // store instruction, which the write path handles at well under half of HBM rate (measured: 20 us of a 60 us
-  // 5120x3072x768 GEMM).  Re-tiling the fp32 accumulators through LDS lets every wave write two full 128-column rows
-  // (512 B fp32 / 256 B bf16, whole cache lines) per instruction, and makes the aux / accumulate reads coalesced too.
-  constexpr int LDW = BN + 4;                    // +4 floats: the 16 rows of a b128 write land in 16 distinct bank groups
-  if constexpr (BM * LDW * 4 > NSTAGE * STAGE * 2) {   // C tile does not fit in the operand ring: store from the MFMA layout
+  // Epilogue through LDS.  A wave's store instructions are issue-bound (~70 cycles each whatever their width, see
+  // MI355X_MICROARCH.md "store tail"), and the MFMA layout gives a lane only 4 consecutive columns (8 bytes of a bf16
+  // row).  Re-tiling the fp32 accumulators through LDS gives every lane 8 consecutive columns -- one 16-byte store per
+  // bf16 output, two per fp32 output, 4 rows x 256-512 contiguous bytes per wave instruction -- and makes the aux /
+  // accumulate reads coalesced as well.  The C tile is [BM][128] fp32 with the float4 slot index XOR-ed with (row & 7):
+  // conflict-free for the 8-row groups of the b128 writes and for the row-contiguous reads, and exactly the size of
+  // the 2-deep operand ring for BM = 128 (64 KiB).
+  static_assert(BM * BN * 4 <= NSTAGE * STAGE * 2 || NSTAGE < 2, "C tile must fit in the operand ring");
+  if constexpr (BM * BN * 4 > NSTAGE * STAGE * 2) {   // (ring depth 1 only) store from the MFMA layout
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = m0 + wm * (BM / 2) + i * 16 + (lane & 15), col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         if (g.ksplit > 1) {
           float* P = g.part + (size_t)slice * g.M * g.N;
-          if (row < g.M) for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = acc[i][j][e];
-        } else epi_store4<EPI>(g, row, col, acc[i][j]);
+          if (row < g.M) for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = a4[e];
+        } else epi_store<EPI, 4>(g, row, col, a4);
       }
     return;
   }
@@ -289,27 +308,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *(f32x4*)(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDW + wn * 64 + j * 16 + (lane >> 4) * 4) = acc[i][j];
-  __syncthreads();
-  const int col = n0 + (t & 31) * 4;
-  if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
-    float* P = g.part + (size_t)slice * g.M * g.N;
-#pragma unroll
-    for (int p = 0; p < BM / 8; ++p) {
-      const int rl = p * 8 + (t >> 5), row = m0 + rl;
-      const f32x4 v = *(const f32x4*)(ct + rl * LDW + (t & 31) * 4);
-      if (row < g.M) {
-        if (col + 4 <= g.N && (g.N & 3) == 0) *(float4*)(P + (size_t)row * g.N + col) = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v[e];
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int rl = wm * (BM / 2) + i * 16 + (lane & 15), c4 = wn * 16 + j * 4 + (lane >> 4);
+      *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[i][j];
     }
-    return;
-  }
+  __syncthreads();
+  const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + 16 p
 #pragma unroll
-  for (int p = 0; p < BM / 8; ++p) {
-    const int rl = p * 8 + (t >> 5);
-    epi_store4<EPI>(g, m0 + rl, col, *(const f32x4*)(ct + rl * LDW + (t & 31) * 4));
+  for (int p = 0; p < BM / 16; ++p) {
+    const int rl = p * 16 + (t >> 4), row = m0 + rl;
+    const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
+    const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+    const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
+      float* P = g.part + (size_t)slice * g.M * g.N;
+      if (row < g.M) {
+        if (col + 8 <= g.N && (g.N & 3) == 0) st_f<8>(P + (size_t)row * g.N + col, v8);
+        else for (int e = 0; e < 8; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v8[e];
+      }
+    } else epi_store<EPI, 8>(g, row, col, v8);
   }
 }
 
