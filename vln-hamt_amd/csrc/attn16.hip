@@ -374,18 +374,66 @@ __device__ __forceinline__ bf16x8 rfrag_lim(const bf16_t* lds, int stride, int r
   if (k8 < klim) f.u = *(const uint4*)(lds + r * stride + k8);
   return f.v;
 }
-// rows [0, rows16) of one head -> lds[rows16][AST] (bf16), rows >= rlim zero; 8 threads per row
-template <typename T>
-__device__ __forceinline__ void stage_rows(const T* base, int ld, int rlim, int rows16, bf16_t* lds, int t, int nt) {
-  const int c = (t & 7) * 8;
-  for (int r = t >> 3; r < rows16; r += nt >> 3) {
-    uint4 u = make_uint4(0, 0, 0, 0);
-    if (r < rlim) { float f[8]; ld8<T>(base + (size_t)r * ld + c, f); u = pack8(f); }
-    *(uint4*)(lds + r * AST + c) = u;
+// Staging in two phases so that every global load of a matrix (or of several matrices) is in flight before the first
+// LDS store waits for one: raw 8-element pieces first (8 threads per row, IT pieces per thread), conversion + store after.
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { uint4 u; };
+template <> struct Raw8<float> { float4 a, b; };
+__device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.u = *(const uint4*)p; }
+__device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) { r.a = ((const float4*)p)[0]; r.b = ((const float4*)p)[1]; }
+__device__ __forceinline__ void raw_zero(Raw8<bf16_t>& r) { r.u = make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ void raw_zero(Raw8<float>& r) { r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; }
+__device__ __forceinline__ uint4 raw_bf16(const Raw8<bf16_t>& r) { return r.u; }
+__device__ __forceinline__ uint4 raw_bf16(const Raw8<float>& r) {
+  return make_uint4(pack_bf2(r.a.x, r.a.y), pack_bf2(r.a.z, r.a.w), pack_bf2(r.b.x, r.b.y), pack_bf2(r.b.z, r.b.w));
+}
+__device__ __forceinline__ void raw_f32(const Raw8<bf16_t>& r, float (&f)[8]) {
+  const uint32_t u[4] = {r.u.x, r.u.y, r.u.z, r.u.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(u[j] << 16); f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ void raw_f32(const Raw8<float>& r, float (&f)[8]) {
+  f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w;
+}
+// rows [0, rows16) of one head: piece i of thread t is row (t >> 3) + i * (nt >> 3), columns (t & 7) * 8 .. +7
+template <typename T, int IT>
+__device__ __forceinline__ void rows_load(const T* base, int ld, int rlim, int t, int nt, Raw8<T> (&raw)[IT]) {
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int r = (t >> 3) + i * (nt >> 3);
+    // unconditional load from a clamped row, zeroed afterwards: a branch around the load would make hipcc wait for each
+    // piece separately (cdna_hip_programming.md, "register or load" trap) instead of keeping all of them in flight
+    raw_load(base + (size_t)(r < rlim ? r : rlim - 1) * ld + (t & 7) * 8, raw[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int r = (t >> 3) + i * (nt >> 3);
+    if (r >= rlim) raw_zero(raw[i]);
+  }
+}
+template <typename T, int IT>
+__device__ __forceinline__ void rows_store(const Raw8<T> (&raw)[IT], int rows16, bf16_t* lds, int t, int nt) {
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int r = (t >> 3) + i * (nt >> 3);
+    if (r < rows16) *(uint4*)(lds + r * AST + (t & 7) * 8) = raw_bf16(raw[i]);
   }
 }
 
-template <typename TI, typename TO, int KB>   // KB: compile-time bound on the number of 16-key blocks (2, 4, 8)
+// bf16 MFMA fragment of 8 consecutive head-dim elements of one global row (Q): no conversion for bf16 sources
+template <typename T> __device__ __forceinline__ bf16x8 gfrag(const T* p) {
+  union { uint4 u; bf16x8 v; } c;
+  if constexpr (sizeof(T) == 2) c.u = *(const uint4*)p;
+  else { float f[8]; ld8<T>(p, f); c.u = pack8(f); }
+  return c.v;
+}
+// additive key mask of one (batch) row into LDS: mask value for keys < Sk (0 without a mask), -inf for the padding keys,
+// so that the score update is ONE fma per element and padding keys get probability exactly 0
+__device__ __forceinline__ void stage_mask(const float* mask, int b, int Sk, int sk16, float* mk_s, int t, int nt) {
+  for (int i = t; i < sk16; i += nt) mk_s[i] = i < Sk ? (mask ? mask[(size_t)b * Sk + i] : 0.f) : -INFINITY;
+}
+
+template <typename TI, typename TO, int KB>   // KB: compile-time bound on the number of 16-key blocks (2, 4, 6, 8)
 __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   const hamt_attn_desc& d = a.d;
@@ -394,27 +442,24 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   const int nkb = (d.Sk + 15) >> 4, sk16 = nkb * 16;
   bf16_t* Ks = sm;
   bf16_t* Vs = sm + sk16 * AST;
+  float* mk_s = (float*)(Vs + sk16 * AST);
   const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
   const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
   const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
-  stage_rows<TI>(K, d.ldk, d.Sk, sk16, Ks, t, nt);
-  stage_rows<TI>(V, d.ldv, d.Sk, sk16, Vs, t, nt);
+  Raw8<TI> rk[4], rv[4];                               // the launcher guarantees 8 * sk16 <= 4 * nt
+  rows_load<TI, 4>(K, d.ldk, d.Sk, t, nt, rk);
+  rows_load<TI, 4>(V, d.ldv, d.Sk, t, nt, rv);
   const int qrow = 16 * w + l15;                       // the ONE query row this lane owns
   const bool qok = qrow < d.Sq;
   bf16x8 qf[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    float f[8];
-    if (qok) ld8<TI>(Q + (size_t)qrow * d.ldq + 32 * s + 8 * g, f);
-    else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] = 0.f;
-    }
-    union { uint4 u; bf16x8 v; } c;
-    c.u = pack8(f);
-    qf[s] = c.v;
-  }
+  for (int s = 0; s < 2; ++s)   // clamped, not branched (rows >= Sq are never stored)
+    qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : d.Sq - 1) * d.ldq + 32 * s + 8 * g);
+  stage_mask(a.mask, b, d.Sk, sk16, mk_s, t, nt);
+  rows_store<TI, 4>(rk, sk16, Ks, t, nt);
+  rows_store<TI, 4>(rv, sk16, Vs, t, nt);
   __syncthreads();
+  if (16 * w >= d.Sq) return;                          // waves that only helped staging (no barrier below)
   f32x4 sf[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
@@ -427,30 +472,36 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   // sf[kb][r] = S[q = qrow][key = 16kb + 4g + r]
   float mx = -INFINITY;
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int kk = 16 * kb + 4 * g + r;
-      const bool kval = kk < d.Sk;
-      const float mk = (kval && a.mask) ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
-      sf[kb][r] = kval ? sf[kb][r] * d.scale + mk : -INFINITY;
-      mx = fmaxf(mx, sf[kb][r]);
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb < nkb) {
+      const float4 mk = *(const float4*)(mk_s + 16 * kb + 4 * g);
+      sf[kb][0] = fmaf(sf[kb][0], d.scale, mk.x); sf[kb][1] = fmaf(sf[kb][1], d.scale, mk.y);
+      sf[kb][2] = fmaf(sf[kb][2], d.scale, mk.z); sf[kb][3] = fmaf(sf[kb][3], d.scale, mk.w);
+      mx = fmaxf(fmaxf(mx, fmaxf(sf[kb][0], sf[kb][1])), fmaxf(sf[kb][2], sf[kb][3]));
     }
+  }
   const float mn = xg_max(mx);
   const RngKey key = rng_key(a.rng, d.call_id);
   const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + qrow) ^ key.k0);
   float rs = 0.f;
   float p[KB][4];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb)
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb < nkb) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float e = expf(sf[kb][r] - mn);                  // exp(-inf) = 0 for the padding keys
-      rs += e;
-      if (d.p_drop > 0.f && kb < nkb)
-        e *= drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + qrow) * d.Sk + (16 * kb + 4 * g + r), d.p_drop, inv_keep);
-      p[kb][r] = e;
+      for (int r = 0; r < 4; ++r) { p[kb][r] = __expf(sf[kb][r] - mn); rs += p[kb][r]; }   // exp(-inf) = 0: padding keys
+      if (d.p_drop > 0.f) {
+        float ds4[4];
+        drop_scale4(key, rowh, (uint32_t)(4 * kb + g), d.p_drop, inv_keep, ds4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[kb][r] *= ds4[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[kb][r] = 0.f;
     }
+  }
   const float l_run = xg_sum(rs);
   f32x4 of[4];
 #pragma unroll
@@ -470,7 +521,7 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
     const float inv = 1.0f / l_run;
 #pragma unroll
     for (int db = 0; db < 4; ++db) st4<TO>(O + 16 * db + 4 * g, of[db][0] * inv, of[db][1] * inv, of[db][2] * inv, of[db][3] * inv);
-    if (g == 0) a.lse[((size_t)b * d.heads + h) * d.Sq + qrow] = mn + logf(l_run);
+    if (g == 0) a.lse[((size_t)b * d.heads + h) * d.Sq + qrow] = mn + __logf(l_run);
   }
 }
 
@@ -489,33 +540,39 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   bf16_t* dSt = Pt + sk16 * PST;
   float* lse_s = (float*)(dSt + sk16 * PST);
   float* delta_s = lse_s + sq16;
+  float* mk_s = delta_s + sq16;
   const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
   const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
   const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
   const TO* O = (const TO*)a.o + (size_t)b * d.Sq * d.ldo + h * 64;
   const TO* dO = (const TO*)a.d_o + (size_t)b * d.Sq * d.ldo + h * 64;
-  stage_rows<TI>(Q, d.ldq, d.Sq, sq16, Qs, t, nt);
-  stage_rows<TI>(K, d.ldk, d.Sk, sk16, Ks, t, nt);
-  stage_rows<TI>(V, d.ldv, d.Sk, sk16, Vs, t, nt);
-  {  // dO, with delta = rowsum(dO * O) in fp32 from the un-rounded values (8 threads per row) and the saved lse
-    const int c = (t & 7) * 8;
-    for (int r = t >> 3; r < sq16; r += nt >> 3) {
-      uint4 u = make_uint4(0, 0, 0, 0);
-      float acc = 0.f;
-      if (r < d.Sq) {
-        float f[8], o8[8];
-        ld8<TO>(dO + (size_t)r * d.ldo + c, f);
-        ld8<TO>(O + (size_t)r * d.ldo + c, o8);
+  {  // all five matrices in flight at once (nt = 64 * max(nqb, nkb) => 2 pieces per thread and matrix)
+    Raw8<TI> rq[2], rk[2], rv[2];
+    Raw8<TO> rdo[2], ro[2];
+    rows_load<TI, 2>(Q, d.ldq, d.Sq, t, nt, rq);
+    rows_load<TO, 2>(dO, d.ldo, d.Sq, t, nt, rdo);
+    rows_load<TO, 2>(O, d.ldo, d.Sq, t, nt, ro);
+    rows_load<TI, 2>(K, d.ldk, d.Sk, t, nt, rk);
+    rows_load<TI, 2>(V, d.ldv, d.Sk, t, nt, rv);
+    stage_mask(a.mask, b, d.Sk, sk16, mk_s, t, nt);
+    for (int i = t; i < sk16 * PST / 8; i += nt) { ((uint4*)Pt)[i] = make_uint4(0, 0, 0, 0); ((uint4*)dSt)[i] = make_uint4(0, 0, 0, 0); }
+    rows_store<TI, 2>(rq, sq16, Qs, t, nt);
+    rows_store<TO, 2>(rdo, sq16, dOs, t, nt);
+    // delta = rowsum(dO * O) in fp32 from the un-rounded values (8 threads per row) and the saved lse
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += f[i] * o8[i];
-        u = pack8(f);
-      }
-      *(uint4*)(dOs + r * AST + c) = u;
+    for (int i = 0; i < 2; ++i) {
+      const int r = (t >> 3) + i * (nt >> 3);
+      float f[8], o8[8], acc = 0.f;
+      raw_f32(rdo[i], f);
+      raw_f32(ro[i], o8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += f[j] * o8[j];
       acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-      if ((t & 7) == 0) { delta_s[r] = acc; lse_s[r] = r < d.Sq ? a.lse[((size_t)b * d.heads + h) * d.Sq + r] : 0.f; }
+      if ((t & 7) == 0 && r < sq16) { delta_s[r] = acc; lse_s[r] = r < d.Sq ? a.lse[((size_t)b * d.heads + h) * d.Sq + r] : 0.f; }
     }
+    rows_store<TI, 2>(rk, sk16, Ks, t, nt);
+    rows_store<TI, 2>(rv, sk16, Vs, t, nt);
   }
-  for (int i = t; i < sk16 * PST / 8; i += nt) { ((uint4*)Pt)[i] = make_uint4(0, 0, 0, 0); ((uint4*)dSt)[i] = make_uint4(0, 0, 0, 0); }
   __syncthreads();
   const RngKey key = rng_key(a.rng, d.call_id);
   const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
@@ -525,6 +582,8 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) { qf[s] = rfrag(Qs, ql, 32 * s + 8 * g); df[s] = rfrag(dOs, ql, 32 * s + 8 * g); }
     const float lse_q = lse_s[ql], delta_q = delta_s[ql];
+    const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + ql) ^ key.k0);
+    const bool qv = ql < d.Sq;                         // padding queries keep their (zero) columns; the MFMAs need every lane
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       if (kb < nkb) {
@@ -534,16 +593,17 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
           sf = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf);      // S^T[key][q]
           dpf = MFMA16(rfrag(Vs, 16 * kb + l15, 32 * s + 8 * g), df[s], dpf);    // dP^T[key][q] = V dO^T
         }
+        const float4 mk = *(const float4*)(mk_s + 16 * kb + 4 * g);
+        const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
+        float ds4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (d.p_drop > 0.f) drop_scale4(key, rowh, (uint32_t)(4 * kb + g), d.p_drop, inv_keep, ds4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kk = 16 * kb + 4 * g + r;
-          if (kk < d.Sk && ql < d.Sq) {                // everything else stays zero
-            const float mk = a.mask ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
-            const float pr = expf(sf[r] * d.scale + mk - lse_q);
-            float dsc = 1.0f;
-            if (d.p_drop > 0.f) dsc = drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + ql) * d.Sk + kk, d.p_drop, inv_keep);
-            Pt[kk * PST + ql] = f2bf(pr * dsc);
-            dSt[kk * PST + ql] = f2bf(pr * (dpf[r] * dsc - delta_q) * d.scale);
+          const float pr = __expf(fmaf(sf[r], d.scale, mk4[r]) - lse_q);          // 0 for the padding keys (mask = -inf)
+          if (qv) {
+            Pt[kk * PST + ql] = f2bf(pr * ds4[r]);
+            dSt[kk * PST + ql] = f2bf(pr * (dpf[r] * ds4[r] - delta_q) * d.scale);
           }
         }
       }
@@ -601,10 +661,12 @@ template <typename TI, typename TO>
 void launch_s128_fwd(const Attn16Args& a, hipStream_t s) {
   const hamt_attn_desc& d = a.d;
   const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16;
-  const dim3 grid(d.heads, d.B), block(64 * nqb);
-  const size_t lds = (size_t)2 * nkb * 16 * AST * sizeof(bf16_t);
+  const int nw = nqb > (nkb + 1) / 2 ? nqb : (nkb + 1) / 2;   // >= 2 threads per staged key row: 4 pieces per thread at most
+  const dim3 grid(d.heads, d.B), block(64 * nw);
+  const size_t lds = (size_t)2 * nkb * 16 * AST * sizeof(bf16_t) + (size_t)nkb * 16 * sizeof(float);
   if (nkb <= 2) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 2>), grid, block, lds, s, a);
   else if (nkb <= 4) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 4>), grid, block, lds, s, a);
+  else if (nkb <= 6) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 6>), grid, block, lds, s, a);
   else hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 8>), grid, block, lds, s, a);
 }
 
@@ -624,9 +686,10 @@ void launch_s128_bwd(const Attn16Args& a, hipStream_t s) {
   const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16, nb = nqb > nkb ? nqb : nkb;
   const int sq16 = nqb * 16, sk16 = nkb * 16;
   const dim3 grid(d.heads, d.B), block(64 * nb);
-  const size_t lds = ((size_t)2 * (sq16 + sk16) * AST + (size_t)2 * sk16 * (sq16 + 8)) * sizeof(bf16_t) + (size_t)2 * sq16 * sizeof(float);
+  const size_t lds = ((size_t)2 * (sq16 + sk16) * AST + (size_t)2 * sk16 * (sq16 + 8)) * sizeof(bf16_t) + (size_t)(2 * sq16 + sk16) * sizeof(float);
   if (nb <= 2) launch_s128_bwd_nb<TI, TO, 2>(a, grid, block, lds, s);
   else if (nb <= 4) launch_s128_bwd_nb<TI, TO, 4>(a, grid, block, lds, s);
+  else if (nb <= 6) launch_s128_bwd_nb<TI, TO, 6>(a, grid, block, lds, s);
   else launch_s128_bwd_nb<TI, TO, 8>(a, grid, block, lds, s);
 }
 

@@ -33,17 +33,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef unsigned short bf16_t;  // raw bf16 bits in memory
 
-// ---- bf16 <-> f32 (round to nearest even; NaN preserved)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// ---- bf16 <-> f32 (round to nearest even; NaN preserved): gfx950's v_cvt_pk_bf16_f32, one instruction per PAIR
+typedef __attribute__((ext_vector_type(2))) __bf16 hamt_bf2;
+typedef __attribute__((ext_vector_type(2))) float hamt_f2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const hamt_f2 v = {lo, hi};
+  const hamt_bf2 b = __builtin_convertvector(v, hamt_bf2);
+  return __builtin_bit_cast(uint32_t, b);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.0f) & 0xffffu); }
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // ---- counter-based dropout RNG: 24-bit uniform from (seed, epoch, call_id, element index)
 __device__ __forceinline__ uint32_t hamt_mix32(uint32_t x) {
@@ -64,6 +63,18 @@ __device__ __forceinline__ float drop_scale(RngKey k, uint64_t idx, float p, flo
   x = hamt_mix32(x + (uint32_t)(idx >> 32) * 0x9e3779b9u + k.k1);
   float u = (float)(x >> 8) * (1.0f / 16777216.0f);
   return u >= p ? inv_keep : 0.0f;
+}
+
+// Four keep factors at once for 4 consecutive elements of one row (short-sequence attention): one 2-round hash of
+// (row, group-of-4) gives 4 x 16-bit uniforms.  `rowh` = hamt_mix32(row_id ^ k.k0) is computed once per row.
+__device__ __forceinline__ void drop_scale4(RngKey k, uint32_t rowh, uint32_t grp, float p, float inv_keep, float (&f)[4]) {
+  const uint32_t x = hamt_mix32(rowh + grp * 0x9e3779b9u + k.k1);
+  const uint32_t y = hamt_mix32(x ^ 0x85ebca6bu);
+  const uint32_t thr = (uint32_t)(p * 65536.0f);           // keep iff u16 >= thr
+  f[0] = (x & 0xffffu) >= thr ? inv_keep : 0.0f;
+  f[1] = (x >> 16) >= thr ? inv_keep : 0.0f;
+  f[2] = (y & 0xffffu) >= thr ? inv_keep : 0.0f;
+  f[3] = (y >> 16) >= thr ? inv_keep : 0.0f;
 }
 
 // ---- wave reductions (64 lanes)
