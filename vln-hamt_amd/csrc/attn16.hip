@@ -433,89 +433,73 @@ __device__ __forceinline__ void stage_mask(const float* mask, int b, int Sk, int
   for (int i = t; i < sk16; i += nt) mk_s[i] = i < Sk ? (mask ? mask[(size_t)b * Sk + i] : 0.f) : -INFINITY;
 }
 
-template <typename TI, typename TO, int KB>   // KB: compile-time bound on the number of 16-key blocks (2, 4, 6, 8)
+template <typename TI, typename TO, int KB>   // KB: number of 16-key blocks staged and processed (2, 4, 6, 8) >= ceil(Sk / 16)
 __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   const hamt_attn_desc& d = a.d;
   const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int nkb = (d.Sk + 15) >> 4, sk16 = nkb * 16;
-  bf16_t* Ks = sm;
-  bf16_t* Vs = sm + sk16 * AST;
-  float* mk_s = (float*)(Vs + sk16 * AST);
+  constexpr int SKP = KB * 16;                         // staged key rows: zeros (K, V) and -inf (mask) beyond Sk, so the
+  bf16_t* Ks = sm;                                     // whole kernel is branch-free in the key dimension
+  bf16_t* Vs = sm + SKP * AST;
+  float* mk_s = (float*)(Vs + SKP * AST);
   const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
   const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
   const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
-  Raw8<TI> rk[4], rv[4];                               // the launcher guarantees 8 * sk16 <= 4 * nt
-  rows_load<TI, 4>(K, d.ldk, d.Sk, t, nt, rk);
-  rows_load<TI, 4>(V, d.ldv, d.Sk, t, nt, rv);
+  Raw8<TI> rk[2], rv[2];                               // the launcher guarantees 8 * SKP <= 2 * nt
+  rows_load<TI, 2>(K, d.ldk, d.Sk, t, nt, rk);
+  rows_load<TI, 2>(V, d.ldv, d.Sk, t, nt, rv);
   const int qrow = 16 * w + l15;                       // the ONE query row this lane owns
   const bool qok = qrow < d.Sq;
   bf16x8 qf[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)   // clamped, not branched (rows >= Sq are never stored)
     qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : d.Sq - 1) * d.ldq + 32 * s + 8 * g);
-  stage_mask(a.mask, b, d.Sk, sk16, mk_s, t, nt);
-  rows_store<TI, 4>(rk, sk16, Ks, t, nt);
-  rows_store<TI, 4>(rv, sk16, Vs, t, nt);
+  stage_mask(a.mask, b, d.Sk, SKP, mk_s, t, nt);
+  rows_store<TI, 2>(rk, SKP, Ks, t, nt);
+  rows_store<TI, 2>(rv, SKP, Vs, t, nt);
   __syncthreads();
   if (16 * w >= d.Sq) return;                          // waves that only helped staging (no barrier below)
-  f32x4 sf[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    sf[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (kb < nkb) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) sf[kb] = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf[kb]);
-    }
-  }
-  // sf[kb][r] = S[q = qrow][key = 16kb + 4g + r]
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    if (kb < nkb) {
-      const float4 mk = *(const float4*)(mk_s + 16 * kb + 4 * g);
-      sf[kb][0] = fmaf(sf[kb][0], d.scale, mk.x); sf[kb][1] = fmaf(sf[kb][1], d.scale, mk.y);
-      sf[kb][2] = fmaf(sf[kb][2], d.scale, mk.z); sf[kb][3] = fmaf(sf[kb][3], d.scale, mk.w);
-      mx = fmaxf(fmaxf(mx, fmaxf(sf[kb][0], sf[kb][1])), fmaxf(sf[kb][2], sf[kb][3]));
-    }
-  }
-  const float mn = xg_max(mx);
   const RngKey key = rng_key(a.rng, d.call_id);
   const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
   const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + qrow) ^ key.k0);
-  float rs = 0.f;
-  float p[KB][4];
+  f32x4 sf[KB];
+  float mx = -INFINITY;
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    if (kb < nkb) {
+  for (int kb = 0; kb < KB; ++kb) {                    // sf[kb][r] = S[q = qrow][key = 16kb + 4g + r]
+    sf[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { p[kb][r] = __expf(sf[kb][r] - mn); rs += p[kb][r]; }   // exp(-inf) = 0: padding keys
-      if (d.p_drop > 0.f) {
-        float ds4[4];
-        drop_scale4(key, rowh, (uint32_t)(4 * kb + g), d.p_drop, inv_keep, ds4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[kb][r] *= ds4[r];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[kb][r] = 0.f;
-    }
+    for (int s = 0; s < 2; ++s) sf[kb] = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf[kb]);
+    const float4 mk = *(const float4*)(mk_s + 16 * kb + 4 * g);
+    sf[kb][0] = fmaf(sf[kb][0], d.scale, mk.x); sf[kb][1] = fmaf(sf[kb][1], d.scale, mk.y);
+    sf[kb][2] = fmaf(sf[kb][2], d.scale, mk.z); sf[kb][3] = fmaf(sf[kb][3], d.scale, mk.w);
+    mx = fmaxf(fmaxf(mx, fmaxf(sf[kb][0], sf[kb][1])), fmaxf(sf[kb][2], sf[kb][3]));
   }
-  const float l_run = xg_sum(rs);
+  const float mn = xg_max(mx);
+  float rs = 0.f;
   f32x4 of[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) of[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // O^T = V^T P^T : k-step s covers key blocks 2s, 2s+1; this lane group's k = keys 4g..4g+3 of each block
 #pragma unroll
   for (int s = 0; s < KB / 2; ++s) {
-    if (2 * s < nkb) {
-      const bf16x8 pf = pack_frag(p[2 * s], p[2 * s + 1]);
+    float p[2][4];
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
-        of[db] = MFMA16(tfrag_lim(Vs, AST, 32 * s + 4 * g, 32 * s + 16 + 4 * g, sk16, 16 * db, lane), pf, of[db]);
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[e][r] = __expf(sf[2 * s + e][r] - mn); rs += p[e][r]; }   // exp(-inf) = 0: padding keys
+      if (d.p_drop > 0.f) {
+        float ds4[4];
+        drop_scale4(key, rowh, (uint32_t)(4 * (2 * s + e) + g), d.p_drop, inv_keep, ds4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[e][r] *= ds4[r];
+      }
     }
+    const bf16x8 pf = pack_frag(p[0], p[1]);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) of[db] = MFMA16(tfrag(Vs, 32 * s + 4 * g, 32 * s + 16 + 4 * g, 16 * db, lane), pf, of[db]);
   }
+  const float l_run = xg_sum(rs);
   if (qok) {
     TO* O = (TO*)a.out + (size_t)b * d.Sq * d.ldo + h * 64 + (size_t)qrow * d.ldo;
     const float inv = 1.0f / l_run;
@@ -661,12 +645,13 @@ template <typename TI, typename TO>
 void launch_s128_fwd(const Attn16Args& a, hipStream_t s) {
   const hamt_attn_desc& d = a.d;
   const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16;
-  const int nw = nqb > (nkb + 1) / 2 ? nqb : (nkb + 1) / 2;   // >= 2 threads per staged key row: 4 pieces per thread at most
+  const int kb = nkb <= 2 ? 2 : nkb <= 4 ? 4 : nkb <= 6 ? 6 : 8;
+  const int nw = nqb > kb ? nqb : kb;                  // >= 4 threads per staged key row: 2 pieces per thread and matrix
   const dim3 grid(d.heads, d.B), block(64 * nw);
-  const size_t lds = (size_t)2 * nkb * 16 * AST * sizeof(bf16_t) + (size_t)nkb * 16 * sizeof(float);
-  if (nkb <= 2) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 2>), grid, block, lds, s, a);
-  else if (nkb <= 4) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 4>), grid, block, lds, s, a);
-  else if (nkb <= 6) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 6>), grid, block, lds, s, a);
+  const size_t lds = (size_t)2 * kb * 16 * AST * sizeof(bf16_t) + (size_t)kb * 16 * sizeof(float);
+  if (kb == 2) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 2>), grid, block, lds, s, a);
+  else if (kb == 4) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 4>), grid, block, lds, s, a);
+  else if (kb == 6) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 6>), grid, block, lds, s, a);
   else hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 8>), grid, block, lds, s, a);
 }
 
