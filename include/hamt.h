@@ -158,7 +158,7 @@ int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, co
                 const uint64_t* rng, void* stream);
 /* dz = d(pre-LN sum) (also the residual gradient); dx = dropout_pre-masked dz (may be NULL); dx16 (optional) = the same
  * as bf16 [Mpad16, H] -- the operand of the dgrad/wgrad GEMMs of the dense layer that produced x; dxsum (optional) +=
- * column sums of dx = that layer's bias gradient; dgamma/dbeta are ACCUMULATED (+=).  ws: >= 3*256*H floats. */
+ * column sums of dx = that layer's bias gradient; dgamma/dbeta/dxsum are STORED (overwritten).  ws: >= 3*256*H floats. */
 int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
                 const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                 float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);

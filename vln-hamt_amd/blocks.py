@@ -168,10 +168,13 @@ class SelfAttnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
         ctx.meta = (B, S, H, M, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
         ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
         return y.view(B, S, H), y16
 
     @staticmethod
     def backward(ctx, dy, _unused=None):
+        if dy is None:
+            return (None,) * 16
         x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma = ctx.saved_tensors
         B, S, H, M, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
         dev = dy.device
@@ -224,10 +227,13 @@ class CrossAttnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
         ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
         ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
         return y.view(B, Sq, H), y16
 
     @staticmethod
     def backward(ctx, dy, _unused=None):
+        if dy is None:
+            return (None,) * 17
         x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma = ctx.saved_tensors
         B, Sq, Sk, H, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
         Mq, Mk = B * Sq, B * Sk
@@ -273,10 +279,13 @@ class FfnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma)
         ctx.meta = (shp, M, H, I, float(p_hidden), float(eps), cid_ln)
         ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
         return y.view(shp), y16
 
     @staticmethod
     def backward(ctx, dy, _unused=None):
+        if dy is None:
+            return (None,) * 9
         x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma = ctx.saved_tensors
         shp, M, H, I, p_hidden, eps, cid_ln = ctx.meta
         dev = dy.device

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(int nb, int H, cons
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
-      o[col] += t;
+      o[col] = t;
     }
   }
 }

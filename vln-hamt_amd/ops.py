@@ -473,7 +473,7 @@ def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_
     dx = torch.empty(M, H, dtype=torch.float32, device=dev) if (want_dx32 and p_pre > 0) else None
     Mp = _rup(M) if want_dx16 else 0
     dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want_dx16 else None
-    red = torch.zeros(3, H, dtype=torch.float32, device=dev)
+    red = torch.empty(3, H, dtype=torch.float32, device=dev)      # stored (not accumulated) by the reduce kernel
     ws = torch.empty(3 * 256 * H, dtype=torch.float32, device=dev)
     d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp)
     L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dx16),
@@ -497,10 +497,13 @@ class LnFn(torch.autograd.Function):
         ctx.args = (float(eps), float(p_pre), float(p_post), cid, residual is not None, x.shape)
         if y16 is not None:
             ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)         # no zero-filled stand-in for the bf16 image's (non-existent) gradient
         return y.view(x.shape), y16
 
     @staticmethod
     def backward(ctx, dy, _d16=None):
+        if dy is None:
+            return (None,) * 8
         z, mean, rstd, gamma = ctx.saved_tensors
         eps, p_pre, p_post, cid, has_res, xshape = ctx.args
         dy2 = dy.reshape(z.shape).contiguous()
