@@ -143,8 +143,8 @@ def main():
     from vln_hamt_amd import ops
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
-    from vln_hamt_amd.parallel import (TaskSchedule, allreduce_grads, barrier, broadcast_params, init_distributed, max_over_ranks,
-                                       sum_over_ranks)
+    from vln_hamt_amd.parallel import (OverlappedGradSync, TaskSchedule, allreduce_grads, barrier, broadcast_params, init_distributed,
+                                       max_over_ranks, sum_over_ranks)
     from vln_hamt_amd.synth import make_batch, make_itm_rng
 
     rank, local_rank, world = init_distributed()
@@ -164,7 +164,10 @@ def main():
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     if dist_on:
         broadcast_params(opt)                           # every rank starts from rank 0's weights (DDP does this at wrap time)
-    grad_sync = allreduce_grads if dist_on else None    # flat-arena RCCL all-reduce between backward and the update
+    # gradient exchange: flat-arena RCCL all-reduces, range by range behind the grouped weight-gradient GEMMs
+    grad_sync = None
+    if dist_on:
+        grad_sync = allreduce_grads if os.environ.get("HAMT_NO_OVERLAP") else OverlappedGradSync(opt, n_groups=4)
     net = model
 
     sched = TaskSchedule(cyclic=True) if args.task == "mix" else None
@@ -254,7 +257,7 @@ def main():
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
-                       "parallelism": f"dp{world}" + (" (flat-arena RCCL all-reduce)" if dist_on else ""),
+                       "parallelism": f"dp{world}" + (" (flat-arena RCCL all-reduce" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
                        "launch": "hipGraph replay" if graphed is not None else "eager"},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),

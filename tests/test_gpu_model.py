@@ -3,6 +3,8 @@
 Tolerances (north_star): activations/logits/losses <= 1e-3 in fp32 mode, <= 1e-2 in bf16 mode (max-abs,
 relative to max(1, |ref|_max)); integer/index work (compaction order, -inf positions) bit exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -334,3 +336,81 @@ def test_graph_replay_matches_eager_steps(tiny):
         worst = max(worst, float((a - b).abs().max()))
     print(f"[graph vs eager] worst parameter difference after {len(seq)} steps: {worst:.2e}")
     assert worst < 2e-5, worst      # total parameter movement over the 9 steps is ~9e-3
+
+
+def test_overlapped_grad_sync_matches_single_process_steps(tiny):
+    """The multi-GPU step (parallel.OverlappedGradSync: forward/backward graph, grouped weight gradients launched from a
+    stored plan with the arena all-reduces on a side stream, update graph) with a one-rank RCCL group == the plain
+    single-process steps, both through graphs and eagerly.  One rank makes the collective an identity, so any difference
+    is plumbing: missing / doubled gradients, wrong accumulate flags, stream ordering."""
+    import torch.distributed as dist
+    from vln_hamt_amd.graph import GraphedTrainStep
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    from vln_hamt_amd.parallel import OverlappedGradSync, broadcast_params
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+    from vln_hamt_amd import wgrad
+    store, cfg, sd = tiny
+
+    def make():
+        m = build(cfg, sd, "bf16", train=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        named = list(m.named_parameters())
+        groups = [{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+                  {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}]
+        return m, AdamW(groups, lr=1e-3, betas=(0.9, 0.98), eps=1.0)
+
+    seq = ["sap", "mlm", "itm", "sap", "mlm", "itm", "mrc", "sap"]
+    batches = {}
+    for t in set(seq):
+        b = make_batch(t, 4, cfg, seed=sum(map(ord, t)), txt_len=20, hist_len=4, ragged=True, device=DEV)
+        if t == "itm":
+            r = make_itm_rng(b, seed=3)
+            b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+        batches[t] = b
+    m1, o1 = make()
+    for t in seq:
+        m1(batches[t], t, True).mean().backward()
+        clip_grad_norm_(m1.parameters(), 5.0, optimizer=o1)
+        o1.step()
+        o1.zero_grad()
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for use_graph in (True, False):
+            m2, o2 = make()
+            o2.materialize()
+            broadcast_params(o2)
+            sync = OverlappedGradSync(o2, n_groups=3)
+            try:
+                n0 = wgrad.stats["problems"]
+                if use_graph:
+                    gs = GraphedTrainStep(m2, o2, 5.0, grad_sync=sync)
+                    for t in seq:
+                        gs.step(t, batches[t], t)
+                    assert all(ent[3] is not None and len(ent[3].groups) >= 1 for ent in gs.graphs.values())
+                else:
+                    for t in seq:
+                        m2(batches[t], t, True).mean().backward()
+                        sync(o2)
+                        clip_grad_norm_(m2.parameters(), 5.0, optimizer=o2)
+                        o2.step()
+                        o2.zero_grad()
+                assert wgrad.stats["problems"] > n0          # the queue did feed the plan
+            finally:
+                sync.close()
+            torch.cuda.synchronize()
+            worst = 0.0
+            for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+                worst = max(worst, float((a - b).abs().max()))
+            print(f"[overlapped sync, graph={use_graph}] worst parameter difference after {len(seq)} steps: {worst:.2e}")
+            assert worst < 2e-5, (use_graph, worst)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -74,6 +74,9 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
+        overl = getattr(self.grad_sync, "overlapped", False)
+        if overl:
+            self.grad_sync.mode = "plan"       # the end-of-backward flush only builds the plan during the capture
         with torch.cuda.graph(g, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
             loss_c = self.model(batch, task, True).mean()
             loss_c.backward()
@@ -82,6 +85,10 @@ class GraphedTrainStep:
             else:
                 self.opt._pack_grads()
             loss_c = loss_c.detach()           # drop the captured step's autograd graph (its buffers live in the pool)
+        plan = None
+        if overl:
+            self.grad_sync.mode = "eager"
+            plan = self.grad_sync.take_plan()  # the pass's weight-gradient GEMMs: launched between the two graphs
         if self.grad_sync is not None:
             if self.update_graph is None:      # norm + AdamW over the arena: the same launches for every key
                 self.update_graph = torch.cuda.CUDAGraph()
@@ -92,7 +99,7 @@ class GraphedTrainStep:
         self.opt._packed = False
         for p in self.opt._params:             # the captured gradient buffers stay alive inside the graph's pool
             p.grad = None
-        self.graphs[key] = (g, loss_c, active)
+        self.graphs[key] = (g, loss_c, active, plan)
         return loss
 
     def step(self, key, batch, task):
@@ -100,12 +107,15 @@ class GraphedTrainStep:
         ent = self.graphs.get(key)
         if ent is None:
             return self._capture(key, batch, task)
-        g, loss_c, active = ent
+        g, loss_c, active, plan = ent
         self.opt.prepare_step(active)
         g.replay()
         if self.grad_sync is not None:
-            self.opt._packed = True            # the replay packed the gradients; only the collective is left
-            self.grad_sync(self.opt)
-            self.opt._packed = False
+            if plan is not None:
+                self.grad_sync.run(plan)       # wgrad groups + overlapped all-reduces
+            else:
+                self.opt._packed = True        # the replay packed the gradients; only the collective is left
+                self.grad_sync(self.opt)
+                self.opt._packed = False
             self.update_graph.replay()
         return loss_c

@@ -105,6 +105,91 @@ def allreduce_grads(optimizer) -> None:
     allreduce_mean_(optimizer._flat_g)
 
 
+class OverlappedGradSync:
+    """Gradient exchange overlapped with the weight-gradient GEMMs (the only part of backward that is off the critical
+    path, and here deliberately run last, see wgrad.py):
+
+        backward (dgrad chain, queue filled)  ->  pack autograd grads into the arena
+        -> for g in launch groups (arena order):   grouped wgrad g on the compute stream
+                                                    all-reduce(arena range g) on the communication stream
+        -> tail range (biases / LayerNorm / whatever the last group touched) -> join -> clip + AdamW
+
+    so that RCCL moves range g over xGMI while group g+1 multiplies.  Works eagerly (the queue's end-of-backward
+    callback runs the whole sequence) and with graph.GraphedTrainStep (forward/backward/pack graph, then this sequence
+    launched eagerly from a stored plan, then the update graph).  Use as the `grad_sync` callable."""
+
+    overlapped = True
+
+    def __init__(self, optimizer, n_groups: int = 4):
+        from . import wgrad
+        self.opt, self.n_groups = optimizer, n_groups
+        self.comm = torch.cuda.Stream()
+        self.mode = "eager"                # "eager": run at flush; "plan": only build the plan (graph capture)
+        self.plan = None
+        self.done = False
+        wgrad.set_handler(self._on_flush)
+
+    def close(self):
+        from . import wgrad
+        wgrad.set_handler(None)
+
+    def _on_flush(self, items):
+        from . import wgrad
+        plan = wgrad.build_plan(items, self.opt, self.n_groups)
+        if plan is None:                   # some parameter lives outside the arena: plain semantics
+            wgrad.set_handler(None)
+            try:
+                wgrad._items.extend(items)
+                wgrad.flush()
+            finally:
+                wgrad.set_handler(self._on_flush)
+            return
+        if self.mode == "plan":
+            self.plan = plan
+            return
+        self.opt._pack_grads()
+        self.run(plan)
+        self.done = True
+
+    def take_plan(self):
+        p, self.plan = self.plan, None
+        return p
+
+    def run(self, plan):
+        """Launch the plan's groups on the current stream with the arena all-reduces on the communication stream."""
+        from . import wgrad
+        flat = self.opt._flat_g
+        main = torch.cuda.current_stream()
+        pending = sorted(plan.ranges, key=lambda r: r[2])
+        k = 0
+
+        def reduce_ready(after):
+            nonlocal k
+            first = True
+            while k < len(pending) and pending[k][2] <= after:
+                if first:
+                    self.comm.wait_stream(main)
+                    first = False
+                lo, hi, _ = pending[k]
+                with torch.cuda.stream(self.comm):
+                    allreduce_mean_(flat[lo:hi])
+                k += 1
+
+        reduce_ready(-1)
+        for g in range(len(plan.groups)):
+            wgrad.launch_group(plan, g)
+            reduce_ready(g)
+        main.wait_stream(self.comm)
+
+    def __call__(self, optimizer):
+        """After backward: nothing left to do when the flush already exchanged; else (no queued GEMM gradients in this
+        pass, e.g. fp32 mode) the plain flat all-reduce."""
+        if self.done:
+            self.done = False
+            return
+        allreduce_grads(optimizer)
+
+
 def broadcast_params(optimizer, src: int = 0) -> None:
     """Every rank starts from rank `src`'s parameters (what DDP does at construction)."""
     optimizer.materialize()

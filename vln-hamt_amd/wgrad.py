@@ -31,7 +31,13 @@ ENABLED = os.environ.get("HAMT_NO_DEFER_WGRAD") is None     # ablation switch: c
 
 _items: List[tuple] = []
 _scheduled = [False]
+_handler = [None]            # optional consumer of the queued items (multi-GPU overlap, parallel.OverlappedGradSync)
 stats = {"flushes": 0, "problems": 0}
+
+
+def set_handler(fn):
+    """Route the end-of-pass item list [(w, b, dy16, x16), ...] to `fn` instead of launching it here (None: default)."""
+    _handler[0] = fn
 
 
 def eligible(w: torch.Tensor, dy16: torch.Tensor, x16: torch.Tensor) -> bool:
@@ -101,6 +107,11 @@ def flush():
     _scheduled[0] = False
     if not items:
         return
+    if _handler[0] is not None:
+        stats["flushes"] += 1
+        stats["problems"] += len(items)
+        _handler[0](items)
+        return
     targets: dict = {}
     fresh: list = []
     # Two problems that write the same buffer (a parameter used twice in the pass) must not share a launch: the k-th
@@ -138,3 +149,103 @@ def flush():
             p.grad = t
         else:                                   # an existing gradient of another dtype / layout
             p.grad.add_(t.to(p.grad.dtype))
+
+
+# ------------------------------------------------------------------------------------------ planned (arena) mode
+class Plan:
+    """The queued weight gradients of one backward pass, resolved against the optimizer's flat gradient arena and cut
+    into `n_groups` launch groups in arena order, so that a caller can all-reduce the arena range of group g while
+    group g+1 is still computing (parallel.OverlappedGradSync).  `ranges` = [(lo, hi, after_group)]: arena elements
+    [lo, hi) are final once launch group `after_group` has run (-1: final before any group)."""
+
+    def __init__(self):
+        self.groups: List[tuple] = []      # (ctypes desc array, count)
+        self.ranges: List[tuple] = []
+        self.keep: list = []               # operand tensors: alive as long as the plan (graph replays re-use their memory)
+
+
+def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
+    """Resolve `items` to arena slots (every parameter must own one) and publish `.grad` views.  A parameter that
+    already has an autograd-produced `.grad` gets accum = 1: the caller packs that gradient into the slot BEFORE the
+    groups run.  Returns None when some parameter has no arena slot (caller falls back to flush semantics)."""
+    flat_g = optimizer._flat_g
+    base, n_total = flat_g.data_ptr(), flat_g.numel()
+
+    def off(p):
+        slot = getattr(p, "_hamt_grad_slot", None)
+        if slot is None or not (base <= slot.data_ptr() < base + 4 * n_total):
+            return None
+        return (slot.data_ptr() - base) // 4
+
+    probs = []
+    seen: dict = {}
+    for (w, b, dy16, x16) in items:
+        ow = off(w)
+        ob = off(b) if b is not None else None
+        if ow is None or (b is not None and ob is None):
+            return None
+        probs.append((ow, ob, w, b, dy16, x16))
+    probs.sort(key=lambda t: t[0])
+    flops = [2.0 * t[2].shape[0] * t[2].shape[1] * t[4].shape[0] for t in probs]
+    total, acc, cuts, gi = sum(flops), 0.0, [], 0
+    group_of = []
+    for f in flops:                         # equal-work cuts in arena order
+        if gi < n_groups - 1 and acc >= (gi + 1) * total / n_groups:
+            gi += 1
+        group_of.append(gi)
+        acc += f
+    # a buffer written twice in the pass: the second write must land in a LATER launch than the first
+    last_group: dict = {}
+    for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
+        gmin = max(last_group.get(ow, -1), last_group.get(ob, -1) if ob is not None else -1) + 1
+        group_of[i] = max(group_of[i], gmin)
+        last_group[ow] = group_of[i]
+        if ob is not None:
+            last_group[ob] = group_of[i]
+    ng = max(group_of) + 1
+    plan = Plan()
+    written: dict = {}
+    per_group: List[list] = [[] for _ in range(ng)]
+    for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
+        aw = 1 if (ow in written or (w.grad is not None and w.grad.data_ptr() != base + 4 * ow)) else 0
+        ab = 0
+        if ob is not None:
+            ab = 1 if (ob in written or (b.grad is not None and b.grad.data_ptr() != base + 4 * ob)) else 0
+            written[ob] = True
+        written[ow] = True
+        per_group[group_of[i]].append((ow, ob, w, b, dy16, x16, aw, ab))
+        plan.keep += [dy16, x16]
+    for grp in per_group:
+        descs = (L.WgradDesc * max(1, len(grp)))()
+        for i, (ow, ob, w, b, dy16, x16, aw, ab) in enumerate(grp):
+            d = descs[i]
+            d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), base + 4 * ow, (base + 4 * ob if ob is not None else None)
+            d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
+            d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), w.shape[1]
+            d.accum_dw, d.accum_db = aw, ab
+        plan.groups.append((descs, len(grp)))
+    # arena ranges and the launch group after which each is final
+    lows = [min(t[0] for t in grp) for grp in per_group if grp]
+    bounds = [0] + lows[1:] + [n_total]
+    for r in range(len(bounds) - 1):
+        lo, hi = bounds[r], bounds[r + 1]
+        after = -1
+        for g, grp in enumerate(per_group):
+            for (ow, ob, w, b, *_rest) in grp:
+                if lo <= ow < hi or (ob is not None and lo <= ob < hi):
+                    after = max(after, g)
+        if hi > lo:
+            plan.ranges.append((lo, hi, after))
+    for (ow, ob, w, b, *_r) in probs:       # publish .grad (arena views) so that "has a gradient" == "is active"
+        if w.grad is None:
+            w.grad = w._hamt_grad_slot
+        if b is not None and b.grad is None:
+            b.grad = b._hamt_grad_slot
+    return plan
+
+
+def launch_group(plan: Plan, g: int):
+    from .ops import _stream
+    descs, n = plan.groups[g]
+    if n:
+        L.check(L.load().hamt_wgrad_grouped(n, descs, _stream()), "hamt_wgrad_grouped")
