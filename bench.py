@@ -58,9 +58,14 @@ def build_model(prec, device):
     return model, cfg
 
 
-def time_gemm_roofline(batch, device, iters=30):
-    """Live HIP-event timing of the dominant kernel: the bf16 MFMA GEMM at the text FFN-1 shape
-    (M = B*80 rows, N = 3072, K = 768; forward).  Algorithmic FLOPs = 2*M*N*K per launch."""
+# HBM bytes per launch of wgrad_grouped_kernel<128> from the PMC passes (profiles/r01_pmc_*.txt: FETCH_SIZE x 2 per
+# MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), keyed by per-GPU batch; None = not collected for that batch
+WGRAD_TRAFFIC_BYTES = {64: int((2 * 952962.0 + 169736.2) * 1024)}   # ~2.1 GB per launch (algorithmic operand bytes ~0.6 GB: L2 re-reads)
+
+
+def time_gemm_probe(batch, device, iters=30):
+    """Secondary probe: the bf16 MFMA GEMM at the text FFN-1 shape (M = B*80 rows, N = 3072, K = 768; forward + bias),
+    HIP-event timed on the launch stream.  Algorithmic FLOPs = 2*M*N*K per launch."""
     from vln_hamt_amd import ops
     M, N, K = batch * L_TXT, FFN, H
     a = torch.randn(M, K, device=device).to(torch.bfloat16)      # operands as the step feeds them: bf16, K-contiguous
@@ -78,9 +83,56 @@ def time_gemm_roofline(batch, device, iters=30):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"kernel": f"gemm_fast_kernel<128, BIAS, NT> M={M} N={N} K={K} (text FFN-1 forward shape)", "achieved": round(tf, 2),
+            "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def time_wgrad_roofline(model, cfg, batch, device, iters=10):
+    """Live HIP-event timing of the dominant kernel of the step (rocprofv3: wgrad_grouped_kernel<128>, profiles/): the
+    grouped weight-gradient launch of one SAP backward pass, re-issued from the very problem list the pass queued
+    (same operands, scratch outputs).  Algorithmic FLOPs = sum over problems of 2*M*N*K; one call = ceil(n/40) launches."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as Lb, ops, wgrad
+    from vln_hamt_amd.synth import make_batch
+    b = make_batch("sap", batch, cfg, seed=4242, txt_len=L_TXT, hist_len=T_HIST, device=device)
+    items = []
+    prev = wgrad._handler[0]
+    wgrad.set_handler(items.extend)
+    try:
+        model(b, "sap", True).mean().backward()
+    finally:
+        wgrad.set_handler(prev)
+    for p_ in model.parameters():
+        p_.grad = None
+    n = len(items)
+    descs = (Lb.WgradDesc * n)()
+    keep, flops = [], 0.0
+    for i, (w, bb, dy16, x16) in enumerate(items):
+        dw = torch.empty(w.shape, dtype=torch.float32, device=device)
+        db = torch.empty(w.shape[0], dtype=torch.float32, device=device)
+        keep += [dw, db]
+        d = descs[i]
+        d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), (db.data_ptr() if bb is not None else None)
+        d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
+        flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
+    lib = Lb.load()
+    run = lambda: Lb.check(lib.hamt_wgrad_grouped(n, descs, ops._stream()), "hamt_wgrad_grouped")
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
+    s.record()
+    for _ in range(iters):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    launches = (n + 39) // 40
+    tf = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": f"gemm_nt_fast_kernel<128,BIAS> M={M} N={N} K={K} (text FFN-1 forward)", "avg_launch_us": round(ms * 1e3, 2)}
+            "kernel": f"wgrad_grouped_kernel (bf16 MFMA, {n} weight-gradient problems of one SAP backward pass, B={batch})",
+            "flops_per_call": flops, "launches_per_call": launches, "avg_launch_us": round(ms * 1e3 / launches, 2)}
 
 
 def cpu_baseline(budget_s=20.0, batch=16):
@@ -263,7 +315,9 @@ def main():
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
-        out["roofline"] = time_gemm_roofline(args.batch, device)
+        out["roofline"] = time_wgrad_roofline(model, cfg, args.batch, device)
+        out["roofline"]["traffic"] = WGRAD_TRAFFIC_BYTES.get(args.batch)
+        out["roofline_probe_ffn1"] = time_gemm_probe(args.batch, device)
         log("roofline probe done; timing the CPU oracle baseline")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
