@@ -90,7 +90,8 @@ def time_gemm_probe(batch, device, iters=30):
 def time_wgrad_roofline(model, cfg, batch, device, iters=10):
     """Live HIP-event timing of the dominant kernel of the step (rocprofv3: wgrad_grouped_kernel<128>, profiles/): the
     grouped weight-gradient launch of one SAP backward pass, re-issued from the very problem list the pass queued
-    (same operands, scratch outputs).  Algorithmic FLOPs = sum over problems of 2*M*N*K; one call = ceil(n/40) launches."""
+    (same operands, scratch outputs; the problems of the 256-square-tile class = one launch of
+    wgrad_grouped_kernel<256,256,2,4>).  Algorithmic FLOPs = sum over problems of 2*M*N*K."""
     import ctypes as C
     from vln_hamt_amd import _lib as Lb, ops, wgrad
     from vln_hamt_amd.synth import make_batch
@@ -104,6 +105,7 @@ def time_wgrad_roofline(model, cfg, batch, device, iters=10):
         wgrad.set_handler(prev)
     for p_ in model.parameters():
         p_.grad = None
+    items = [it for it in items if it[2].stride(0) >= 256 and it[3].stride(0) >= 256 and it[2].shape[0] >= 2048]   # the 256-square-tile launch class
     n = len(items)
     descs = (Lb.WgradDesc * n)()
     keep, flops = [], 0.0
@@ -116,7 +118,8 @@ def time_wgrad_roofline(model, cfg, batch, device, iters=10):
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
         flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
     lib = Lb.load()
-    run = lambda: Lb.check(lib.hamt_wgrad_grouped(n, descs, ops._stream()), "hamt_wgrad_grouped")
+    tab = torch.empty(n * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
+    run = lambda: Lb.check(lib.hamt_wgrad_grouped(n, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     for _ in range(2):
         run()
     torch.cuda.synchronize()
@@ -127,11 +130,11 @@ def time_wgrad_roofline(model, cfg, batch, device, iters=10):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
-    launches = (n + 39) // 40
+    launches = 1
     tf = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": f"wgrad_grouped_kernel (bf16 MFMA, {n} weight-gradient problems of one SAP backward pass, B={batch})",
+            "kernel": f"wgrad_grouped_kernel<256,256,2,4> (bf16 MFMA, {n} weight-gradient problems of one SAP backward pass, B={batch})",
             "flops_per_call": flops, "launches_per_call": launches, "avg_launch_us": round(ms * 1e3 / launches, 2)}
 
 

@@ -97,6 +97,7 @@ int hamt_smallk_wgrad(int M, int N, int K, const float* dy, int lddy, const floa
  *     dW_p[M_p][N_p] (+)= dY_p^T X_p      and, when db != NULL,      db_p[M_p] (+)= column sums of dY_p,
  * with dY_p bf16 [K_p][ldy] (its M_p columns = the layer's output features) and X_p bf16 [K_p][ldx] (the layer's input
  * image), both exactly as the forward / dgrad GEMMs left them (K_p = rows padded to a multiple of 64 with ZERO rows).
+ * Problems are packed into one launch per tile class (256-square tiles when the operand rows allow, else 128 / 64 rows).
  * This is what torch.autograd does one nn.Linear at a time in the reference (vilmodel.py: every nn.Linear backward);
  * weight gradients are not on the backward critical path, so the host queues them and hands the whole list over once per
  * backward pass: 768x768 outputs that alone fill 36 CUs become one chip-filling grid without split-K.
@@ -110,7 +111,11 @@ typedef struct {
   int M, N, K, ldy, ldx, ldw;
   int accum_dw, accum_db; /* 0: store, 1: += */
 } hamt_wgrad_desc;
-int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* stream);
+/* `table`: caller-provided DEVICE scratch of >= n * HAMT_WGRAD_TABLE_ENTRY bytes (16-byte aligned) that holds the launch
+ * table; it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can
+ * be captured in a hipGraph.  The table must stay untouched until the launches have run. */
+#define HAMT_WGRAD_TABLE_ENTRY 64
+int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
 int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate,

@@ -159,10 +159,14 @@ torch.save((o1.cpu(), o2.cpu()), sys.argv[1])
         assert torch.equal(x, y)
 
 
-def test_wgrad_grouped_matches_per_problem_reference():
+@pytest.mark.parametrize("tile", ["auto", "256", "128", "64"])
+def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
     """hamt_wgrad_grouped: heterogeneous problems in one call (ragged M/N, column-slice operands, short and long K,
-    store and accumulate, fused bias sums) against fp64 matmuls of the same bf16 operands."""
+    store and accumulate, fused bias sums) against fp64 matmuls of the same bf16 operands; every tile variant
+    (256x256 / 8 waves, 128x128 and 64x128 / 4 waves) and the launcher's own choice."""
     import ctypes as C
+    if tile != "auto":
+        monkeypatch.setenv("HAMT_WGRAD_TILE", tile)
     from vln_hamt_amd import _lib as L
     ops = _ops()
     lib = L.load()
@@ -175,10 +179,10 @@ def test_wgrad_grouped_matches_per_problem_reference():
     descs = (L.WgradDesc * len(specs))()
     for i, (K, M, N, aw, wdb, ab) in enumerate(specs):
         valid = K - (i % 3) * 7                    # rows >= valid are zero padding
-        dyf = rnd(K, max(M + 8, 64), seed=3 * i, scale=0.5)
+        dyf = rnd(K, max(M + 8, 256), seed=3 * i, scale=0.5)
         dyf[valid:] = 0
         dy = dyf.to(torch.bfloat16).to(DEV)[:, 8 * (i % 2):8 * (i % 2) + M]   # column slice of a wider buffer
-        x = rnd(K, N, seed=3 * i + 1).to(torch.bfloat16).to(DEV)
+        x = rnd(K, max(N, 256), seed=3 * i + 1).to(torch.bfloat16).to(DEV)[:, :N]
         dw0 = rnd(M, N, seed=3 * i + 2)
         db0 = rnd(M, seed=3 * i + 5)
         dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
@@ -189,7 +193,8 @@ def test_wgrad_grouped_matches_per_problem_reference():
         rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
         rb = (dy.double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
         refs.append((dw, db, rw, rb))
-    L.check(lib.hamt_wgrad_grouped(len(specs), descs, ops._stream()), "hamt_wgrad_grouped")
+    tab = torch.empty(len(specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
+    L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     torch.cuda.synchronize()
     for i, (dw, db, rw, rb) in enumerate(refs):
         close(dw, rw, 3e-5, f"dW[{i}] {specs[i]}")
@@ -197,7 +202,7 @@ def test_wgrad_grouped_matches_per_problem_reference():
     # argument validation is loud
     descs[0].K = 100
     with pytest.raises(L.HamtError):
-        L.check(lib.hamt_wgrad_grouped(1, descs, ops._stream()), "hamt_wgrad_grouped")
+        L.check(lib.hamt_wgrad_grouped(1, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
 
 
 def test_deferred_wgrad_queue_semantics():

@@ -37,6 +37,9 @@ class LnDesc(C.Structure):
 
 
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
+WGRAD_TABLE_ENTRY = 64      # HAMT_WGRAD_TABLE_ENTRY
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32), ("ldy", i32),
                 ("ldx", i32), ("ldw", i32), ("accum_dw", i32), ("accum_db", i32)]
@@ -50,7 +53,7 @@ SIGNATURES = {
     "hamt_gemm_ws": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, sz, vp],
     "hamt_cast_pad_bf16": [i32, i32, i32, i32, vp, i32, vp, i32, vp],
     "hamt_cast_transpose": [i32, i32, vp, i32, i32, vp, i32, i32, vp],
-    "hamt_wgrad_grouped": [i32, C.POINTER(WgradDesc), vp],
+    "hamt_wgrad_grouped": [i32, C.POINTER(WgradDesc), vp, sz, vp],
     "hamt_smallk_wgrad": [i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp],
     "hamt_colsum": [i32, i32, vp, i32, i32, vp, i32, vp, vp],
     "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],

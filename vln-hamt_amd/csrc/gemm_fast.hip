@@ -59,18 +59,18 @@ __device__ __forceinline__ unsigned lds_addr(const bf16_t* p) { return __builtin
 // quad reads 32 contiguous bytes) and sends the 4 rows of a tr-read (and, for 256-byte rows, the sibling 16-lane
 // group 8 rows further) to different bank groups.
 template <int R> __device__ __forceinline__ int col_swz(int kk) {
-  return R == 128 ? (((kk & 3) | (((kk >> 3) & 1) << 2)) << 1) : ((kk & 3) << 1);
+  return R == 256 ? (((kk & 3) | (((kk >> 3) & 3) << 2)) << 1) : R == 128 ? (((kk & 3) | (((kk >> 3) & 1) << 2)) << 1) : ((kk & 3) << 1);
 }
 
 // DMA one operand tile into LDS; every wave-instruction moves 1 KiB (64 lanes x 16 B).
 //   KM == false: operand stored [rows][K] (K contiguous): tile image [R][64], 8 rows per instruction, chunk ^= row & 7
 //   KM == true : operand stored [K][cols] (K strided):    tile image [64][R], 1 KiB = 1024/(2R) k-rows per instruction
 // Out-of-range rows are clamped (re-read a valid row); see the callers for why that is harmless.
-template <bool KM, int R>
+template <bool KM, int R, int NW = 4>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, int kmax, bf16_t* lds,
                                            int w, int lane) {
   if constexpr (!KM) {
-    constexpr int PER_WAVE = R / 4;              // tile rows per wave
+    constexpr int PER_WAVE = R / NW;             // tile rows per wave
 #pragma unroll
     for (int j = 0; j < PER_WAVE / 8; ++j) {
       const int rbase = w * PER_WAVE + j * 8;    // wave-uniform
@@ -81,9 +81,9 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld,
       glds16(P + (size_t)gr * ld + k0 + chunk * 8, lds_addr(lds + rbase * BK));
     }
   } else {
-    constexpr int CH = R / 8;                    // 16-byte chunks per k-row (16 or 8)
-    constexpr int ROWS_PER_INSTR = 64 / CH;      // 4 or 8
-    constexpr int PER_WAVE = BK / 4;             // 16 k-rows per wave
+    constexpr int CH = R / 8;                    // 16-byte chunks per k-row (32, 16 or 8)
+    constexpr int ROWS_PER_INSTR = 64 / CH;      // 2, 4 or 8
+    constexpr int PER_WAVE = BK / NW;            // k-rows per wave
 #pragma unroll
     for (int j = 0; j < PER_WAVE / ROWS_PER_INSTR; ++j) {
       const int kbase = w * PER_WAVE + j * ROWS_PER_INSTR;   // wave-uniform
@@ -205,13 +205,17 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
 // One BMx128 output tile over k-tiles [kt0, kt0 + nk).  COLSUM (weight-gradient form, A = dY stored [K][M]): the wave
 // column wn == 0 of the tiles with n0 == 0 also reduces A over k with one extra MFMA per fragment against a ones
 // operand (D'[n][m] = sum_k 1 * A[m][k]) -- the bias gradient, for free of any extra pass over dY.
-template <int BM, int EPI, bool A_KM, bool B_KM, int NSTAGE, bool COLSUM>
+template <int BM, int EPI, bool A_KM, bool B_KM, int NSTAGE, bool COLSUM, int BN = 128, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, int kt0, int nk, int slice, float* db, int db_accum) {
+  // WM x WN waves, each a (BM/WM) x (BN/WN) output as FM x FN fragments of 16x16.  Instances: 64/128 x 128 with 2x2 waves
+  // (two or three workgroups per CU), and 256 x 256 with 2x4 waves (one 512-thread workgroup per CU; half the DMA
+  // pieces and 3/4 of the LDS fragment reads per MFMA of the 128-square tile) for grids that are large enough.
+  constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN;
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
-  constexpr int FM = BM / 32;                    // 16-row fragments per wave along M (wave tile = BM/2 x 64)
-  constexpr int NLD = (BM + BN) / 32;            // glds instructions per wave per stage (8 or 6)
+  constexpr int FM = TM / 16, FN = TN / 16;      // 16x16 fragments per wave along M and N
+  constexpr int NLD = (BM + BN) / (8 * NW);      // glds instructions per wave per stage
   __shared__ __attribute__((aligned(16))) bf16_t lds[NSTAGE * STAGE];
-  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w / WN, wn = w % WN;
   const bool do_cs = COLSUM && db != nullptr && n0 == 0 && wn == 0;   // wave-uniform
   f32x4 cs[FM];
   if constexpr (COLSUM) {
@@ -219,16 +223,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     for (int i = 0; i < FM; ++i) cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  f32x4 acc[FM][4];
+  f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int kt, int slot) {
     bf16_t* dst = lds + slot * STAGE;
-    stage_tile<A_KM, BM>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, g.ka_max, dst, w, lane);
-    stage_tile<B_KM, BN>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + A_ELEMS, w, lane);
+    stage_tile<A_KM, BM, NW>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, g.ka_max, dst, w, lane);
+    stage_tile<B_KM, BN, NW>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + A_ELEMS, w, lane);
   };
   if constexpr (NSTAGE > 1) {
 #pragma unroll
@@ -252,15 +256,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 af[FM], bfr[4];
+      bf16x8 af[FM], bfr[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = frag<A_KM, BM>(As, wm * (BM / 2) + i * 16, s, lane);
+      for (int i = 0; i < FM; ++i) af[i] = frag<A_KM, BM>(As, wm * TM + i * 16, s, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = frag<B_KM, BN>(Bs, wn * 64 + j * 16, s, lane);
+      for (int j = 0; j < FN; ++j) bfr[j] = frag<B_KM, BN>(Bs, wn * TN + j * 16, s, lane);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)   // swapped roles: D[n][m] => lane owns C[m = lane&15][n = 4*(lane>>4) .. +3]
+        for (int j = 0; j < FN; ++j)   // swapped roles: D[n][m] => lane owns C[m = lane&15][n = 4*(lane>>4) .. +3]
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       if constexpr (COLSUM) {
         if (do_cs) {
@@ -276,7 +280,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     if (do_cs && lane < 16) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = m0 + wm * (BM / 2) + i * 16 + lane;
+        const int row = m0 + wm * TM + i * 16 + lane;
         if (row < g.M) db[row] = db_accum ? db[row] + cs[i][0] : cs[i][0];
       }
     }
@@ -288,45 +292,45 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
   // accumulate reads coalesced as well.  The C tile is [BM][128] fp32 with the float4 slot index XOR-ed with (row & 7):
   // conflict-free for the 8-row groups of the b128 writes and for the row-contiguous reads, and exactly the size of
   // the 2-deep operand ring for BM = 128 (64 KiB).
-  static_assert(BM * BN * 4 <= NSTAGE * STAGE * 2 || NSTAGE < 2, "C tile must fit in the operand ring");
-  if constexpr (BM * BN * 4 > NSTAGE * STAGE * 2) {   // (ring depth 1 only) store from the MFMA layout
-#pragma unroll
+  if constexpr (BM * BN * 4 > NSTAGE * STAGE * 2) {   // C tile larger than the ring (256-square tile): store from the MFMA
+#pragma unroll                                        // layout -- 16 bytes per lane for fp32 outputs, which is all it is used for
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = m0 + wm * (BM / 2) + i * 16 + (lane & 15), col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      for (int j = 0; j < FN; ++j) {
+        const int row = m0 + wm * TM + i * 16 + (lane & 15), col = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
         const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         if (g.ksplit > 1) {
           float* P = g.part + (size_t)slice * g.M * g.N;
           if (row < g.M) for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = a4[e];
         } else epi_store<EPI, 4>(g, row, col, a4);
       }
-    return;
-  }
-  float* ct = (float*)lds;
-  __syncthreads();                               // every wave is done reading the last operand tile
+  } else {
+    static_assert(BN == 128 && NW == 4, "the staged epilogue is written for 128-column tiles and 256 threads");
+    float* ct = (float*)lds;
+    __syncthreads();                               // every wave is done reading the last operand tile
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rl = wm * (BM / 2) + i * 16 + (lane & 15), c4 = wn * 16 + j * 4 + (lane >> 4);
-      *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[i][j];
-    }
-  __syncthreads();
-  const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + 16 p
-#pragma unroll
-  for (int p = 0; p < BM / 16; ++p) {
-    const int rl = p * 16 + (t >> 4), row = m0 + rl;
-    const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
-    const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
-    const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
-      float* P = g.part + (size_t)slice * g.M * g.N;
-      if (row < g.M) {
-        if (col + 8 <= g.N && (g.N & 3) == 0) st_f<8>(P + (size_t)row * g.N + col, v8);
-        else for (int e = 0; e < 8; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v8[e];
+      for (int j = 0; j < FN; ++j) {
+        const int rl = wm * TM + i * 16 + (lane & 15), c4 = wn * 16 + j * 4 + (lane >> 4);
+        *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[i][j];
       }
-    } else epi_store<EPI, 8>(g, row, col, v8);
+    __syncthreads();
+    const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + 16 p
+#pragma unroll
+    for (int p = 0; p < BM / 16; ++p) {
+      const int rl = p * 16 + (t >> 4), row = m0 + rl;
+      const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
+      const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+      const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (g.ksplit > 1) {   // raw partial tile, combined (and epilogued) by the reduce pass
+        float* P = g.part + (size_t)slice * g.M * g.N;
+        if (row < g.M) {
+          if (col + 8 <= g.N && (g.N & 3) == 0) st_f<8>(P + (size_t)row * g.N + col, v8);
+          else for (int e = 0; e < 8; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v8[e];
+        }
+      } else epi_store<EPI, 8>(g, row, col, v8);
+    }
   }
 }
 
@@ -350,24 +354,36 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
 // split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
-constexpr int WG_MAX = 40;
+constexpr int WG_MAX = 40;                       // table entries carried by one kernarg block
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
 };
-struct WgradArgs { int n, ntiles; WgradProb p[WG_MAX]; };
+struct WgradChunk { WgradProb p[WG_MAX]; };
+// The problem table lives in caller-provided device memory and is WRITTEN BY KERNELS whose kernargs carry it 40 entries
+// at a time: no host buffer has to outlive the call, so the whole sequence is hipGraph-capturable as is.
+__global__ void wgrad_table_write_kernel(WgradChunk c, WgradProb* tab, int off, int cnt) {
+  if ((int)threadIdx.x < cnt) tab[off + threadIdx.x] = c.p[threadIdx.x];
+}
 
-template <int BM>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(WgradArgs a) {
-  const int bid = xcd_remap(blockIdx.x, a.ntiles);
-  int pi = 0;
-  while (pi + 1 < a.n && bid >= a.p[pi].tile_end) ++pi;
-  const WgradProb& q = a.p[pi];
-  const int local = bid - (pi ? a.p[pi - 1].tile_end : 0);
-  const int tiles_n = (q.N + BN - 1) / BN;
+template <int BM, int BNT, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const WgradProb* __restrict__ tab, int n, int ntiles) {
+  const int bid = blockIdx.x;                    // problems in launch order (longest K first) ...
+  int lo = 0, hi = n - 1;                        // first problem whose tile_end > bid (wave-uniform binary search)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (bid >= tab[mid].tile_end) lo = mid + 1; else hi = mid;
+  }
+  const WgradProb q = tab[lo];
+  const int start = lo ? tab[lo - 1].tile_end : 0;
+  // ... and the XCD remap PER PROBLEM (blocks with equal (bid - start) & 7 sit on one XCD): each XCD gets a contiguous run
+  // of every problem's tiles.  Remapping the concatenated tile space instead would hand XCD 0 only the longest
+  // reductions and XCD 7 only the shortest.
+  const int local = xcd_remap(bid - start, q.tile_end - start);
+  const int tiles_n = (q.N + BNT - 1) / BNT;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
               q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1};
-  gemm_tile<BM, -2, true, true, 2, true>(g, (local / tiles_n) * BM, (local % tiles_n) * BN, 0, q.K / BK, 0, q.db, q.flags & 2);
+  gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, q.K / BK, 0, q.db, q.flags & 2);
 }
 
 // ---------------------------------------------------------------- fp32/bf16 [R][C] -> bf16 [C][Rpad] (zero padded)
@@ -474,7 +490,7 @@ extern "C" int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dty
   return HAMT_OK;
 }
 
-extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* stream) {
+extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream) {
   HAMT_CHECK_ARG(n >= 0 && (n == 0 || probs), "hamt_wgrad_grouped: bad argument");
   std::vector<int> order;
   for (int i = 0; i < n; ++i) {
@@ -487,26 +503,55 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* str
     if (d.K > 0) order.push_back(i);
     else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
   }
-  // longest reductions first: the short tail tiles fill in behind them
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[a].K > probs[b].K; });
-  for (size_t c0 = 0; c0 < order.size(); c0 += WG_MAX) {
-    const int cn = (int)std::min<size_t>(WG_MAX, order.size() - c0);
-    long t128 = 0;
-    for (int i = 0; i < cn; ++i) { const hamt_wgrad_desc& d = probs[order[c0 + i]]; t128 += (long)((d.M + 127) / 128) * ((d.N + BN - 1) / BN); }
-    const int bm = t128 >= 1024 ? 128 : 64;      // same rule as hamt_gemm_fast_launch: fill the chip first
-    WgradArgs a;
-    a.n = cn;
-    int tiles = 0;
-    for (int i = 0; i < cn; ++i) {
-      const hamt_wgrad_desc& d = probs[order[c0 + i]];
-      tiles += ((d.M + bm - 1) / bm) * ((d.N + BN - 1) / BN);
-      a.p[i] = WgradProb{(const bf16_t*)d.dy, (const bf16_t*)d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy, d.ldx, d.ldw,
-                         (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles};
+  if (order.empty()) return HAMT_OK;
+  HAMT_CHECK_ARG(table && table_bytes >= order.size() * sizeof(WgradProb) && (uintptr_t)table % 16 == 0,
+                 "hamt_wgrad_grouped: table must be 16-byte aligned device memory of >= %zu bytes", order.size() * sizeof(WgradProb));
+  hipStream_t s = as_stream(stream);
+  // Two launch classes: problems whose operand rows are >= 256 elements wide can use 256-square tiles; the rest 128 / 64
+  // rows.  Within a class: longest reductions first, the short tail tiles fill in behind them.
+  std::vector<int> cls[2];
+  // (a 256-square tile runs alone on its CU, so its prologue and store tail are exposed: only worth it for long reductions)
+  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && probs[i].K >= 2048) ? 0 : 1].push_back(i);
+  const char* fenv = getenv("HAMT_WGRAD_TILE");   // test / tuning override: 256, 128 or 64 (read per call)
+  const int force = fenv ? atoi(fenv) : 0;
+  {
+    long t256 = 0;
+    for (int i : cls[0]) t256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
+    if (force == 128 || force == 64 || (t256 < 768 && force != 256)) { cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
+  }
+  WgradProb* tab = (WgradProb*)table;
+  int off = 0;
+  for (int c = 0; c < 2; ++c) {
+    std::vector<int>& v = cls[c];
+    if (v.empty()) continue;
+    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return probs[a].K > probs[b].K; });
+    long t128 = 0, t256 = 0;
+    for (int i : v) {
+      t128 += (long)((probs[i].M + 127) / 128) * ((probs[i].N + 127) / 128);
+      t256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
     }
-    a.ntiles = tiles;
-    if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128>), dim3(tiles), dim3(256), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL((wgrad_grouped_kernel<64>), dim3(tiles), dim3(256), 0, as_stream(stream), a);
+    // 256-square tiles (one 8-wave workgroup per CU) when they still give every CU >= 3 tiles; else 128 / 64 rows
+    int bm = c == 0 ? 256 : (t128 >= 1024 ? 128 : 64);
+    if (force == 128 || force == 64) bm = force;
+    const int bn = bm == 256 ? 256 : 128;
+    int tiles = 0;
+    const int cn = (int)v.size();
+    for (int b0 = 0; b0 < cn; b0 += WG_MAX) {
+      WgradChunk ch;
+      const int cnt = std::min(WG_MAX, cn - b0);
+      for (int i = 0; i < cnt; ++i) {
+        const hamt_wgrad_desc& d = probs[v[b0 + i]];
+        tiles += ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
+        ch.p[i] = WgradProb{(const bf16_t*)d.dy, (const bf16_t*)d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy, d.ldx, d.ldw,
+                            (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles};
+      }
+      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, off + b0, cnt);
+    }
+    if (bm == 256) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 256, 2, 4>), dim3(tiles), dim3(512), 0, s, tab + off, cn, tiles);
+    else if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0, s, tab + off, cn, tiles);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<64, 128, 2, 2>), dim3(tiles), dim3(256), 0, s, tab + off, cn, tiles);
     HAMT_CHECK_LAUNCH("hamt_wgrad_grouped");
+    off += cn;
   }
   return HAMT_OK;
 }

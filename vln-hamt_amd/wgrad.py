@@ -69,6 +69,17 @@ def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: t
         torch.autograd.Variable._execution_engine.queue_callback(flush)
 
 
+def launch(descs, n: int, table: Optional[torch.Tensor] = None):
+    """hamt_wgrad_grouped on the current stream; `table` = device scratch for the launch table (allocated here when
+    None: from the caching allocator, i.e. from the graph's private pool during a capture)."""
+    from .ops import _stream
+    if n == 0:
+        return
+    if table is None:
+        table = torch.empty(n * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device="cuda")
+    L.check(L.load().hamt_wgrad_grouped(n, descs, table.data_ptr(), table.numel(), _stream()), "hamt_wgrad_grouped")
+
+
 def pending() -> int:
     return len(_items)
 
@@ -141,7 +152,7 @@ def flush():
             d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), tw.stride(0)
             d.accum_dw, d.accum_db = int(bool(aw)), int(bool(ab))
-        L.check(lib.hamt_wgrad_grouped(len(grp), descs, _stream()), "hamt_wgrad_grouped")
+        launch(descs, len(grp))
     stats["flushes"] += 1
     stats["problems"] += len(items)
     for p, t in fresh:
@@ -160,6 +171,7 @@ class Plan:
 
     def __init__(self):
         self.groups: List[tuple] = []      # (ctypes desc array, count)
+        self.tables: List[torch.Tensor] = []   # per-group device scratch for the launch tables (re-used every replay)
         self.ranges: List[tuple] = []
         self.keep: list = []               # operand tensors: alive as long as the plan (graph replays re-use their memory)
 
@@ -224,6 +236,7 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), w.shape[1]
             d.accum_dw, d.accum_db = aw, ab
         plan.groups.append((descs, len(grp)))
+        plan.tables.append(torch.empty(max(1, len(grp)) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=flat_g.device))
     # arena ranges and the launch group after which each is final
     lows = [min(t[0] for t in grp) for grp in per_group if grp]
     bounds = [0] + lows[1:] + [n_total]
@@ -245,7 +258,6 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
 
 
 def launch_group(plan: Plan, g: int):
-    from .ops import _stream
     descs, n = plan.groups[g]
     if n:
-        L.check(L.load().hamt_wgrad_grouped(n, descs, _stream()), "hamt_wgrad_grouped")
+        launch(descs, n, table=plan.tables[g])
