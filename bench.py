@@ -83,7 +83,7 @@ def time_gemm_probe(batch, device, iters=30):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return {"kernel": f"gemm_fast_kernel<128, BIAS, NT> M={M} N={N} K={K} (text FFN-1 forward shape)", "achieved": round(tf, 2),
+    return {"kernel": f"bf16 MFMA GEMM + bias, NT, M={M} N={N} K={K} (text FFN-1 forward shape; tile picked by the launcher)", "achieved": round(tf, 2),
             "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2)}
 
 

@@ -261,11 +261,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       for (int i = 0; i < FM; ++i) af[i] = frag<A_KM, BM>(As, wm * TM + i * 16, s, lane);
 #pragma unroll
       for (int j = 0; j < FN; ++j) bfr[j] = frag<B_KM, BN>(Bs, wn * TN + j * 16, s, lane);
+      __builtin_amdgcn_s_setprio(1);             // the co-resident wave (other workgroup / other half) is in its load phase
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)   // swapped roles: D[n][m] => lane owns C[m = lane&15][n = 4*(lane>>4) .. +3]
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
       if constexpr (COLSUM) {
         if (do_cs) {
           const s16x8 one8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
@@ -409,6 +411,29 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(int R, int C, const
   }
 }
 
+// 256x256 tile, 8 waves, one workgroup per CU: for grids of about one (or several) 256-square tiles per CU
+template <int EPI, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512) void gemm_fast256_kernel(GemmArgsF g) {
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  gemm_tile<256, EPI, A_KM, B_KM, 2, false, 256, 2, 4>(g, (bid / tiles_n) * 256, (bid % tiles_n) * 256, 0, g.K / BK, 0, nullptr, 0);
+}
+
+template <bool A_KM, bool B_KM>
+bool launch_256(const GemmArgsF& g, hipStream_t s) {
+  const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256));
+  const int e = g.epi;
+#define HAMT_L(E) hipLaunchKernelGGL((gemm_fast256_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g)
+  if (e == 0) HAMT_L(0);
+  else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
+  else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
+  else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
+  else return false;
+#undef HAMT_L
+  return true;
+}
+
 template <int BM, bool A_KM, bool B_KM>
 void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   const int e = g.epi;
@@ -456,6 +481,15 @@ int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes) {
   return s < 2 ? 1 : s;
 }
 
+// 256-square tiles (8 waves, one workgroup per CU, operands re-used twice as often per DMA piece and LDS read): when the
+// grid is 0.8 .. 1 tile per CU or at least 3 per CU, and the K-strided operand rows are wide enough for the tile.
+static bool use256(const hamt_gemm_desc* d, int force_bm) {
+  if (d->b_kmajor && d->ldb < 256) return false;
+  if (force_bm) return force_bm == 256;
+  const long t = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  return (t >= 208 && t <= 256) || t >= 768;
+}
+
 void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, void* aux,
                            float* ws, size_t ws_bytes, hipStream_t s) {
   GemmArgsF g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha,
@@ -474,6 +508,10 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
   g.ksplit = ks;
   g.part = ks > 1 ? ws : nullptr;
   const dim3 g64(((d->M + 63) / 64) * ((d->N + BN - 1) / BN), ks), g128(((d->M + 127) / 128) * ((d->N + BN - 1) / BN), ks);
+  if (ks == 1 && use256(d, force_bm)) {
+    const bool ok = !d->a_kmajor ? (!d->b_kmajor ? launch_256<false, false>(g, s) : launch_256<false, true>(g, s)) : false;
+    if (ok) return;
+  }
   if (!d->a_kmajor && !d->b_kmajor) { if (bm64) launch_bm<64, false, false>(g, g64, s); else launch_bm<128, false, false>(g, g128, s); }
   else if (!d->a_kmajor) { if (bm64) launch_bm<64, false, true>(g, g64, s); else launch_bm<128, false, true>(g, g128, s); }
   else { if (bm64 && d->lda >= 64) launch_bm<64, true, true>(g, g64, s); else launch_bm<128, true, true>(g, g128, s); }
