@@ -307,21 +307,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
         } else epi_store<EPI, 4>(g, row, col, a4);
       }
   } else {
-    static_assert(BN == 128 && NW == 4, "the staged epilogue is written for 128-column tiles and 256 threads");
+    static_assert(BN == 128, "the staged epilogue is written for 128-column tiles");
+    constexpr int RPP = NW * 4;                    // tile rows per pass: 16 threads per row
     float* ct = (float*)lds;
     __syncthreads();                               // every wave is done reading the last operand tile
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int rl = wm * TM + i * 16 + (lane & 15), c4 = wn * 16 + j * 4 + (lane >> 4);
+        const int rl = wm * TM + i * 16 + (lane & 15), c4 = wn * (TN / 4) + j * 4 + (lane >> 4);
         *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[i][j];
       }
     __syncthreads();
-    const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + 16 p
+    const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + RPP p
 #pragma unroll
-    for (int p = 0; p < BM / 16; ++p) {
-      const int rl = p * 16 + (t >> 4), row = m0 + rl;
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int rl = p * RPP + (t >> 4), row = m0 + rl;
       const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
       const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
       const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -482,11 +483,12 @@ int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes) {
 }
 
 // 256-square tiles (8 waves, one workgroup per CU, operands re-used twice as often per DMA piece and LDS read): when the
-// grid is 0.8 .. 1 tile per CU or at least 3 per CU, and the K-strided operand rows are wide enough for the tile.
+// reduction is long, the grid is 0.8 .. 1 tile per CU or at least 3 per CU, and the K-strided operand rows are wide enough.
 static bool use256(const hamt_gemm_desc* d, int force_bm) {
   if (d->b_kmajor && d->ldb < 256) return false;
   if (force_bm) return force_bm == 256;
-  const long t = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  if (d->K < 2048) return false;   // one workgroup per CU exposes the tile's prologue and store tail: long reductions only
+  const long t = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);   // (measured: 5120x3072x768 35.7 us with 128-row tiles, 40 with 256)
   return (t >= 208 && t <= 256) || t >= 768;
 }
 
