@@ -414,3 +414,54 @@ def test_overlapped_grad_sync_matches_single_process_steps(tiny):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_two_stream_cross_layers_match_single_stream():
+    """R2R-canon size, training mode, B=16: the vision side of the cross-modal layers on a second stream (streams.py)
+    gives the same losses and gradients as the single-stream order, run after run (a cross-stream race would show as a
+    run-to-run difference).  Dropout off: the call order, hence the per-call mask ids, differs between the two orders."""
+    from oracle.hamt_oracle import OracleConfig, make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd import ops, streams
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+    cfg = OracleConfig()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=11)
+    model = build(cfg, sd, "bf16", train=True)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    batches = {}
+    for task in ("sap", "mlm", "itm"):
+        b = make_batch(task, 16, cfg, seed=5 + len(task), txt_len=80, hist_len=5, ragged=True, device=DEV)
+        if task == "itm":
+            r = make_itm_rng(b, seed=9)
+            b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+        batches[task] = b
+
+    def run(two):
+        streams.set_two_stream(two)
+        out = {}
+        try:
+            for task, b in batches.items():
+                ops.manual_seed(77, torch.device(DEV))
+                model.zero_grad(set_to_none=True)
+                loss = model(b, task, True)
+                loss.mean().backward()
+                torch.cuda.synchronize()
+                gn = torch.stack([p.grad.double().norm() for p in model.parameters() if p.grad is not None])
+                out[task] = (loss.detach().double().cpu(), gn.cpu())
+        finally:
+            streams.set_two_stream(True)
+        return out
+
+    ref = run(False)
+    ref2 = run(False)     # run-to-run noise floor of the single-stream order (atomic adds in the embedding scatter)
+    for rep in range(3):
+        got = run(True)
+        for task in batches:
+            scale = float(ref[task][1].max())
+            dl = float((got[task][0] - ref[task][0]).abs().max())
+            dg = float((got[task][1] - ref[task][1]).abs().max()) / scale
+            floor = float((ref2[task][1] - ref[task][1]).abs().max()) / scale
+            print(f"[two-stream rep {rep} {task}] max loss diff {dl:.2e}, max grad-norm diff {dg:.2e} of the largest norm "
+                  f"(single-stream run-to-run: {floor:.2e})")
+            assert dl <= 1e-6 and dg <= max(1e-6, 10 * floor), (rep, task, dl, dg, floor)

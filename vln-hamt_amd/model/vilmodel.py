@@ -17,7 +17,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import blocks, ops
+from .. import blocks, ops, streams
 from ..modeling import HamtPreTrainedModel, precision_of
 
 BertLayerNorm = torch.nn.LayerNorm
@@ -322,9 +322,32 @@ class LXRTXLayer(nn.Module):
         return _ffn(self.lang_inter, self.lang_output, lang_input, self.training), _ffn(self.visn_inter, self.visn_output, visn_input, self.training)
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
+        if lang_feats.is_cuda and streams.two_stream_enabled():
+            return self._forward_two_streams(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         lang, visn = self.cross_att(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         lang, visn = self.self_att(lang, lang_attention_mask, visn, visn_attention_mask)
         return self.output_fc(lang[0], visn[0])
+
+    def _forward_two_streams(self, lang_feats, lang_mask, visn_feats, visn_mask):
+        """Same computation with the vision-side chain (cross <- lang, self, FFN) on a second stream: after the shared
+        cross-attention both sides are independent until the next layer, and the vision side is a chain of tiny kernels
+        (6 history tokens per sample when there is no observation) that would otherwise leave the chip mostly idle.
+        autograd replays each backward node on its forward stream, so backward overlaps the same way."""
+        main = torch.cuda.current_stream()
+        side = streams.side_stream(lang_feats.device)
+        side.wait_stream(main)
+        for t in (lang_feats, visn_feats, lang_mask, visn_mask):
+            streams.share(t, side)                      # inputs produced on `main`, read by the vision-side kernels
+        with torch.cuda.stream(side):
+            visn = self.visual_attention(visn_feats, lang_feats, ctx_att_mask=lang_mask)
+            visn = self.visn_self_att(visn[0] if isinstance(visn, tuple) else visn, visn_mask)
+            visn_out = _ffn(self.visn_inter, self.visn_output, visn[0], self.training)
+        lang = self.visual_attention(lang_feats, visn_feats, ctx_att_mask=visn_mask)
+        lang = self.lang_self_att(lang[0] if isinstance(lang, tuple) else lang, lang_mask)
+        lang_out = _ffn(self.lang_inter, self.lang_output, lang[0], self.training)
+        main.wait_stream(side)
+        streams.share(visn_out, main)                   # produced on `side`, consumed on `main` from here on
+        return lang_out, visn_out
 
 
 class LxmertEncoder(nn.Module):

@@ -1,0 +1,49 @@
+"""Second compute stream for independent sub-graphs of the model (the vision side of the cross-modal layers).
+
+Rules kept by the callers (model/vilmodel.py): every side region starts with ``side.wait_stream(main)`` and ends with
+``main.wait_stream(side)``; every tensor that crosses is registered with ``share`` (``record_stream`` on it and on its
+bf16 image), so the caching allocator never hands its memory to the other stream's later allocations while kernels of
+this stream may still read it.  The deferred weight-gradient launch (wgrad.py) joins the side streams before it reads
+operands their backward kernels produced.  HAMT_NO_XSTREAM=1 disables the second stream (ablation / debugging)."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+_ENABLED = [os.environ.get("HAMT_NO_XSTREAM") is None]
+_side: dict = {}
+
+
+def two_stream_enabled() -> bool:
+    return _ENABLED[0]
+
+
+def set_two_stream(flag: bool):
+    _ENABLED[0] = bool(flag)
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    s = _side.get(key)
+    if s is None:
+        s = _side[key] = torch.cuda.Stream(device=key)
+    return s
+
+
+def share(t, stream):
+    """`t` (and its bf16 image, if it carries one) will be read by kernels on `stream`."""
+    if t is None or not torch.is_tensor(t) or not t.is_cuda:
+        return
+    t.record_stream(stream)
+    img = getattr(t, "_hamt_bf16", None)
+    if img is not None and torch.is_tensor(img[0]):
+        img[0].record_stream(stream)
+
+
+def join_all():
+    """Make the current stream wait for everything enqueued on the side streams (cheap when they are idle)."""
+    cur = torch.cuda.current_stream()
+    for s in _side.values():
+        if s.device == cur.device:
+            cur.wait_stream(s)

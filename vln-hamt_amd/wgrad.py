@@ -118,6 +118,8 @@ def flush():
     _scheduled[0] = False
     if not items:
         return
+    from . import streams
+    streams.join_all()                # operands queued by backward nodes that ran on the second compute stream
     if _handler[0] is not None:
         stats["flushes"] += 1
         stats["problems"] += len(items)
