@@ -47,13 +47,14 @@ constexpr int BN = 128, BK = 64;
 
 __device__ __forceinline__ void glds16(const bf16_t* src, unsigned dst_uniform) {
   // Issued through inline asm on purpose: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the first ds_read
-  // that follows a __builtin_amdgcn_global_load_lds it can see, which drains the prefetch of tile kt+2 before tile kt
-  // is multiplied.  The DMA is ordered by the counted vmcnt + s_barrier in the main loop instead.
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(dst_uniform) : "memory");
+  // that follows a __builtin_amdgcn_global_load_lds it can see, which drains the prefetch of tile kt+1 before tile kt
+  // is multiplied.  The DMA is ordered by the explicit vmcnt + s_barrier in the main loop instead.  M0 (the LDS
+  // destination) is declared clobbered rather than saved/restored: 3 instructions per piece instead of 5.
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst_uniform) : "memory", "m0");
 }
-__device__ __forceinline__ unsigned lds_addr(const bf16_t* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)p); }
+// LDS byte address of a __shared__ object as a plain integer (taken ONCE: every use of the pointer cast costs a null
+// check, s_cmp + s_cselect, per DMA piece otherwise); piece destinations are integer offsets from it.
+__device__ __forceinline__ unsigned lds_base_of(const bf16_t* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)p); }
 
 // XOR applied to the 16-byte chunk index of a k-strided ("col") tile row kk: keeps 32-byte pairs together (a tr-read
 // quad reads 32 contiguous bytes) and sends the 4 rows of a tr-read (and, for 256-byte rows, the sibling 16-lane
@@ -67,8 +68,8 @@ template <int R> __device__ __forceinline__ int col_swz(int kk) {
 //   KM == true : operand stored [K][cols] (K strided):    tile image [64][R], 1 KiB = 1024/(2R) k-rows per instruction
 // Out-of-range rows are clamped (re-read a valid row); see the callers for why that is harmless.
 template <bool KM, int R, int NW = 4>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, int kmax, bf16_t* lds,
-                                           int w, int lane) {
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, int kmax, unsigned lds_bytes,
+                                           int w, int lane) {   // lds_bytes: LDS byte address of the tile image (wave-uniform)
   if constexpr (!KM) {
     constexpr int PER_WAVE = R / NW;             // tile rows per wave
 #pragma unroll
@@ -78,7 +79,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld,
       const int chunk = (lane & 7) ^ (r & 7);    // source k-chunk that lands in LDS slot (lane & 7)
       int gr = r0 + r;
       gr = gr < rmax ? gr : rmax;
-      glds16(P + (size_t)gr * ld + k0 + chunk * 8, lds_addr(lds + rbase * BK));
+      glds16(P + (size_t)gr * ld + k0 + chunk * 8, lds_bytes + (unsigned)(rbase * BK * 2));
     }
   } else {
     constexpr int CH = R / 8;                    // 16-byte chunks per k-row (32, 16 or 8)
@@ -93,7 +94,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld,
       gk = gk < kmax ? gk : kmax;
       int c = r0 + chunk * 8;
       c = c < ld - 8 ? c : ld - 8;               // stay inside the row's allocation; masked at the store
-      glds16(P + (size_t)gk * ld + c, lds_addr(lds + kbase * R));
+      glds16(P + (size_t)gk * ld + c, lds_bytes + (unsigned)(kbase * R * 2));
     }
   }
 }
@@ -229,10 +230,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const unsigned lds0 = lds_base_of(lds);
   auto stage = [&](int kt, int slot) {
-    bf16_t* dst = lds + slot * STAGE;
+    const unsigned dst = lds0 + (unsigned)(slot * STAGE * 2);
     stage_tile<A_KM, BM, NW>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, g.ka_max, dst, w, lane);
-    stage_tile<B_KM, BN, NW>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + A_ELEMS, w, lane);
+    stage_tile<B_KM, BN, NW>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + (unsigned)(A_ELEMS * 2), w, lane);
   };
   if constexpr (NSTAGE > 1) {
 #pragma unroll
