@@ -366,10 +366,15 @@ class LxmertEncoder(nn.Module):
         self.r_layers = nn.ModuleList([BertLayer(config) for _ in range(self.num_r_layers)]) if self.num_r_layers > 0 else None
         self.x_layers = nn.ModuleList([LXRTXLayer(config) for _ in range(self.num_x_layers)])
 
-    def forward(self, txt_embeds, extended_txt_masks, hist_embeds, extended_hist_masks,
-                img_embeds=None, extended_img_masks=None):
+    def text_layers(self, txt_embeds, extended_txt_masks):
         for layer in self.layer:
             txt_embeds = layer(txt_embeds, extended_txt_masks)[0]
+        return txt_embeds
+
+    def forward(self, txt_embeds, extended_txt_masks, hist_embeds, extended_hist_masks,
+                img_embeds=None, extended_img_masks=None, text_done=False):
+        if not text_done:       # (the caller may have run them already, next to the vision-side embedders)
+            txt_embeds = self.text_layers(txt_embeds, extended_txt_masks)
         if not self.update_lang_bert:
             txt_embeds = txt_embeds.detach()
         if img_embeds is not None and self.r_layers is not None:
@@ -524,21 +529,40 @@ class NavPreTrainedModel(BertPreTrainedModel):
                 hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks):
         B = txt_ids.size(0)
         txt_m = self._extend(txt_masks)
-        txt = self.embeddings(txt_ids)
         hist_m = self._extend(hist_masks)
-        step_ids = None
-        if hist_img_feats is not None:
-            step_ids = torch.arange(hist_img_feats.size(1), device=txt_ids.device)[None]
-        cls, steps = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
-                                          step_ids, batch_size=B)
-        hist = cls if steps is None else torch.cat([cls, steps], 1)
-        if ob_img_feats is not None:
-            ones = torch.ones(B, dtype=torch.long, device=txt_ids.device)
-            tt = ops.gather_rows(self.embeddings.token_type_embeddings.weight, ones).view(B, 1, -1)
-            ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)
-            ob_m = self._extend(ob_masks)
-        else:
-            ob, ob_m = None, None
+        ob_m = self._extend(ob_masks) if ob_img_feats is not None else None
+
+        def vision_side():
+            step_ids = None
+            if hist_img_feats is not None:
+                step_ids = torch.arange(hist_img_feats.size(1), device=txt_ids.device)[None]
+            cls, steps = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
+                                              step_ids, batch_size=B)
+            hist = cls if steps is None else torch.cat([cls, steps], 1)
+            ob = None
+            if ob_img_feats is not None:
+                ones = torch.ones(B, dtype=torch.long, device=txt_ids.device)
+                tt = ops.gather_rows(self.embeddings.token_type_embeddings.weight, ones).view(B, 1, -1)
+                ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)
+            return hist, ob
+
+        if txt_ids.is_cuda and streams.two_stream_enabled():
+            # history / observation embedders (incl. the panorama encoder) on the second stream, next to the text embedder
+            # and the text-only layers: the two chains do not meet before the first cross-modal layer
+            main = torch.cuda.current_stream()
+            side = streams.side_stream(txt_ids.device)
+            side.wait_stream(main)
+            for t in (hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, ob_img_feats, ob_ang_feats, ob_nav_types):
+                streams.share(t, side)
+            with torch.cuda.stream(side):
+                hist, ob = vision_side()
+            txt = self.encoder.text_layers(self.embeddings(txt_ids), txt_m)
+            main.wait_stream(side)
+            streams.share(hist, main)
+            streams.share(ob, main)
+            return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True)
+        txt = self.embeddings(txt_ids)
+        hist, ob = vision_side()
         return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m)
 
     def forward_itm(self, txt_ids, txt_masks, hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
@@ -547,49 +571,66 @@ class NavPreTrainedModel(BertPreTrainedModel):
         when None they are drawn like the reference does (np.random.choice :684, torch.randperm :698)."""
         B, T = hist_img_feats.shape[:2]
         dev = txt_ids.device
-        txt_m = self._extend(txt_masks)
-        txt = self.embeddings(txt_ids)
-        for layer in self.encoder.layer:
-            txt = layer(txt, txt_m)[0]
         n_rep = 1 + num_neg_trajs
-        L, H = txt.shape[1:]
-        rep = torch.arange(B, device=dev).repeat(n_rep)
-        txt = ops.gather_rows(txt.reshape(B, L * H), rep).view(n_rep * B, L, H)
-        txt_m = txt_m.repeat(n_rep, 1, 1, 1)
-
+        txt_m1 = self._extend(txt_masks)
         hist_m = self._extend(hist_masks)
-        cls, nopos = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
-                                          pos_ids=None, batch_size=B)
-        hist = torch.cat([cls, self.hist_embeddings.add_position(nopos, torch.arange(T, device=dev)[None])], 1)
-        if self.encoder.h_layers is not None:
-            for layer in self.encoder.h_layers:
-                hist = layer(hist, hist_m)[0]
-        neg_h, neg_m = [], []
-        K = num_neg_trajs // 2
-        if B > 1:
-            if neg_idxs is None:
-                neg_idxs = torch.from_numpy(np.stack(
-                    [np.random.choice([j for j in range(B) if j != i], K) for i in range(B)], 0)).to(dev)
-            for k in range(K):
-                neg_h.append(ops.gather_rows(hist.reshape(B, -1), neg_idxs[:, k]).view(hist.shape))
-                neg_m.append(hist_m[neg_idxs[:, k]])
-        else:
-            K = num_neg_trajs
-        if shuffled_pos_ids is None:
-            lens = (hist_masks.sum(1) - 1).tolist()
-            shuffled_pos_ids = []
-            for _ in range(K):
-                rows = [torch.cat([torch.randperm(n), torch.arange(n, T, dtype=torch.long)], 0) for n in lens]
-                shuffled_pos_ids.append(torch.stack(rows, 0).to(dev))
-        for pos in shuffled_pos_ids:
-            sh = torch.cat([cls, self.hist_embeddings.add_position(nopos, pos)], 1)
+
+        def text_side():
+            txt = self.encoder.text_layers(self.embeddings(txt_ids), txt_m1)
+            L, H = txt.shape[1:]
+            rep = torch.arange(B, device=dev).repeat(n_rep)
+            return ops.gather_rows(txt.reshape(B, L * H), rep).view(n_rep * B, L, H), txt_m1.repeat(n_rep, 1, 1, 1)
+
+        def vision_side(neg_idxs, shuffled_pos_ids):
+            cls, nopos = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
+                                              pos_ids=None, batch_size=B)
+            hist = torch.cat([cls, self.hist_embeddings.add_position(nopos, torch.arange(T, device=dev)[None])], 1)
             if self.encoder.h_layers is not None:
                 for layer in self.encoder.h_layers:
-                    sh = layer(sh, hist_m)[0]
-            neg_h.append(sh)
-            neg_m.append(hist_m)
-        vis = torch.cat([hist] + neg_h, 0)
-        vis_m = torch.cat([hist_m] + neg_m, 0)
+                    hist = layer(hist, hist_m)[0]
+            neg_h, neg_m = [], []
+            K = num_neg_trajs // 2
+            if B > 1:
+                if neg_idxs is None:
+                    neg_idxs = torch.from_numpy(np.stack(
+                        [np.random.choice([j for j in range(B) if j != i], K) for i in range(B)], 0)).to(dev)
+                for k in range(K):
+                    neg_h.append(ops.gather_rows(hist.reshape(B, -1), neg_idxs[:, k]).view(hist.shape))
+                    neg_m.append(hist_m[neg_idxs[:, k]])
+            else:
+                K = num_neg_trajs
+            if shuffled_pos_ids is None:
+                lens = (hist_masks.sum(1) - 1).tolist()
+                shuffled_pos_ids = []
+                for _ in range(K):
+                    rows = [torch.cat([torch.randperm(n), torch.arange(n, T, dtype=torch.long)], 0) for n in lens]
+                    shuffled_pos_ids.append(torch.stack(rows, 0).to(dev))
+            for pos in shuffled_pos_ids:
+                sh = torch.cat([cls, self.hist_embeddings.add_position(nopos, pos)], 1)
+                if self.encoder.h_layers is not None:
+                    for layer in self.encoder.h_layers:
+                        sh = layer(sh, hist_m)[0]
+                neg_h.append(sh)
+                neg_m.append(hist_m)
+            return torch.cat([hist] + neg_h, 0), torch.cat([hist_m] + neg_m, 0)
+
+        if txt_ids.is_cuda and streams.two_stream_enabled():     # history side next to the text side, as in forward()
+            main = torch.cuda.current_stream()
+            side = streams.side_stream(dev)
+            side.wait_stream(main)
+            for t in (hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, hist_m, neg_idxs,
+                      *(shuffled_pos_ids or [])):
+                streams.share(t, side)
+            with torch.cuda.stream(side):
+                vis, vis_m = vision_side(neg_idxs, shuffled_pos_ids)
+            txt, txt_m = text_side()
+            main.wait_stream(side)
+            streams.share(vis, main)
+            streams.share(vis_m, main)
+        else:
+            txt, txt_m = text_side()
+            vis, vis_m = vision_side(neg_idxs, shuffled_pos_ids)
+        H = txt.shape[-1]
         for layer in self.encoder.x_layers:
             txt, vis = layer(txt, txt_m, vis, vis_m)
         fused = ops.mul_bcast(txt[:, :1].contiguous(), vis[:, 0])        # txt[:,0] * hist[:,0]
