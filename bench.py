@@ -105,7 +105,7 @@ def time_wgrad_roofline(model, cfg, batch, device, iters=10):
         wgrad.set_handler(prev)
     for p_ in model.parameters():
         p_.grad = None
-    items = [it for it in items if it[2].stride(0) >= 256 and it[3].stride(0) >= 256 and it[2].shape[0] >= 2048]   # the 256-square-tile launch class
+    items = [it for it in items if it[2].stride(0) >= 256 and it[3].stride(0) >= 256]   # the 256-square-tile launch class
     n = len(items)
     descs = (Lb.WgradDesc * n)()
     keep, flops = [], 0.0
@@ -118,7 +118,7 @@ def time_wgrad_roofline(model, cfg, batch, device, iters=10):
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
         flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
     lib = Lb.load()
-    tab = torch.empty(n * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
+    tab = torch.empty(wgrad.table_entries(descs, n) * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
     run = lambda: Lb.check(lib.hamt_wgrad_grouped(n, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     for _ in range(2):
         run()

@@ -111,8 +111,8 @@ typedef struct {
   int M, N, K, ldy, ldx, ldw;
   int accum_dw, accum_db; /* 0: store, 1: += */
 } hamt_wgrad_desc;
-/* `table`: caller-provided DEVICE scratch of >= n * HAMT_WGRAD_TABLE_ENTRY bytes (16-byte aligned) that holds the launch
- * table; it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can
+/* `table`: caller-provided DEVICE scratch (16-byte aligned) that holds the launch table: HAMT_WGRAD_TABLE_ENTRY bytes per
+ * entry, at most sum over the problems of ceil(M_p / 64) entries (large problems are cut into bands of tile rows); it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can
  * be captured in a hipGraph.  The table must stay untouched until the launches have run. */
 #define HAMT_WGRAD_TABLE_ENTRY 64
 int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream);

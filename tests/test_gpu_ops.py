@@ -193,7 +193,7 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
         rb = (dy.double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
         refs.append((dw, db, rw, rb))
-    tab = torch.empty(len(specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
+    tab = torch.empty(sum((sp[1] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
     L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     torch.cuda.synchronize()
     for i, (dw, db, rw, rb) in enumerate(refs):

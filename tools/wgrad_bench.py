@@ -18,7 +18,7 @@ def bench(specs, with_db=True, iters=20):
         d = descs[i]
         d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if with_db else None)
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = M, N, K, M, N, N, 0, 0
-    tab = torch.empty(len(probs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device="cuda")
+    tab = torch.empty(sum((pr[4] + 63) // 64 for pr in probs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device="cuda")
     fn = lambda: L.check(lib.hamt_wgrad_grouped(len(probs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "wgrad")
     for _ in range(3): fn()
     torch.cuda.synchronize()

@@ -371,20 +371,25 @@ __global__ void wgrad_table_write_kernel(WgradChunk c, WgradProb* tab, int off, 
   if ((int)threadIdx.x < cnt) tab[off + threadIdx.x] = c.p[threadIdx.x];
 }
 
+struct WgradXcd { int start[9]; };               // table entries [start[x], start[x+1]) belong to XCD x
+
+// Placement: blocks are dealt round-robin to the 8 XCDs (XCD = blockIdx & 7), each with its own 4 MiB L2.  Every table
+// entry (a problem, or a band of tile rows of a large one) is processed ENTIRELY by one XCD, so the operand panels its
+// tiles share (3 + 3 panels of 2.6 MB for a 768x768x5120 problem with 256-square tiles) cross the fabric once instead of
+// once per tile: measured 8.4 GB -> see profiles/ of HBM/MALL fetch per launch, the kernel was fabric-bound.  The host
+// balances the XCDs (longest-processing-time first) and orders each XCD's entries by K, longest first.
 template <int BM, int BNT, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const WgradProb* __restrict__ tab, int n, int ntiles) {
-  const int bid = blockIdx.x;                    // problems in launch order (longest K first) ...
-  int lo = 0, hi = n - 1;                        // first problem whose tile_end > bid (wave-uniform binary search)
-  while (lo < hi) {
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const WgradProb* __restrict__ tab, WgradXcd xs) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  int lo = xs.start[xcd], hi = xs.start[xcd + 1] - 1;
+  if (hi < lo || idx >= tab[hi].tile_end) return;   // this XCD has fewer tiles than the longest queue
+  const int first = lo;
+  while (lo < hi) {                              // first entry whose tile_end > idx (wave-uniform binary search)
     const int mid = (lo + hi) >> 1;
-    if (bid >= tab[mid].tile_end) lo = mid + 1; else hi = mid;
+    if (idx >= tab[mid].tile_end) lo = mid + 1; else hi = mid;
   }
   const WgradProb q = tab[lo];
-  const int start = lo ? tab[lo - 1].tile_end : 0;
-  // ... and the XCD remap PER PROBLEM (blocks with equal (bid - start) & 7 sit on one XCD): each XCD gets a contiguous run
-  // of every problem's tiles.  Remapping the concatenated tile space instead would hand XCD 0 only the longest
-  // reductions and XCD 7 only the shortest.
-  const int local = xcd_remap(bid - start, q.tile_end - start);
+  const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + BNT - 1) / BNT;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
               q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1};
@@ -546,20 +551,18 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
   }
   if (order.empty()) return HAMT_OK;
-  HAMT_CHECK_ARG(table && table_bytes >= order.size() * sizeof(WgradProb) && (uintptr_t)table % 16 == 0,
-                 "hamt_wgrad_grouped: table must be 16-byte aligned device memory of >= %zu bytes", order.size() * sizeof(WgradProb));
+  HAMT_CHECK_ARG(table && (uintptr_t)table % 16 == 0, "hamt_wgrad_grouped: table must be 16-byte aligned device memory");
   hipStream_t s = as_stream(stream);
   // Two launch classes: problems whose operand rows are >= 256 elements wide can use 256-square tiles; the rest 128 / 64
   // rows.  Within a class: longest reductions first, the short tail tiles fill in behind them.
   std::vector<int> cls[2];
-  // (a 256-square tile runs alone on its CU, so its prologue and store tail are exposed: only worth it for long reductions)
-  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && probs[i].K >= 2048) ? 0 : 1].push_back(i);
+  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256) ? 0 : 1].push_back(i);
   const char* fenv = getenv("HAMT_WGRAD_TILE");   // test / tuning override: 256, 128 or 64 (read per call)
   const int force = fenv ? atoi(fenv) : 0;
   {
     long t256 = 0;
     for (int i : cls[0]) t256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
-    if (force == 128 || force == 64 || (t256 < 768 && force != 256)) { cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
+    if (force == 128 || force == 64 || (t256 < 128 && force != 256)) {   // too few 256-square tiles to occupy half the chip cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
   }
   WgradProb* tab = (WgradProb*)table;
   int off = 0;
@@ -576,22 +579,60 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     int bm = c == 0 ? 256 : (t128 >= 1024 ? 128 : 64);
     if (force == 128 || force == 64) bm = force;
     const int bn = bm == 256 ? 256 : 128;
-    int tiles = 0;
-    const int cn = (int)v.size();
+    // units: a problem, or bands of tile rows of a problem with many tiles (so that one XCD's share stays ~<= 12 tiles)
+    struct Unit { int prob, m_lo, m_rows, tiles; double cost; };
+    std::vector<Unit> units;
+    for (int i : v) {
+      const hamt_wgrad_desc& d = probs[i];
+      const int tm = (d.M + bm - 1) / bm, tn = (d.N + bn - 1) / bn;
+      const int band = tn >= 12 ? 1 : 12 / tn;   // tile rows per unit
+      for (int r = 0; r < tm; r += band) {
+        const int rows = std::min(band * bm, d.M - r * bm);
+        const int t = ((rows + bm - 1) / bm) * tn;
+        units.push_back(Unit{i, r * bm, rows, t, (double)t * d.K});
+      }
+    }
+    std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
+    std::vector<int> xq[8];
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < (int)units.size(); ++u) {           // longest processing time first onto the least loaded XCD
+      int best = 0;
+      for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      xq[best].push_back(u);
+      load[best] += units[u].cost;
+    }
+    const int cn = (int)units.size();
+    HAMT_CHECK_ARG((size_t)(off + cn) * sizeof(WgradProb) <= table_bytes, "hamt_wgrad_grouped: table too small (%zu bytes needed)",
+                   (size_t)(off + cn) * sizeof(WgradProb));
+    WgradXcd xs;
+    std::vector<WgradProb> flat;
+    flat.reserve(cn);
+    int max_tiles = 0;
+    for (int x = 0; x < 8; ++x) {
+      xs.start[x] = (int)flat.size();
+      std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return probs[units[a].prob].K > probs[units[b].prob].K; });
+      int tiles = 0;
+      for (int u : xq[x]) {
+        const Unit& un = units[u];
+        const hamt_wgrad_desc& d = probs[un.prob];
+        tiles += un.tiles;
+        flat.push_back(WgradProb{(const bf16_t*)d.dy + un.m_lo, (const bf16_t*)d.x, d.dw + (size_t)un.m_lo * d.ldw,
+                                 d.db ? d.db + un.m_lo : nullptr, un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
+                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles});
+      }
+      max_tiles = std::max(max_tiles, tiles);
+    }
+    xs.start[8] = (int)flat.size();
     for (int b0 = 0; b0 < cn; b0 += WG_MAX) {
       WgradChunk ch;
       const int cnt = std::min(WG_MAX, cn - b0);
-      for (int i = 0; i < cnt; ++i) {
-        const hamt_wgrad_desc& d = probs[v[b0 + i]];
-        tiles += ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
-        ch.p[i] = WgradProb{(const bf16_t*)d.dy, (const bf16_t*)d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy, d.ldx, d.ldw,
-                            (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles};
-      }
+      for (int i = 0; i < cnt; ++i) ch.p[i] = flat[b0 + i];
       hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, off + b0, cnt);
     }
-    if (bm == 256) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 256, 2, 4>), dim3(tiles), dim3(512), 0, s, tab + off, cn, tiles);
-    else if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0, s, tab + off, cn, tiles);
-    else hipLaunchKernelGGL((wgrad_grouped_kernel<64, 128, 2, 2>), dim3(tiles), dim3(256), 0, s, tab + off, cn, tiles);
+    const dim3 grid(8 * max_tiles);
+    if (bm == 256) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, tab + off, xs);
+    else if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, tab + off, xs);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<64, 128, 2, 2>), grid, dim3(256), 0, s, tab + off, xs);
     HAMT_CHECK_LAUNCH("hamt_wgrad_grouped");
     off += cn;
   }

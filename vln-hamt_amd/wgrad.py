@@ -69,6 +69,11 @@ def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: t
         torch.autograd.Variable._execution_engine.queue_callback(flush)
 
 
+def table_entries(descs, n: int) -> int:
+    """upper bound on the launch-table entries of hamt_wgrad_grouped for these problems (include/hamt.h)"""
+    return sum((descs[i].M + 63) // 64 for i in range(n))
+
+
 def launch(descs, n: int, table: Optional[torch.Tensor] = None):
     """hamt_wgrad_grouped on the current stream; `table` = device scratch for the launch table (allocated here when
     None: from the caching allocator, i.e. from the graph's private pool during a capture)."""
@@ -76,7 +81,7 @@ def launch(descs, n: int, table: Optional[torch.Tensor] = None):
     if n == 0:
         return
     if table is None:
-        table = torch.empty(n * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device="cuda")
+        table = torch.empty(table_entries(descs, n) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device="cuda")
     L.check(L.load().hamt_wgrad_grouped(n, descs, table.data_ptr(), table.numel(), _stream()), "hamt_wgrad_grouped")
 
 
@@ -238,7 +243,7 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), w.shape[1]
             d.accum_dw, d.accum_db = aw, ab
         plan.groups.append((descs, len(grp)))
-        plan.tables.append(torch.empty(max(1, len(grp)) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=flat_g.device))
+        plan.tables.append(torch.empty(max(1, table_entries(descs, len(grp))) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=flat_g.device))
     # arena ranges and the launch group after which each is final
     lows = [min(t[0] for t in grp) for grp in per_group if grp]
     bounds = [0] + lows[1:] + [n_total]
