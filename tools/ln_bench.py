@@ -8,10 +8,14 @@ from vln_hamt_amd import ops
 def t(fn, iters=30):
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(); st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters): fn()
+    torch.cuda.synchronize(); g.replay(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters): fn()
-    e.record(); torch.cuda.synchronize()
+    s.record(); g.replay(); e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 
 for M in (5120, 11520, 2368, 384):
