@@ -562,7 +562,8 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   {
     long t256 = 0;
     for (int i : cls[0]) t256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
-    if (force == 128 || force == 64 || (t256 < 128 && force != 256)) {   // too few 256-square tiles to occupy half the chip cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
+    // too few 256-square tiles to occupy half the chip: use the smaller tiles for everything
+    if (force == 128 || force == 64 || (t256 < 128 && force != 256)) { cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
   }
   WgradProb* tab = (WgradProb*)table;
   int off = 0;
