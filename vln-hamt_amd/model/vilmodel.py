@@ -335,6 +335,11 @@ class LXRTXLayer(nn.Module):
         autograd replays each backward node on its forward stream, so backward overlaps the same way."""
         main = torch.cuda.current_stream()
         side = streams.side_stream(lang_feats.device)
+        # the shared cross-attention is applied on BOTH streams: build its lazily cached bf16 weight images (only used when
+        # the optimizer's bf16 arena is not there) on `main` before the fork, not concurrently on whichever stream is first
+        xa = self.visual_attention
+        for lin in (xa.att.query, xa.att.key, xa.att.value, xa.output.dense):
+            ops.weight_operand(lin.weight, xa.att.prec)
         side.wait_stream(main)
         for t in (lang_feats, visn_feats, lang_mask, visn_mask):
             streams.share(t, side)                      # inputs produced on `main`, read by the vision-side kernels
