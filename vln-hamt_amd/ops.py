@@ -160,11 +160,12 @@ def weight_operand(w: torch.Tensor, prec: str) -> torch.Tensor:
     c = getattr(w, "_hamt_w16", None)
     key = (w._version, _cache_epoch[0])
     if c is None or c[0] != key or c[1] != w.data_ptr():
-        c = (key, w.data_ptr(), cast_bf16(wd))
+        c = (key, w.data_ptr(), cast_bf16(wd)) + _cache_stamp(w)
         try:
             w._hamt_w16 = c
         except Exception:
             pass
+    _cache_sync(c)
     return c[2]
 
 
@@ -202,6 +203,24 @@ def cast_t16(x2: torch.Tensor, rpad: Optional[int] = None) -> torch.Tensor:
 _cache_epoch = [0]
 
 
+def _cache_stamp(w):
+    """(event, stream handle) of the stream that just built a lazily cached weight image: another stream (the model runs
+    independent branches on two, streams.py) waits for the event before its first read."""
+    if not w.is_cuda:
+        return (None, None)
+    st = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return (ev, st.cuda_stream)
+
+
+def _cache_sync(c):
+    if c[3] is not None:
+        st = torch.cuda.current_stream()
+        if st.cuda_stream != c[4]:
+            st.wait_event(c[3])
+
+
 def invalidate_weight_caches():
     """Force every lazily cached weight shadow to be rebuilt at its next use (call right before capturing a graph so
     that the rebuild kernels are part of the captured step)."""
@@ -213,11 +232,12 @@ def weight_t16(w: torch.Tensor) -> torch.Tensor:
     c = getattr(w, "_hamt_wt16", None)
     key = (w._version, _cache_epoch[0])
     if c is None or c[0] != key or c[1] != w.data_ptr():
-        c = (key, w.data_ptr(), cast_t16(w.detach()))
+        c = (key, w.data_ptr(), cast_t16(w.detach())) + _cache_stamp(w)
         try:
             w._hamt_wt16 = c
         except Exception:
             pass
+    _cache_sync(c)
     return c[2]
 
 
