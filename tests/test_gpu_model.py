@@ -3,6 +3,7 @@
 Tolerances (north_star): activations/logits/losses <= 1e-3 in fp32 mode, <= 1e-2 in bf16 mode (max-abs,
 relative to max(1, |ref|_max)); integer/index work (compaction order, -inf positions) bit exact.
 """
+import math
 import os
 
 import numpy as np
@@ -469,3 +470,72 @@ def test_two_stream_cross_layers_match_single_stream():
             print(f"[two-stream rep {rep} {task}] max loss diff {dl:.2e}, max grad-norm diff {dg:.2e} of the largest norm "
                   f"(single-stream run-to-run: {floor:.2e})")
             assert dl <= 1e-6 and dg <= max(1e-6, 10 * floor), (rep, task, dl, dg, floor)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("no_lang_ca", [False, True])
+def test_finetune_rollout_backward_vs_oracle(prec, no_lang_ca):
+    """Finetune twin, training direction (next row N2): a 3-step rollout -- language once, then history / visual per
+    step with the growing history -- with an imitation loss on every step's action logits (agent_cmt.py:476-518 order),
+    ONE backward over the whole rollout; parameter gradients against the oracle's autograd on the same inputs."""
+    from oracle.hamt_oracle import HamtOracle, make_state_dict, navcmt_param_shapes
+    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+    from vln_hamt_amd.modeling import HamtConfig
+    store = load_npz("tiny_finetune.npz")
+    tag = "nolangca" if no_lang_ca else "ca"
+    extra = dict(no_lang_ca=True, act_pred_token="ob") if no_lang_ca else dict(no_lang_ca=False, act_pred_token="ob_txt")
+    ocfg = tiny_cfg(**extra)
+    for k in ("hidden_dropout_prob", "attention_probs_dropout_prob", "pred_head_dropout_prob"):
+        setattr(ocfg, k, 0.0)
+    sd = make_state_dict(navcmt_param_shapes(ocfg), seed=9)
+    kw = dict(vars(ocfg))
+    kw.pop("pretrain_tasks")
+    model = NavCMT(HamtConfig(hamt_precision=prec, **kw))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    bc = {k: torch.from_numpy(v) for k, v in sub(store, f"{tag}/in/").items()}
+    B = bc["txt_ids"].shape[0]
+    target = (bc["ob_nav_types"] != 0).int().argmax(1)          # a navigable view (the others have logit -inf)
+
+    def rollout(fwd, b, dev, ce):
+        lang = fwd("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+        hs = [fwd("history").expand(B, -1)]
+        loss = 0.0
+        for t in range(3):
+            hist = torch.stack(hs, 1)
+            out = fwd("visual", txt_embeds=lang, hist_embeds=hist, txt_masks=b["txt_masks"], hist_masks=b["hist_masks"][:, :t + 1].contiguous(),
+                      ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+            loss = loss + ce(out[0], target.to(dev)).mean()
+            hs.append(fwd("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
+                          ob_step_ids=torch.tensor([t], device=dev), hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
+                          hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
+        return loss
+
+    from vln_hamt_amd import ops
+    loss = rollout(model, to_dev(bc), DEV, ops.cross_entropy)
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle (CPU, fp32 autograd)
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    orc = HamtOracle(osd, ocfg, training=True)      # (every dropout probability is 0)
+    oloss = rollout(lambda mode, **k: orc.ft_forward(mode, **k), bc, "cpu",
+                    lambda x, y: torch.nn.functional.cross_entropy(x, y, reduction="none"))
+    oloss.backward()
+    assert rel_err(loss.detach(), oloss.detach()) <= TOL[prec]
+    ref = {k: v.grad for k, v in osd.items() if v.grad is not None}
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    gmax = max(float(v.norm()) for v in ref.values())
+    num = den = dot = 0.0
+    worst = 0.0
+    for k, r in ref.items():
+        if float(r.norm()) == 0.0 and k not in got:
+            continue
+        g = got[k].detach().cpu().double()
+        r = r.double()
+        worst = max(worst, abs(float(g.norm()) - float(r.norm())) / max(float(r.norm()), 5e-2 * gmax))
+        dot += float((g * r).sum()); num += float((g * g).sum()); den += float((r * r).sum())
+    cos = dot / math.sqrt(num * den)
+    print(f"[finetune rollout bwd {tag} {prec}] loss {float(loss):.5f} vs {float(oloss):.5f}; global grad cosine {cos:.6f}; "
+          f"worst per-parameter norm error {worst:.2e}")
+    assert cos >= (0.99999 if prec == "fp32" else 0.995), cos
+    assert worst <= (2e-3 if prec == "fp32" else 6e-2), worst

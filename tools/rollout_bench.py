@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 shape (RxR long-horizon rollout): NavCMT `language` once, then per step `history` (one panorama)
++ `visual` (text x {history so far, 37 observation tokens}), B=8, L=160, up to 20 history steps, image_feat 512,
+`no_lang_ca`.  Forward latency per rollout step (eager launches, bf16 path), and with grad (IL loss on the action logits
+of every step + one backward over the whole rollout).  A measurement of the 'next' row N2, not the headline bench."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vln_hamt_amd.modeling import HamtConfig
+from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+from vln_hamt_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8); ap.add_argument("--txt", type=int, default=160)
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--feat", type=int, default=512)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda")
+cfg = HamtConfig(hamt_precision="bf16", image_feat_size=a.feat, hist_enc_pano=True, num_h_pano_layers=2, no_lang_ca=True,
+                 act_pred_token="ob_txt", fix_lang_embedding=False, fix_hist_embedding=False, fix_obs_embedding=False,
+                 update_lang_bert=True, vocab_size=250002 // 8 * 8)
+torch.manual_seed(0)
+model = NavCMT(cfg).to(dev)
+B, L, T, V, D = a.batch, a.txt, a.steps, 36, a.feat
+g = torch.Generator(device="cpu").manual_seed(1)
+txt_ids = torch.randint(5, 30000, (B, L), generator=g).to(dev); txt_masks = torch.ones(B, L, dtype=torch.bool, device=dev)
+pano = torch.randn(T, B, V, D, generator=g).to(dev); pang = torch.randn(T, B, V, 4, generator=g).to(dev)
+img = torch.randn(T, B, D, generator=g).to(dev); ang = torch.randn(T, B, 4, generator=g).to(dev)
+ob_img = torch.randn(T, B, V + 1, D, generator=g).to(dev); ob_ang = torch.randn(T, B, V + 1, 4, generator=g).to(dev)
+nav = torch.zeros(B, V + 1, dtype=torch.long, device=dev); nav[:, :4] = 1; nav[:, V] = 2
+ob_masks = torch.ones(B, V + 1, dtype=torch.bool, device=dev)
+target = torch.randint(0, 4, (B,), generator=g).to(dev)
+
+def rollout(train):
+    model.train(train)
+    lang = model("language", txt_ids=txt_ids, txt_masks=txt_masks)
+    hs = [model("history").expand(B, -1)]
+    loss = 0.0
+    for t in range(T):
+        hist = torch.stack(hs, 1)
+        hist_masks = torch.ones(B, len(hs), dtype=torch.bool, device=dev)
+        out = model("visual", txt_embeds=lang, hist_embeds=hist, txt_masks=txt_masks, hist_masks=hist_masks,
+                    ob_img_feats=ob_img[t], ob_ang_feats=ob_ang[t], ob_nav_types=nav, ob_masks=ob_masks)
+        if train:
+            loss = loss + ops.cross_entropy(out[0], target).mean()
+        hs.append(model("history", hist_img_feats=img[t], hist_ang_feats=ang[t], ob_step_ids=torch.tensor([t], device=dev),
+                        hist_pano_img_feats=pano[t], hist_pano_ang_feats=pang[t]))
+    if train:
+        loss.backward()
+        model.zero_grad(set_to_none=True)
+
+for train in (False, True):
+    ctx = torch.enable_grad() if train else torch.no_grad()
+    with ctx:
+        rollout(train); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.reps): rollout(train)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    print(f"{'train (fwd+bwd, IL loss)' if train else 'inference (no_grad)'}: {dt*1e3:8.1f} ms per {T}-step rollout of {B} episodes "
+          f"= {dt/T*1e3:6.2f} ms per step, {B*T/dt:8.1f} agent-steps/s")
