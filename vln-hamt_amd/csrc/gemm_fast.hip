@@ -1,23 +1,28 @@
-// Fast path of hamt_gemm for the shapes that carry the FLOPs of the HAMT step:
-//   C[M,N] = epi(A[M,K] * B[N,K]^T), A and B bf16, both K-contiguous ("NT"), K % 64 == 0.
-// Every contraction of the step is brought to this form by the host side (forward: x16 * W16^T;
-// dgrad: dY16 * (W^T)16^T; wgrad: (dY^T)16 * (X^T)16^T -- transposed bf16 copies come from
-// hamt_cast_transpose), so ONE kernel needs tuning.
+// Fast path of hamt_gemm and the grouped weight-gradient launch: the bf16 MFMA GEMMs that carry the FLOPs of the HAMT step.
+//   C[M,N] = epi(op(A) * op(B)), A and B bf16; each operand either K-contiguous ([rows][K], forward activations and
+//   weights) or K-strided ([K][cols]: the weight in the dgrad "NN" form, both operands in the wgrad "TN" form), so the
+//   row-major bf16 images the producers wrote serve every contraction -- there are no transposed copies.
 //
-// Structure (cdna_hip_programming.md section 5: glds staging, T2 swizzle, T3/T4 counted waits):
-//   * BMx128x64 tile (BM = 128 or 64), 256 threads = 4 waves (2x2); each wave (BM/2)x64 output as fragments of
-//     v_mfma_f32_16x16x32_bf16 with the operand roles SWAPPED (mfma(B,A)): a lane then owns 4 consecutive
-//     columns of one C row, so the epilogue stores 16 bytes per lane instead of four 4-byte scatters;
-//   * operands go L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR round
-//     trip) into a 2-deep ring: tile kt+1 is issued while tile kt is multiplied, waits are explicit s_waitcnt vmcnt
-//     in front of a raw s_barrier (the kernel is generic in the ring depth; 2 is what measures best because 64 / 48
-//     KiB of LDS lets 2-3 workgroups share a CU, and independent workgroups overlap better than a deeper ring);
-//   * LDS image is lane-linear per DMA instruction (8 rows x 128 B); the 16-byte k-chunk index is XOR-swizzled
-//     with (row & 7) on the SOURCE address and on the fragment read (conflict-free ds_read_b128);
+// Structure (cdna_hip_programming.md section 5: glds staging, swizzled LDS, explicit waits):
+//   * gemm_tile<BM, BN, WM x WN waves>: 64/128 x 128 tiles with 4 waves (2-3 workgroups per CU) for forward / dgrad, and a
+//     256 x 256 tile with 8 waves (one workgroup per CU, half the DMA pieces and 3/4 of the LDS reads per MFMA) for long
+//     reductions over large grids (weight gradients; big forward GEMMs); v_mfma_f32_16x16x32_bf16 with the operand roles
+//     SWAPPED (mfma(B,A)) so that a lane owns 4 consecutive columns of one C row;
+//   * operands go L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR round trip) into a
+//     2-deep ring: tile kt+1 is issued while tile kt is multiplied, waits are explicit s_waitcnt vmcnt in front of a raw
+//     s_barrier (the tile body is generic in the ring depth; 2 measures best: independent workgroups sharing a CU overlap
+//     better than a deeper ring in one);
+//   * LDS images are lane-linear per DMA instruction; K-contiguous tiles XOR the 16-byte k-chunk index with (row & 7) on the
+//     SOURCE address and on the ds_read_b128 fragment read (conflict free); K-strided tiles are read with
+//     ds_read_b64_tr_b16 (hardware transpose) under a pair-preserving XOR;
 //   * ragged M/N: row indices are clamped for the loads (no OOB access), the epilogue masks the stores;
-//   * split-K (grid.y slices of the K loop writing fp32 partial tiles, summed by a second kernel in a fixed
-//     order) for the weight-gradient shapes: 768x768 outputs with K = B*L >= 5120 would otherwise use 36 CUs;
-//   * the epilogue is compiled per flag set (template) -- a dynamic one unrolled 64x overflowed the I-cache.
+//   * epilogue: the fp32 accumulators are re-tiled through an XOR-swizzled LDS tile so that a lane stores 8 consecutive
+//     columns (one 16-byte store per bf16 output: stores are issue-bound on this chip), compiled per flag set (template --
+//     a dynamic one unrolled 64x overflowed the I-cache); the 256-square tile stores fp32 straight from the MFMA layout;
+//   * small outputs with a long reduction that are NOT weight gradients use deterministic split-K (grid.y slices writing
+//     fp32 partial tiles, summed by a second kernel in a fixed order); weight gradients go through
+//     hamt_wgrad_grouped instead: all problems of a backward pass in one launch per tile class, each problem pinned to
+//     one XCD so that its operand panels cross the fabric once, bias sums fused in.
 #include "common.h"
 #include <algorithm>
 #include <vector>

@@ -4,7 +4,7 @@ In the reference every ``nn.Linear`` backward computes dW = dY^T X (and db = col
 (vilmodel.py: all nn.Linear layers, through torch.autograd).  Weight gradients are not on the backward critical
 path -- only the optimizer reads them -- and one 768x768 output covers 36 of the 256 CUs, so here the block /
 linear backward functions only *queue* (W, b, dY16, X16) and the whole list is handed to ``hamt_wgrad_grouped``
-once, when the autograd engine finishes the pass (``queue_callback``): a handful of chip-filling launches with
+once, when the autograd engine finishes the pass (``queue_callback``): one chip-filling launch per tile class with
 full-length K loops, bias sums fused in (one extra MFMA per fragment), no split-K scratch and no reduce pass.
 
 Where the result goes: a parameter that owns a slot in the optimizer's flat gradient arena (``_hamt_grad_slot``,
