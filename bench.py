@@ -87,6 +87,47 @@ def time_gemm_probe(batch, device, iters=30):
             "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2)}
 
 
+def time_gemm_family(model, cfg, batch, device, iters=5):
+    """The other big consumer (rocprofv3: gemm_fast_kernel<64|128, BIAS, NT>, the forward projections): every such call of
+    one SAP forward pass is recorded (operands, bias, output) and the list re-issued under HIP events; achieved =
+    sum(2*M*N*K) / time, avg_launch_us comparable with the rocprofv3 averages of those kernels."""
+    from vln_hamt_amd import _lib as Lb, ops
+    from vln_hamt_amd.synth import make_batch
+    b = make_batch("sap", batch, cfg, seed=4243, txt_len=L_TXT, hist_len=T_HIST, device=device)
+    calls, orig = [], ops.gemm
+
+    def rec(a, bb, out, **kw):
+        if kw.get("bias") is not None and not kw.get("a_kmajor") and not kw.get("b_kmajor") and kw.get("epilogue", 0) == 0 \
+                and a.dtype == torch.bfloat16 and bb.dtype == torch.bfloat16 and a.shape[1] % 64 == 0:
+            calls.append((a, bb, out, kw))
+        return orig(a, bb, out, **kw)
+
+    ops.gemm = rec
+    import vln_hamt_amd.blocks as blk
+    blk_gemm, blk.gemm = blk.gemm, rec
+    try:
+        with torch.no_grad():
+            model(b, "sap", True)
+    finally:
+        ops.gemm, blk.gemm = orig, blk_gemm
+    torch.cuda.synchronize()
+    flops = sum(2.0 * o.shape[0] * o.shape[1] * a.shape[1] for a, _, o, _ in calls)
+    run = lambda: [orig(a, bb, o, **kw) for a, bb, o, kw in calls]
+    run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": f"gemm_fast_kernel<64|128, BIAS, NT>: the {len(calls)} forward projection GEMMs of one SAP pass, B={batch} (eager re-issue: "
+                      "includes host launch gaps for the small ones)", "achieved": round(tf, 2), "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / max(1, len(calls)), 2)}
+
+
 def time_wgrad_roofline(model, cfg, batch, device, iters=10):
     """Live HIP-event timing of the dominant kernel of the step (rocprofv3: wgrad_grouped_kernel<128>, profiles/): the
     grouped weight-gradient launch of one SAP backward pass, re-issued from the very problem list the pass queued
@@ -321,6 +362,7 @@ def main():
         out["roofline"] = time_wgrad_roofline(model, cfg, args.batch, device)
         out["roofline"]["traffic"] = WGRAD_TRAFFIC_BYTES.get(args.batch)
         out["roofline_probe_ffn1"] = time_gemm_probe(args.batch, device)
+        out["roofline_probe_fwd_gemms"] = time_gemm_family(model, cfg, args.batch, device)
         log("roofline probe done; timing the CPU oracle baseline")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
