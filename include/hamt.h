@@ -200,6 +200,9 @@ int hamt_mul_bcast_bwd(int B, int S, int H, const float* a, const float* c, int 
 int hamt_sum_rows(int B, int S, int H, const float* x, int mode, float* out, float* ws, void* stream);
 
 /* elementwise: out = a + b (+ c) ; dropout forward/backward (feature dropout, model_HAMT.py:32-52) */
+/* image [N][C][H][W] fp32 -> patch rows y[N*(H/P)*(W/P) .. Rpad)[C*P*P] (fp32 or bf16; rows beyond the patches zero): column
+ * order = the flattened conv weight [D][C][P][P], so PatchEmbed's conv (vision_transformer.py:216-221) becomes one GEMM */
+int hamt_patchify(int N, int C, int H, int W, int P, const float* x, void* y, int ldy, int dtype_y, int Rpad, void* stream);
 int hamt_add3(size_t n, const float* a, const float* b, const float* c, float* out, void* stream);
 int hamt_dropout(size_t n, const float* x, float* y, float p, uint32_t call_id, const uint64_t* rng, void* stream);
 int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* stream);

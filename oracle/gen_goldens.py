@@ -337,8 +337,42 @@ def gen_finetune():
     print("tiny_finetune.npz:", len(store), "arrays")
 
 
+def gen_vit():
+    """ViT backbone (row N3): the reference's own VisionTransformer class (imported through ref_shim.import_vit) on a
+    tiny config (features + every parameter gradient of sum(feats * probe)) and on ViT-B/16 at 224x224 (features only)."""
+    from oracle.hamt_oracle import VitConfig, make_vit_state_dict, vit_forward_features
+    vt = ref_shim.import_vit()
+    store = {}
+    for tag, c, n_img in (("tiny", VitConfig.tiny(), 3), ("b16", VitConfig(), 2)):
+        sd = make_vit_state_dict(c, seed=21)
+        ref = vt.VisionTransformer(img_size=c.img_size, patch_size=c.patch_size, in_chans=c.in_chans, num_classes=0,
+                                   embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, mlp_ratio=c.mlp_ratio, qkv_bias=True)
+        ref.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        ref.eval()
+        rng = np.random.Generator(np.random.PCG64(5))
+        imgs = torch.from_numpy(rng.standard_normal((n_img, c.in_chans, c.img_size, c.img_size), dtype=np.float32))
+        probe = torch.from_numpy(rng.standard_normal((n_img, c.embed_dim), dtype=np.float32))
+        feats = ref.forward_features(imgs)
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ofeats = vit_forward_features(osd, c, imgs)
+        print(f"  [vit {tag}] oracle-vs-reference features max|d|={(feats - ofeats).abs().max().item():.3e}")
+        store[f"{tag}/images"] = imgs.numpy() if tag == "tiny" else imgs[:, :, :8, :8].numpy()      # b16 inputs are regenerated
+        store[f"{tag}/probe"] = probe.numpy()
+        store[f"{tag}/feats"] = feats.detach().numpy()
+        if tag == "tiny":
+            (feats * probe).sum().backward()
+            (ofeats * probe).sum().backward()
+            worst = 0.0
+            for k, p_ in ref.named_parameters():
+                store[f"{tag}/grad/{k}"] = p_.grad.numpy()
+                worst = max(worst, (p_.grad - osd[k].grad).abs().max().item())
+            print(f"  [vit {tag}] oracle-vs-reference gradients max|d|={worst:.3e}")
+    np.savez_compressed(os.path.join(OUT, "vit.npz"), **store)
+    print("vit.npz:", len(store), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit"]
     for w in which:
-        {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune}[w]()
+        {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit}[w]()

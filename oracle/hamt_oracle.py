@@ -595,3 +595,74 @@ def adamw_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: dict,
         p.addcdiv_(m, v.sqrt().add_(eps), value=-step_size)
         if decays(k) and weight_decay > 0:
             p.add_(p, alpha=-lr * weight_decay)
+
+
+# =========================================================================== ViT-B/16 backbone
+@dataclass
+class VitConfig:
+    """vision_transformer.py:236-239 defaults of vit_base_patch16_224 (:486-493): 224/16, 768 wide, 12 deep, 12 heads."""
+    img_size: int = 224
+    patch_size: int = 16
+    in_chans: int = 3
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: float = 4.0
+
+    @classmethod
+    def tiny(cls, **kw):
+        d = dict(img_size=32, patch_size=8, in_chans=3, embed_dim=128, depth=2, num_heads=2, mlp_ratio=2.0)
+        d.update(kw)
+        return cls(**d)
+
+
+def vit_param_shapes(c: VitConfig) -> Dict[str, tuple]:
+    """state_dict of VisionTransformer without classifier head (num_classes=0), in module order (:266-283)."""
+    D, P = c.embed_dim, c.patch_size
+    n_tok = (c.img_size // P) ** 2 + 1
+    Hm = int(D * c.mlp_ratio)
+    sh = {"cls_token": (1, 1, D), "pos_embed": (1, n_tok, D),
+          "patch_embed.proj.weight": (D, c.in_chans, P, P), "patch_embed.proj.bias": (D,)}
+    for i in range(c.depth):
+        b = f"blocks.{i}."
+        sh.update({b + "norm1.weight": (D,), b + "norm1.bias": (D,), b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
+                   b + "attn.proj.weight": (D, D), b + "attn.proj.bias": (D,), b + "norm2.weight": (D,), b + "norm2.bias": (D,),
+                   b + "mlp.fc1.weight": (Hm, D), b + "mlp.fc1.bias": (Hm,), b + "mlp.fc2.weight": (D, Hm), b + "mlp.fc2.bias": (D,)})
+    sh.update({"norm.weight": (D,), "norm.bias": (D,)})
+    return sh
+
+
+def make_vit_state_dict(c: VitConfig, seed: int = 0) -> Dict[str, Tensor]:
+    """numpy-PCG64 recipe like make_state_dict: N(0, 0.02) weights, norm weights 1 + 0.1 N, nothing left at 0 / 1."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for k, shp in vit_param_shapes(c).items():
+        a = rng.standard_normal(size=shp, dtype=np.float32)
+        is_norm_w = k.endswith("weight") and (".norm" in k or k.startswith("norm"))
+        sd[k] = torch.from_numpy((1.0 + 0.1 * a) if is_norm_w else 0.02 * a)
+    return sd
+
+
+def vit_forward_features(sd: Dict[str, Tensor], c: VitConfig, images: Tensor) -> Tensor:
+    """VisionTransformer.forward_features (vision_transformer.py:335-348) in eval / zero-dropout form: conv patch embed
+    (:201-223), cls token + position embedding (:337-342), `depth` pre-LN blocks (:181-198: x += attn(norm1 x);
+    x += mlp(norm2 x)), final LayerNorm eps 1e-6 (:265), return the cls row."""
+    D, nh = c.embed_dim, c.num_heads
+    x = F.conv2d(images, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=c.patch_size)   # :220
+    x = x.flatten(2).transpose(1, 2)
+    B, N, _ = x.shape
+    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], 1) + sd["pos_embed"]                                  # :337-342
+    for i in range(c.depth):
+        b = f"blocks.{i}."
+        y = F.layer_norm(x, (D,), sd[b + "norm1.weight"], sd[b + "norm1.bias"], 1e-6)
+        S = y.shape[1]
+        qkv = F.linear(y, sd[b + "attn.qkv.weight"], sd[b + "attn.qkv.bias"]).reshape(B, S, 3, nh, D // nh).permute(2, 0, 3, 1, 4)  # :167
+        att = (qkv[0] @ qkv[1].transpose(-2, -1)) * (D // nh) ** -0.5                                            # :170
+        att = att.softmax(-1)
+        y = (att @ qkv[2]).transpose(1, 2).reshape(B, S, D)                                                     # :174
+        x = x + F.linear(y, sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"])                               # :196
+        y = F.layer_norm(x, (D,), sd[b + "norm2.weight"], sd[b + "norm2.bias"], 1e-6)
+        y = F.linear(F.gelu(F.linear(y, sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"])), sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"])
+        x = x + y                                                                                               # :197
+    x = F.layer_norm(x, (D,), sd["norm.weight"], sd["norm.bias"], 1e-6)                                         # :344
+    return x[:, 0]                                                                                              # :346

@@ -8,6 +8,7 @@ the reference modules.  Goldens never depend on the shim's random init: every pa
 overwritten from the numpy recipe with ``load_state_dict(strict=True)``.
 """
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -98,3 +99,43 @@ def make_config(ocfg, **extra):
              initializer_range=0.02, num_hidden_layers=12)
     d.update(extra)
     return types.SimpleNamespace(**d)
+
+
+def import_vit():
+    """-> the reference's pretrain_src/model/vision_transformer.py module.  It is a timm copy that imports a handful of
+    timm helpers at module level (vision_transformer.py:30-33); timm is not in the image, so tiny stand-ins for exactly
+    those names are installed first (only `to_2tuple`, `trunc_normal_`, `DropPath` are ever *called* by the classes we
+    instantiate; goldens never depend on random init -- every parameter is overwritten from the numpy recipe)."""
+    install()
+    if "timm" not in sys.modules:
+        timm = types.ModuleType("timm")
+        data = types.ModuleType("timm.data")
+        data.IMAGENET_DEFAULT_MEAN, data.IMAGENET_DEFAULT_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        models = types.ModuleType("timm.models")
+        helpers = types.ModuleType("timm.models.helpers")
+        helpers.build_model_with_cfg = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("not available in the shim"))
+        helpers.overlay_external_default_cfg = lambda cfg, kw: None
+        layers = types.ModuleType("timm.models.layers")
+
+        class DropPath(nn.Module):          # only constructed for drop_path > 0 (vision_transformer.py:190)
+            def __init__(self, p=0.0):
+                super().__init__()
+                self.p = p
+
+            def forward(self, x):
+                assert self.p == 0.0 or not self.training
+                return x
+
+        layers.DropPath = DropPath
+        layers.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+        layers.trunc_normal_ = lambda t, std=1.0, **k: nn.init.trunc_normal_(t, std=std)
+        layers.lecun_normal_ = lambda t: nn.init.normal_(t, std=0.02)
+        registry = types.ModuleType("timm.models.registry")
+        registry.register_model = lambda f: f
+        for name, mod in (("timm", timm), ("timm.data", data), ("timm.models", models), ("timm.models.helpers", helpers),
+                          ("timm.models.layers", layers), ("timm.models.registry", registry)):
+            sys.modules[name] = mod
+    spec = importlib.util.spec_from_file_location("ref_vision_transformer", os.path.join(REF, "pretrain_src", "model", "vision_transformer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

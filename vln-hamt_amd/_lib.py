@@ -69,6 +69,7 @@ SIGNATURES = {
     "hamt_mul_bcast_fwd": [i32, i32, i32, vp, vp, i32, vp, vp],
     "hamt_mul_bcast_bwd": [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp],
     "hamt_sum_rows": [i32, i32, i32, vp, i32, vp, vp, vp],
+    "hamt_patchify": [i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp],
     "hamt_add3": [sz, vp, vp, vp, vp, vp],
     "hamt_dropout": [sz, vp, vp, f32, u32, vp, vp],
     "hamt_cast_f32_bf16": [sz, vp, vp, vp],

@@ -261,6 +261,37 @@ extern "C" int hamt_mul_bcast_bwd(int B, int S, int H, const float* a, const flo
   HAMT_CHECK_LAUNCH("hamt_mul_bcast_bwd");
   return HAMT_OK;
 }
+// ---------------------------------------------------------------- image -> patch rows (ViT patch embedding as a GEMM)
+// y[(n, py, px)][c*P*P + ky*P + kx] = x[n][c][py*P + ky][px*P + kx]: the column order of the flattened conv weight
+// [D][C][P][P], so that conv2d(kernel = stride = P) (vision_transformer.py:216-221) is y @ W.view(D, C*P*P)^T + b.
+// One thread per 4 consecutive kx (16-byte loads along the image row, 8-byte bf16 stores along the patch row).
+template <typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(int N, int C, int H, int W, int P, const float* __restrict__ x, TO* __restrict__ y,
+                                                       int ldy, int Rpad) {
+  const int gw = W / P, gh = H / P, K = C * P * P, q = K / 4;
+  const size_t total = (size_t)Rpad * q;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / q), col = (int)(i % q) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < N * gh * gw) {
+      const int n = row / (gh * gw), py = (row / gw) % gh, px = row % gw;
+      const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+      v = *(const float4*)(x + (((size_t)n * C + c) * H + py * P + ky) * W + px * P + kx);
+    }
+    if constexpr (sizeof(TO) == 2) *(uint2*)(y + (size_t)row * ldy + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    else *(float4*)(y + (size_t)row * ldy + col) = v;
+  }
+}
+extern "C" int hamt_patchify(int N, int C, int H, int W, int P, const float* x, void* y, int ldy, int dtype_y, int Rpad, void* stream) {
+  HAMT_CHECK_ARG(x && y && N >= 0 && C > 0 && P > 0 && P % 4 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0 && ldy >= C * P * P && ldy % 4 == 0 &&
+                 Rpad >= N * (H / P) * (W / P) && ((uintptr_t)x % 16) == 0, "hamt_patchify: bad argument");
+  if (Rpad == 0) return HAMT_OK;
+  const size_t total = (size_t)Rpad * (C * P * P / 4);
+  if (dtype_y == HAMT_BF16) hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(nblocks(total)), dim3(256), 0, as_stream(stream), N, C, H, W, P, x, (bf16_t*)y, ldy, Rpad);
+  else hipLaunchKernelGGL((patchify_kernel<float>), dim3(nblocks(total)), dim3(256), 0, as_stream(stream), N, C, H, W, P, x, (float*)y, ldy, Rpad);
+  HAMT_CHECK_LAUNCH("hamt_patchify");
+  return HAMT_OK;
+}
 extern "C" int hamt_add3(size_t n, const float* a, const float* b, const float* c, float* out, void* stream) {
   HAMT_CHECK_ARG(a && b && out && n % 4 == 0, "hamt_add3: bad argument");
   if (n == 0) return HAMT_OK;
