@@ -539,3 +539,43 @@ def test_finetune_rollout_backward_vs_oracle(prec, no_lang_ca):
           f"worst per-parameter norm error {worst:.2e}")
     assert cos >= (0.99999 if prec == "fp32" else 0.995), cos
     assert worst <= (2e-3 if prec == "fp32" else 6e-2), worst
+
+
+def test_graphed_inference_rollout_matches_eager():
+    """graph.GraphedInference (one captured graph per history length) returns what the eager no-grad call returns, for
+    fresh inputs on every replay (the finetune rollout's `visual` / `history` steps)."""
+    from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
+    from vln_hamt_amd.graph import GraphedInference
+    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+    from vln_hamt_amd.modeling import HamtConfig
+    store = load_npz("tiny_finetune.npz")
+    ocfg = tiny_cfg(no_lang_ca=True, act_pred_token="ob")
+    kw = dict(vars(ocfg))
+    kw.pop("pretrain_tasks")
+    model = NavCMT(HamtConfig(hamt_precision="bf16", **kw))
+    model.load_state_dict(make_state_dict(navcmt_param_shapes(ocfg), seed=9), strict=True)
+    model = model.to(DEV).eval()
+    b = to_dev({k: torch.from_numpy(v) for k, v in sub(store, "nolangca/in/").items()})
+    B = b["txt_ids"].shape[0]
+    with torch.no_grad():
+        lang = model("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+        vis = lambda hist, hm, oi, oa: model("visual", txt_embeds=lang, hist_embeds=hist, txt_masks=b["txt_masks"], hist_masks=hm,
+                                             ob_img_feats=oi, ob_ang_feats=oa, ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+        gv = GraphedInference(vis)
+        hs = [model("history").expand(B, -1).contiguous()]
+        for rep in range(2):                          # second round replays the graphs captured in the first, on new data
+            hs = hs[:1]
+            for t in range(3):
+                hist = torch.stack(hs, 1)
+                hm = b["hist_masks"][:, :t + 1].contiguous()
+                oi = b["ob_img_fts"] * (1.0 + 0.25 * rep)
+                want = vis(hist, hm, oi, b["ob_ang_fts"])
+                got = gv(("visual", t + 1), hist, hm, oi, b["ob_ang_fts"])
+                for w, g_ in zip(want, got):
+                    fin = torch.isfinite(w)
+                    assert torch.equal(torch.isfinite(g_), fin)
+                    assert float((w[fin] - g_[fin]).abs().max()) == 0.0, (rep, t)
+                hs.append(model("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
+                                ob_step_ids=torch.tensor([t], device=DEV), hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
+                                hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
+        assert len(gv.graphs) == 3

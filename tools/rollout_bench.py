@@ -49,6 +49,33 @@ def rollout(train):
         loss.backward()
         model.zero_grad(set_to_none=True)
 
+def rollout_graphed(gv, gh, lang):
+    """inference rollout with one captured graph per history length (`visual`) and one for `history`"""
+    hs = [cls_h]
+    for t in range(T):
+        hist = torch.stack(hs, 1)
+        hist_masks = torch.ones(B, len(hs), dtype=torch.bool, device=dev)
+        gv(("visual", len(hs)), hist, hist_masks, ob_img[t], ob_ang[t])
+        hs.append(gh("history", img[t], ang[t], torch.tensor([t], device=dev), pano[t], pang[t]).clone())
+
+
+from vln_hamt_amd.graph import GraphedInference
+model.eval()
+with torch.no_grad():
+    lang_static = model("language", txt_ids=txt_ids, txt_masks=txt_masks)
+    cls_h = model("history").expand(B, -1).contiguous()
+gv = GraphedInference(lambda hist, hm, oi, oa: model("visual", txt_embeds=lang_static, hist_embeds=hist, txt_masks=txt_masks, hist_masks=hm,
+                                                      ob_img_feats=oi, ob_ang_feats=oa, ob_nav_types=nav, ob_masks=ob_masks))
+gh = GraphedInference(lambda i_, a_, sid, p_, pa_: model("history", hist_img_feats=i_, hist_ang_feats=a_, ob_step_ids=sid,
+                                                          hist_pano_img_feats=p_, hist_pano_ang_feats=pa_))
+rollout_graphed(gv, gh, lang_static); torch.cuda.synchronize()          # captures
+t0 = time.perf_counter()
+for _ in range(a.reps): rollout_graphed(gv, gh, lang_static)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.reps
+print(f"inference, graph replay per step: {dt*1e3:8.1f} ms per {T}-step rollout of {B} episodes = {dt/T*1e3:6.2f} ms per step, "
+      f"{B*T/dt:8.1f} agent-steps/s (language pass excluded: it runs once per episode)")
+
 for train in (False, True):
     ctx = torch.enable_grad() if train else torch.no_grad()
     with ctx:

@@ -119,3 +119,39 @@ class GraphedTrainStep:
                 self.opt._packed = False
             self.update_graph.replay()
         return loss_c
+
+
+class GraphedInference:
+    """hipGraph capture of a no-grad callable over tensors of fixed shapes (rollout steps of the finetune model: one
+    graph per history length for `visual`, one for `history`).  Inputs are copied into static buffers before every replay;
+    the returned tensors are the graph's static outputs (valid until the next call with the same key)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.graphs = {}
+        self.pool = None
+        self.stream = torch.cuda.Stream()
+
+    @torch.no_grad()
+    def __call__(self, key, *tensors):
+        ent = self.graphs.get(key)
+        if ent is None:
+            static = [t.clone() if torch.is_tensor(t) else t for t in tensors]
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.fn(*static)                      # warm-up on the capture stream (allocator, lazy caches)
+            cur.wait_stream(self.stream)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
+                out = self.fn(*static)
+            ent = self.graphs[key] = (g, static, out)
+        g, static, out = ent
+        for s_, t in zip(static, tensors):
+            if torch.is_tensor(t):
+                s_.copy_(t, non_blocking=True)
+        g.replay()
+        return out
