@@ -59,7 +59,9 @@ enum {
   HAMT_EPI_MUL_DGELU = 16, HAMT_EPI_MUL_DRELU = 32, HAMT_EPI_SAVE_PRE = 64,
   /* bf16 training path: forward stores gelu(v) to C and gelu'(v) to aux in ONE erf/exp evaluation (A&S 7.1.26 erf,
    * |err| <= 1.5e-7, far below bf16 resolution); backward just multiplies by aux. */
-  HAMT_EPI_GELU_GRAD = 128, HAMT_EPI_MUL_AUX = 256
+  HAMT_EPI_GELU_GRAD = 128, HAMT_EPI_MUL_AUX = 256,
+  /* C = epi(...) + aux  (residual add of the pre-LN ViT blocks, vision_transformer.py:196-197; aux fp32 or bf16 [M][ldaux]) */
+  HAMT_EPI_ADD_AUX = 512
 };
 typedef struct {
   int M, N, K;

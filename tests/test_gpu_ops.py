@@ -567,3 +567,22 @@ def test_cpu_tensor_is_rejected_loudly():
     from vln_hamt_amd._lib import HamtError
     with pytest.raises(HamtError):
         ops.linear(torch.randn(4, 8), torch.randn(8, 8), torch.randn(8), 0, "fp32")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_linear_with_residual_epilogue(prec):
+    """HAMT_EPI_ADD_AUX: y = x W^T + b + residual in the GEMM epilogue; the residual's gradient is dy."""
+    ops = _ops()
+    x = rnd(300, 256, seed=1).to(DEV).requires_grad_()
+    r = rnd(300, 192, seed=2).to(DEV).requires_grad_()
+    lin = torch.nn.Linear(256, 192).to(DEV)
+    y = ops.linear(x, lin.weight, lin.bias, ops.ACT_NONE, prec, residual=r)
+    go = rnd(300, 192, seed=3).to(DEV)
+    y.backward(go)
+    xr = bf16_round(x.detach()) if prec == "bf16" else x.detach()
+    wr = bf16_round(lin.weight.detach()) if prec == "bf16" else lin.weight.detach()
+    ref = xr.double() @ wr.double().t() + lin.bias.detach().double() + r.detach().double()
+    close(y, ref, 2e-5, "y")
+    close(r.grad, go, 0.0, "d residual")
+    gr = bf16_round(go) if prec == "bf16" else go
+    close(x.grad, gr.double() @ wr.double(), 2e-5 if prec == "fp32" else 3e-3, "dx")

@@ -54,6 +54,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int row, int col, f
     float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
     v *= (g.epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h) : (h > 0.0f ? 1.0f : 0.0f);
   }
+  if (g.epi & HAMT_EPI_ADD_AUX) v += (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
   size_t ic = (size_t)row * g.ldc + col;
   if (g.dtype_c == HAMT_BF16) {
     bf16_t* c = (bf16_t*)g.C;
@@ -428,7 +429,7 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
   HAMT_CHECK_ARG((d->lda * sa) % 16 == 0 && (d->ldb * sb) % 16 == 0, "hamt_gemm: lda/ldb rows must be 16-byte aligned (lda=%d ldb=%d)", d->lda, d->ldb);
   HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
   HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
-  HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) || aux, "hamt_gemm: epilogue needs aux");
+  HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX | HAMT_EPI_ADD_AUX)) || aux, "hamt_gemm: epilogue needs aux");
   const int ka = (d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K, kb = (d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K;
   GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, ka, kb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
   hipStream_t s = as_stream(stream);

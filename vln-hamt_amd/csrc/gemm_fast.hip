@@ -193,6 +193,12 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
       v[j] *= (epi & HAMT_EPI_MUL_AUX) ? h[j] : ((epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h[j]) : (h[j] > 0.0f ? 1.0f : 0.0f));
   }
   if (epi & HAMT_EPI_RELU) { for (int j = 0; j < W; ++j) v[j] = fmaxf(v[j], 0.0f); }
+  if (epi & HAMT_EPI_ADD_AUX) {   // residual add
+    float h[W];
+    if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
+    else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
+    for (int j = 0; j < W; ++j) v[j] += h[j];
+  }
   if (g.dtype_c == HAMT_BF16) {
     bf16_t* c = (bf16_t*)g.C + ic;
     if (vc) {
@@ -459,6 +465,7 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   else if (e == HAMT_EPI_MUL_DGELU) HAMT_L(HAMT_EPI_MUL_DGELU);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
   else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX);
   else HAMT_L(-1);
 #undef HAMT_L
 }

@@ -39,12 +39,15 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
         self.prec = prec
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """mlp(x) (+ residual).  With dropout off the residual add rides in fc2's GEMM epilogue."""
         p = float(self.drop.p) if self.training else 0.0
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, ops.ACT_GELU, self.prec)
         h = ops.dropout(h, p, self.training)
-        y = ops.linear(h, self.fc2.weight, self.fc2.bias, ops.ACT_NONE, self.prec)
-        return ops.dropout(y, p, self.training)
+        if residual is not None and p == 0.0:
+            return ops.linear(h, self.fc2.weight, self.fc2.bias, ops.ACT_NONE, self.prec, residual=residual)
+        y = ops.dropout(ops.linear(h, self.fc2.weight, self.fc2.bias, ops.ACT_NONE, self.prec), p, self.training)
+        return y if residual is None else ops.add3(residual, y)
 
 
 class Attention(nn.Module):
@@ -61,13 +64,17 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.prec = prec
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """attn(x) (+ residual).  With dropout off the residual add rides in the projection's GEMM epilogue."""
         B, N, D = x.shape
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias, ops.ACT_NONE, self.prec).view(B * N, 3 * D)
         pa = float(self.attn_drop.p) if self.training else 0.0
+        pp = float(self.proj_drop.p) if self.training else 0.0
         ctx = ops.attention(qkv, None, None, B, self.num_heads, pa, self.prec)
-        y = ops.linear(ctx, self.proj.weight, self.proj.bias, ops.ACT_NONE, self.prec)
-        return ops.dropout(y, float(self.proj_drop.p), self.training).view(B, N, D)
+        if residual is not None and pp == 0.0:
+            return ops.linear(ctx, self.proj.weight, self.proj.bias, ops.ACT_NONE, self.prec, residual=residual.reshape(B * N, D)).view(B, N, D)
+        y = ops.dropout(ops.linear(ctx, self.proj.weight, self.proj.bias, ops.ACT_NONE, self.prec), pp, self.training).view(B, N, D)
+        return y if residual is None else ops.add3(residual, y)
 
 
 class Block(nn.Module):
@@ -81,8 +88,8 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop, prec)
 
     def forward(self, x):
-        x = ops.add3(x, self.attn(ops.layer_norm(x, None, self.norm1, want16=True)))
-        return ops.add3(x, self.mlp(ops.layer_norm(x, None, self.norm2, want16=True)))
+        x = self.attn(ops.layer_norm(x, None, self.norm1, want16=True), residual=x)
+        return self.mlp(ops.layer_norm(x, None, self.norm2, want16=True), residual=x)
 
 
 class PatchEmbed(nn.Module):

@@ -311,7 +311,7 @@ class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b)  (nn.Linear + optional erf-GELU / ReLU; vilmodel.py:140, 168-171, 182, 263-264)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, prec):
+    def forward(ctx, x, weight, bias, act, prec, residual=None):
         _chk(x, "LinearFn")
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
@@ -324,11 +324,20 @@ class LinearFn(torch.autograd.Function):
         # backward GEMMs as 16-byte aligned operands; everything else is plain contiguous
         y = empty_rows(M, N, x.device) if (N % 4 and N >= 256) else torch.empty(M, N, dtype=torch.float32, device=x.device)
         pre = torch.empty(M, N, dtype=torch.float32, device=x.device) if act == ACT_GELU else None
-        _linear_fwd(x2, weight, bias.detach() if bias is not None else None, y, act, prec, pre, x16)
+        if residual is not None:                 # y = x W^T + b + residual in the GEMM epilogue (pre-LN residual add)
+            assert act == ACT_NONE and residual.numel() == M * N
+            r2 = residual.reshape(M, N)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+            a = x16[:M] if x16 is not None else x2
+            gemm(a, weight_operand(weight, prec), y, bias=bias.detach() if bias is not None else None, epilogue=L.EPI_ADD_AUX,
+                 aux=r2.detach(), prec=prec)
+        else:
+            _linear_fwd(x2, weight, bias.detach() if bias is not None else None, y, act, prec, pre, x16)
         # the bf16 image is all backward needs of x (weight gradient operand); keep fp32 x only on the generic path
         ctx.save_for_backward(x2 if x16 is None else None, x16, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
         ctx.act, ctx.prec, ctx.has_bias, ctx.xshape, ctx.M = act, prec, bias is not None, x.shape, M
         ctx.bias_param = bias if (bias is not None and bias.is_leaf) else (None if bias is None else False)
+        ctx.res_shape = residual.shape if residual is not None else None
         return y if x.dim() == 2 else y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -345,11 +354,13 @@ class LinearFn(torch.autograd.Function):
         dy2 = _operand(dy2)
         dx, dw, db = _linear_bwd(dy2, x2, x16, weight, ctx.prec, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                  ctx.has_bias and ctx.needs_input_grad[2], bias_param=ctx.bias_param)
-        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None, None
+        dres = dy.reshape(ctx.res_shape) if (ctx.res_shape is not None and ctx.needs_input_grad[5]) else None
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None, None, dres
 
 
-def linear(x, weight, bias, act=ACT_NONE, prec="bf16"):
-    return LinearFn.apply(x, weight, bias, act, prec)
+def linear(x, weight, bias, act=ACT_NONE, prec="bf16", residual=None):
+    """act(x W^T + b) (+ residual: added in the GEMM epilogue, act must be ACT_NONE)"""
+    return LinearFn.apply(x, weight, bias, act, prec, residual)
 
 
 class PackedLinearFn(torch.autograd.Function):
