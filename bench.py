@@ -358,6 +358,7 @@ def main():
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
         }
         out["roofline"] = time_wgrad_roofline(model, cfg, args.batch, device)
         out["roofline"]["traffic"] = WGRAD_TRAFFIC_BYTES.get(args.batch)
