@@ -169,6 +169,11 @@ int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, co
 int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
                 const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                 float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);
+/* pre-LN blocks (x + f(LN(x)), vision_transformer.py:196-197): dz = LayerNorm-backward(dy) + add, where `add` is the
+ * gradient that reaches x through the residual path -- one pass instead of a LayerNorm backward and an add. */
+int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean, const float* rstd,
+                    const float* gamma, const float* add, float* dz, float* dgamma, float* dbeta, float* ws,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gather/scatter family (embedding lookups A1/A10/A11, boolean-mask compaction A15/A19

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
         r.x *= drop_scale(kpost, o, d.p_post, ik_post); r.y *= drop_scale(kpost, o + 1, d.p_post, ik_post);
         r.z *= drop_scale(kpost, o + 2, d.p_post, ik_post); r.w *= drop_scale(kpost, o + 3, d.p_post, ik_post);
       }
-      *(float4*)(y + o) = r;
+      if (y) *(float4*)(y + o) = r;
       if (y16) *(uint2*)(y16 + o) = make_uint2(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w));
     }
   }
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
                                                      const float* __restrict__ z, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
                                                      float* __restrict__ dz, float* __restrict__ dx, bf16_t* __restrict__ dx16,
-                                                     float* __restrict__ ws, const uint64_t* __restrict__ rng) {
+                                                     float* __restrict__ ws, const uint64_t* __restrict__ rng,
+                                                     const float* __restrict__ add) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int H = d.H;
   if (dx16 && blockIdx.x == 0)      // zero the reduction-padding rows [M, Mpad16) of the bf16 gradient image
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
         float4 r;
         r.x = rstd * (g[i].x - c1 - xh[i].x * c2); r.y = rstd * (g[i].y - c1 - xh[i].y * c2);
         r.z = rstd * (g[i].z - c1 - xh[i].z * c2); r.w = rstd * (g[i].w - c1 - xh[i].w * c2);
-        *(float4*)(dz + o) = r;
+        if (add) {   // pre-LN block: the residual path's gradient rides along (dz_out = LN-backward + add); dx / dx16 /
+          const float4 q = *(const float4*)(add + o);     // dxsum below stay the pure LayerNorm-input gradient
+          *(float4*)(dz + o) = make_float4(r.x + q.x, r.y + q.y, r.z + q.z, r.w + q.w);
+        } else *(float4*)(dz + o) = r;
         if (d.p_pre > 0.f) {
           r.x *= drop_scale(kpre, o, d.p_pre, ik_pre); r.y *= drop_scale(kpre, o + 1, d.p_pre, ik_pre);
           r.z *= drop_scale(kpre, o + 2, d.p_pre, ik_pre); r.w *= drop_scale(kpre, o + 3, d.p_pre, ik_pre);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(int nb, int H, cons
 extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
                            const float* beta, float* z, float* y, void* y16, float* mean, float* rstd,
                            const uint64_t* rng, void* stream) {
-  HAMT_CHECK_ARG(d && x && gamma && beta && y && mean && rstd, "hamt_ln_fwd: null pointer");
+  HAMT_CHECK_ARG(d && x && gamma && beta && (y || y16) && mean && rstd, "hamt_ln_fwd: null pointer");
   HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_fwd: H=%d unsupported (need H%%4==0, H<=1024)", d->H);
   HAMT_CHECK_ARG(d->p_pre >= 0.f && d->p_pre < 1.f && d->p_post >= 0.f && d->p_post < 1.f, "hamt_ln_fwd: bad dropout p");
   if (d->M == 0) return HAMT_OK;
@@ -205,9 +209,9 @@ extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* r
   return HAMT_OK;
 }
 
-extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
-                           const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
-                           float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream) {
+static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+                       const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
+                       float* dbeta, float* dxsum, float* ws, const uint64_t* rng, const float* add, void* stream) {
   HAMT_CHECK_ARG(d && dy && z && mean && rstd && gamma && dz && ws, "hamt_ln_bwd: null pointer");
   HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_bwd: H=%d unsupported", d->H);
   HAMT_CHECK_ARG(!(d->p_pre > 0.f) || dx || dx16, "hamt_ln_bwd: p_pre > 0 needs dx or dx16");
@@ -217,11 +221,24 @@ extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* 
   if (nb > 256) nb = 256;
   hipStream_t s = as_stream(stream);
   float* dxx = d->p_pre > 0.f ? dx : nullptr;
-#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, (bf16_t*)dx16, ws, rng)
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, (bf16_t*)dx16, ws, rng, add)
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
   if (dgamma || dbeta || dxsum)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(1024), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
   return HAMT_OK;
+}
+
+extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+                           const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
+                           float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream) {
+  return ln_bwd_impl(d, dy, z, mean, rstd, gamma, dz, dx, dx16, dgamma, dbeta, dxsum, ws, rng, nullptr, stream);
+}
+
+extern "C" int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+                               const float* rstd, const float* gamma, const float* add, float* dz, float* dgamma,
+                               float* dbeta, float* ws, void* stream) {
+  HAMT_CHECK_ARG(add && d && !(d->p_pre > 0.f) && !(d->p_post > 0.f), "hamt_ln_bwd_add: needs `add`, and no dropout inside the LayerNorm");
+  return ln_bwd_impl(d, dy, z, mean, rstd, gamma, dz, nullptr, nullptr, dgamma, dbeta, nullptr, ws, nullptr, add, stream);
 }

@@ -13,9 +13,11 @@ Same class surface and parameter names as the reference's ``VisionTransformer`` 
   fc2 -> residual add;
 * final LayerNorm, cls row.
 
-First version on the fine-grained autograd Functions of ``ops.py`` (every op has its backward, so images that need
+bf16 mode with the branch dropouts off: one autograd Function per half block (``blocks_preln.py``: bf16 images between
+the kernels, residual adds in GEMM epilogues / in the LayerNorm-backward kernel, queued weight gradients).  Otherwise
+(fp32 mode, branch dropout on) the fine-grained Functions of ``ops.py``.  Every op has its backward, so images that need
 gradients -- observation / history images in image_vilmodel.py:40-59 -- train end to end; the 36-view panorama pass runs
-under ``torch.no_grad()`` as in the reference).  The block-level fusions of ``blocks.py`` are post-LN and do not apply.
+under ``torch.no_grad()`` as in the reference.
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from .. import ops
+from .. import blocks_preln, ops
 from ..ops import _p, _stream
 
 
@@ -88,6 +90,15 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop, prec)
 
     def forward(self, x):
+        a, m = self.attn, self.mlp
+        pd = float(a.proj_drop.p) if self.training else 0.0
+        md = float(m.drop.p) if self.training else 0.0
+        if x.dim() == 3 and blocks_preln.usable(a.prec, x, pd, md):       # one autograd Function per half block
+            pa = float(a.attn_drop.p) if self.training else 0.0
+            x = blocks_preln.PreLnAttnFn.apply(x, a.num_heads, pa, self.norm1.eps, self.norm1.weight, self.norm1.bias,
+                                               a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias)
+            return blocks_preln.PreLnMlpFn.apply(x, self.norm2.eps, self.norm2.weight, self.norm2.bias,
+                                                 m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
         x = self.attn(ops.layer_norm(x, None, self.norm1, want16=True), residual=x)
         return self.mlp(ops.layer_norm(x, None, self.norm2, want16=True), residual=x)
 
