@@ -61,7 +61,12 @@ enum {
    * |err| <= 1.5e-7, far below bf16 resolution); backward just multiplies by aux. */
   HAMT_EPI_GELU_GRAD = 128, HAMT_EPI_MUL_AUX = 256,
   /* C = epi(...) + aux  (residual add of the pre-LN ViT blocks, vision_transformer.py:196-197; aux fp32 or bf16 [M][ldaux]) */
-  HAMT_EPI_ADD_AUX = 512
+  HAMT_EPI_ADD_AUX = 512,
+  /* v = dropout(v) after the activation and before ADD_AUX (the proj_drop / Mlp.drop of the ViT blocks, vision_transformer.py:
+   * 148-150, 176-177): keep factor of element (m, n) = drop_mask(rng, call_id, m, n >> 2)[n & 3], the same mask
+   * hamt_cast_pad_bf16_dropout applies in backward.  With GELU_GRAD the stored gelu' is masked too (so backward's
+   * MUL_AUX needs no second mask).  bf16 fast path only (bf16 operands, K % 64 == 0); anything else is an error. */
+  HAMT_EPI_DROPOUT = 1024
 };
 typedef struct {
   int M, N, K;
@@ -73,6 +78,9 @@ typedef struct {
   float alpha;
   int ka_rows, kb_rows; /* K-strided operands only: number of valid reduction rows actually stored in A / B when K was
                            rounded up for the other operand (0 = K).  Rows beyond are never dereferenced. */
+  float p_drop;         /* HAMT_EPI_DROPOUT only */
+  uint32_t call_id;
+  const uint64_t* rng;  /* DEVICE pointer: {seed, epoch} */
 } hamt_gemm_desc;
 int hamt_gemm(const hamt_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
               void* aux, void* stream);
@@ -89,6 +97,10 @@ int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* B, void* C,
  * (dgrad uses the transposed weight, wgrad the transposed activations / gradients.) */
 int hamt_cast_pad_bf16(int R, int C, int Rpad, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream);
 int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dtype_x, void* y, int ldy, int Rpad, void* stream);
+/* y[Rpad][C] (bf16) = x[R][C] (fp32) * keep(m, n) with the mask of a HAMT_EPI_DROPOUT GEMM of the same (rng, call_id):
+ * the gradient of the dropped branch, ready as dgrad / wgrad operand.  C % 8 == 0; rows >= R zero filled. */
+int hamt_cast_pad_bf16_dropout(int R, int C, int Rpad, const float* x, int ldx, void* y, int ldy, float p, uint32_t call_id,
+                               const uint64_t* rng, void* stream);
 
 /* dW[n][k] (+)= sum_m dy[m][n] * x[m][k] for K <= 8 (weight gradient of the 4-wide angle-feature linears, vilmodel.py:498,
  * 550, 558): exact fp32, K weighted column sums.  ws: >= 64*N*K floats */

@@ -44,7 +44,7 @@ def test_library_exports_every_symbol():
 def test_struct_layouts_match_header():
     """field order/count of the descriptor structs (plain ints/floats, no padding surprises)."""
     from vln_hamt_amd import _lib
-    assert ctypes.sizeof(_lib.GemmDesc) == 18 * 4
+    assert ctypes.sizeof(_lib.GemmDesc) == 18 * 4 + 4 + 4 + 8 and _lib.GemmDesc.p_drop.offset == 72 and _lib.GemmDesc.rng.offset == 80
     assert ctypes.sizeof(_lib.AttnDesc) == 15 * 4
     assert ctypes.sizeof(_lib.LnDesc) == 7 * 4
     assert ctypes.sizeof(_lib.WgradDesc) == 4 * 8 + 8 * 4          # 4 pointers + 8 ints, no padding

@@ -279,7 +279,8 @@ def _attn_ref(q, k, v, mask, heads):
 @pytest.mark.parametrize("B,heads,Sq,Sk,packed,use_mask", [
     (2, 2, 80, 80, True, True), (3, 2, 36, 36, True, False), (2, 3, 43, 80, False, True),
     (2, 2, 80, 43, False, True), (1, 2, 130, 150, False, True), (2, 1, 6, 20, False, True), (2, 2, 250, 250, True, True),
-    (2, 2, 128, 128, True, True), (2, 2, 80, 6, False, True), (3, 1, 1, 37, False, False), (2, 2, 100, 17, False, True), (2, 1, 128, 130, False, True)])
+    (2, 2, 128, 128, True, True), (2, 2, 80, 6, False, True), (3, 1, 1, 37, False, False), (2, 2, 100, 17, False, True), (2, 1, 128, 130, False, True),
+    (2, 2, 197, 197, True, False), (1, 2, 300, 256, False, True), (2, 1, 200, 100, False, True), (1, 1, 140, 257, False, True)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_attention_fwd_bwd(B, heads, Sq, Sk, packed, use_mask, prec):
     """fp32: exact-MFMA kernels (attn.hip) <= 5e-5; bf16: bf16-MFMA kernels (attn16.hip), operands and P rounded to bf16
@@ -317,11 +318,13 @@ def test_attention_fwd_bwd(B, heads, Sq, Sk, packed, use_mask, prec):
     close(gv, v.grad, t_grad, "attn dv")
 
 
+@pytest.mark.parametrize("S", [80, 197, 300])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_attention_dropout_properties(prec):
-    """Counter-based dropout: same mask in fwd and bwd (adjoint identity in V), keep-rate, 1/(1-p) scaling."""
+def test_attention_dropout_properties(prec, S):
+    """Counter-based dropout: same mask in fwd and bwd (adjoint identity in V), keep-rate, 1/(1-p) scaling.  S = 197 pairs
+    the single-pass forward with the tiled backward (bf16 path), S = 300 is tiled both ways: one mask stream for all."""
     ops = _ops()
-    B, heads, S, H, p = 4, 2, 80, 128, 0.3
+    B, heads, H, p = 4, 2, 128, 0.3
     qkv = rnd(B * S, 3 * H, seed=9).to(DEV)
     ops.manual_seed(1234)
     torch.manual_seed(0)

@@ -79,3 +79,179 @@ def test_vit_hip_matches_reference_goldens(tag, prec):
         msg += f"; grad cosine {cos:.6f}, worst per-parameter norm error {worst:.2e}"
         assert cos >= (0.99999 if prec == "fp32" else 0.995) and worst <= (2e-3 if prec == "fp32" else 6e-2), msg
     print(msg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_image_input_model_vs_oracle_composition(prec):
+    """Config-4 model (images -> ViT backbone -> the feature-input model): SAP and MRC losses + gradients against the
+    composition of the two pinned oracles (vit_forward_features, HamtOracle) on tiny configs, dropout off."""
+    sys_path_oracle = None
+    from _util import tiny_cfg
+    from oracle.hamt_oracle import HamtOracle, VitConfig, make_state_dict, make_vit_state_dict, pretrain_param_shapes, vit_forward_features
+    from vln_hamt_amd.model.image_pretrain import MultiStepNavImagePreTraining
+    from vln_hamt_amd.modeling import HamtConfig
+    from vln_hamt_amd.synth import make_batch
+    vc = VitConfig.tiny()                              # 32x32 images, 128-d features
+    ocfg = tiny_cfg()
+    ocfg.image_feat_size = vc.embed_dim
+    for k in ("hidden_dropout_prob", "attention_probs_dropout_prob", "pred_head_dropout_prob"):
+        setattr(ocfg, k, 0.0)
+    sd = make_state_dict(pretrain_param_shapes(ocfg), seed=3)
+    vsd = make_vit_state_dict(vc, seed=4)
+    kw = dict(vars(ocfg))
+    model = MultiStepNavImagePreTraining(HamtConfig(hamt_precision=prec, **kw),
+                                         vit_kwargs=dict(img_size=vc.img_size, patch_size=vc.patch_size, depth=vc.depth, num_heads=vc.num_heads, mlp_ratio=vc.mlp_ratio))
+    full = {k: v.clone() for k, v in sd.items()}
+    full.update({"bert.vision_backbone." + k: v.clone() for k, v in vsd.items()})
+    model.load_state_dict(full, strict=True)
+    model = model.cuda().train()
+    B, T, V = 3, 2, 36
+    rng = np.random.Generator(np.random.PCG64(17))
+    img = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32))
+    for task in ("sap", "mrc"):
+        b = make_batch(task, B, ocfg, seed=40, txt_len=12, hist_len=T, ragged=False)
+        ib = {k: v for k, v in b.items() if k not in ("hist_img_fts", "hist_pano_img_fts", "ob_img_fts")}
+        ib["hist_images"], ib["hist_pano_images"] = img(B, T, 3, 32, 32), img(B, T, V, 3, 32, 32)
+        if task == "sap":
+            ib["ob_images"] = img(B, V, 3, 32, 32)
+            ib["ob_v_exists"] = torch.ones(B, V, dtype=torch.bool)
+            ib["ob_v_exists"][0, 5] = False
+        # ---- oracle composition (CPU fp32 autograd)
+        osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+        ovsd = {k: v.clone().requires_grad_(True) for k, v in vsd.items()}
+        fb = dict(b)
+        hf = vit_forward_features(ovsd, vc, ib["hist_images"].reshape(-1, 3, 32, 32)).reshape(B, T, -1)
+        with torch.no_grad():
+            pf = vit_forward_features(ovsd, vc, ib["hist_pano_images"].reshape(-1, 3, 32, 32)).reshape(B, T, V, -1)
+        if task == "mrc":
+            hf = hf.masked_fill(b["hist_mrc_masks"].unsqueeze(-1), 0)
+            pf = pf.masked_fill(b["hist_mrc_masks"].unsqueeze(-1).unsqueeze(-1), 0)
+        fb["hist_img_fts"], fb["hist_pano_img_fts"] = hf, pf
+        if task == "sap":
+            of = vit_forward_features(ovsd, vc, ib["ob_images"].reshape(-1, 3, 32, 32)).reshape(B, V, -1)
+            of = of.masked_fill(ib["ob_v_exists"].logical_not().unsqueeze(-1), 0)
+            fb["ob_img_fts"] = torch.cat([of, of.new_zeros(B, 1, of.shape[2])], 1)
+        oloss = HamtOracle(osd, ocfg, training=True).forward(fb, task, True)
+        oloss.mean().backward()
+        # ---- HIP
+        model.zero_grad(set_to_none=True)
+        loss = model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ib.items()}, task, True)
+        loss.mean().backward()
+        e = _rel(loss, oloss.detach())
+        ref = {k: v.grad for k, v in osd.items() if v.grad is not None}
+        ref.update({"bert.vision_backbone." + k: v.grad for k, v in ovsd.items() if v.grad is not None})
+        got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        dot = n1 = n2 = 0.0
+        for k, r in ref.items():
+            if k not in got:
+                assert float(r.abs().max()) == 0.0, k
+                continue
+            g, r = got[k].detach().double().cpu(), r.double()
+            dot += float((g * r).sum()); n1 += float((g * g).sum()); n2 += float((r * r).sum())
+        cos = dot / math.sqrt(n1 * n2)
+        print(f"[image model {task} {prec}] loss err {e:.2e}, global grad cosine {cos:.6f}")
+        assert e <= TOL[prec] and cos >= (0.99999 if prec == "fp32" else 0.99), (task, e, cos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,out_dt", [(197 * 3, 256, 128, torch.float32), (1000, 768, 3072, torch.float32), (333, 512, 64, torch.bfloat16),
+                                          (197 * 16, 3072, 768, torch.bfloat16)])
+def test_gemm_dropout_epilogue(M, N, K, out_dt):
+    """HAMT_EPI_DROPOUT: the keep mask of element (m, n) is the one hamt_cast_pad_bf16_dropout re-creates (extracted by
+    casting ones), values are exactly {0, 1/(1-p)}, the keep rate is 1-p, dropout comes BEFORE the residual add, and with
+    GELU_GRAD both outputs carry the mask.  Covers the 4- and 8-wide epilogues and every tile height the dispatcher picks."""
+    from vln_hamt_amd import _lib as L, ops
+    dev = torch.device("cuda")
+    ops.manual_seed(11, dev)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, N, device=dev, generator=g)
+    p, cid = 0.1, ops.next_call_id()
+    mask = ops.cast_pad16_dropout(torch.ones(M, N, device=dev), p, cid)[:M].float()
+    vals = torch.unique(mask)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.9) < 5e-3
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - 0.9) < 4 * math.sqrt(0.09 / (M * N)) + 1e-3, keep
+    assert abs(float((mask[:, ::4] > 0).float().mean()) - 0.9) < 5e-3 and abs(float((mask[::3] > 0).float().mean()) - 0.9) < 5e-3
+    keepf = (mask > 0).float() / 0.9
+    base = a.float() @ w.float().t() + bias
+    # residual form (proj / fc2)
+    out = torch.empty(M, N, dtype=out_dt, device=dev)
+    ops.gemm(a, w, out, bias=bias, epilogue=L.EPI_ADD_AUX, aux=res, drop=(p, cid))
+    ref = res + keepf * base
+    tol = 2e-2 if out_dt == torch.bfloat16 else 2e-3
+    assert float((out.float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    # activation form (fc1): gelu and gelu' both masked
+    out2 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, out2, bias=bias, epilogue=L.EPI_GELU_GRAD, aux=pre, drop=(p, cid))
+    xr = base.clone().requires_grad_(True)
+    gl = torch.nn.functional.gelu(xr)
+    gl.sum().backward()
+    assert float((out2.float() - keepf * gl.detach()).abs().max()) <= 2e-2 * max(1.0, float(gl.abs().max()))
+    assert float((pre.float() - keepf * xr.grad).abs().max()) <= 2e-2
+    # another call id / another epoch -> another mask
+    m2 = ops.cast_pad16_dropout(torch.ones(M, N, device=dev), p, cid + 1)[:M].float()
+    assert float(((m2 > 0) != (mask > 0)).float().mean()) > 0.1
+    ops.advance_rng_epoch(dev)
+    m3 = ops.cast_pad16_dropout(torch.ones(M, N, device=dev), p, cid)[:M].float()
+    assert float(((m3 > 0) != (mask > 0)).float().mean()) > 0.1
+
+
+@pytest.mark.gpu
+def test_preln_blocks_with_branch_dropout_vs_torch():
+    """The fused pre-LN half blocks with proj_drop / Mlp.drop on: forward and every gradient against torch fp32 autograd
+    given the SAME masks (extracted through hamt_cast_pad_bf16_dropout with the call ids the Functions draw)."""
+    from vln_hamt_amd import blocks_preln, ops
+    dev = torch.device("cuda")
+    ops.manual_seed(5, dev)
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    B, S, D, H, I, p = 6, 197, 256, 4, 1024, 0.1
+    M = B * S
+    rn = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).requires_grad_(True)
+    x = rn(B, S, D)
+    gam, bet = rn(D), rn(D, sc=0.1)
+    with torch.no_grad():
+        gam.add_(1.0)
+    wq, bq, wp, bp = rn(3 * D, D, sc=D ** -0.5), rn(3 * D, sc=0.1), rn(D, D, sc=D ** -0.5), rn(D, sc=0.1)
+    w1, b1, w2, b2 = rn(I, D, sc=D ** -0.5), rn(I, sc=0.1), rn(D, I, sc=I ** -0.5), rn(D, sc=0.1)
+    probe = torch.randn(B, S, D, device=dev, generator=g)
+    leaves = [x, gam, bet, wq, bq, wp, bp, w1, b1, w2, b2]
+    names = "x gamma beta wqkv bqkv wproj bproj w1 b1 w2 b2".split()
+
+    def masks(cid, n):
+        return (ops.cast_pad16_dropout(torch.ones(M, n, device=dev), p, cid)[:M].float() > 0).float() / (1 - p)
+
+    def check(tag, out, ref, used):
+        e = float((out - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert e <= 1e-2, (tag, e)
+        for u in used:
+            u.grad = None
+        (out * probe).sum().backward()                      # (.backward(): weight gradients come from the deferred queue)
+        go = [u.grad.clone() for u in used]
+        gr = torch.autograd.grad((ref * probe).sum(), used, retain_graph=True)
+        for t, a, b in zip([names[[id(l) for l in leaves].index(id(u))] for u in used], go, gr):
+            ea = float((a - b).abs().max()) / max(1e-3, float(b.abs().max()))
+            assert ea <= 3e-2, (tag, t, ea)
+        print(f"[pre-LN {tag} with dropout] forward err {e:.2e}, gradients ok")
+
+    # attention half: x + drop(proj(attn(qkv(LN x))))
+    c0 = ops._call_counter[0]
+    out = blocks_preln.PreLnAttnFn.apply(x, H, 0.0, p, 1e-6, gam, bet, wq, bq, wp, bp)
+    mp = masks(c0 + 2, D)                                   # c0+1: the attention kernel's id, c0+2: proj_drop
+    ln = torch.nn.functional.layer_norm(x, (D,), gam, bet, 1e-6)
+    qkv = (ln @ wq.t() + bq).view(B, S, 3, H, D // H).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * (D // H) ** -0.5, -1)
+    cx = (att @ qkv[2]).transpose(1, 2).reshape(B, S, D)
+    ref = x + mp.view(B, S, D) * (cx @ wp.t() + bp)
+    check("attention", out, ref, [x, gam, bet, wq, bq, wp, bp])
+    # MLP half: x + drop(fc2(drop(gelu(fc1(LN x)))))
+    c0 = ops._call_counter[0]
+    out = blocks_preln.PreLnMlpFn.apply(x, p, 1e-6, gam, bet, w1, b1, w2, b2)
+    m1, m2 = masks(c0 + 1, I), masks(c0 + 2, D)
+    h = m1.view(B, S, I) * torch.nn.functional.gelu(ln @ w1.t() + b1)
+    ref = x + m2.view(B, S, D) * (h @ w2.t() + b2)
+    check("mlp", out, ref, [x, gam, bet, w1, b1, w2, b2])

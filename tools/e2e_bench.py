@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Image-input pretrain step (BASELINE config "end-to-end pretrain", one GPU): raw 224x224 views -> ViT-B/16 backbone
+(T*36 panorama views no-grad, T history views + 36 observation views with gradient) -> HAMT trunk -> loss -> backward
+-> clip 5.0 -> flat AdamW over all 261 M parameters.  The reference runs this at train_batch_size 1, max_txt_len 60
+(pretrain_r2r_e2e.json) with the 5:1:1:1:2:2 task mix; its Ralamb+Lookahead optimiser is outside the hot-path scope,
+AdamW stands in.  Eager launches.  usage: e2e_bench.py [batch=2] [steps=12]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vln_hamt_amd import ops
+from vln_hamt_amd.model.image_pretrain import MultiStepNavImagePreTraining
+from vln_hamt_amd.modeling import HamtConfig
+from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+from vln_hamt_amd.optim.misc import NO_DECAY
+from vln_hamt_amd.parallel import TaskSchedule
+from vln_hamt_amd.synth import make_batch, make_itm_rng
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+T, V, L = 5, 36, 60
+dev = torch.device("cuda", 0)
+ops.manual_seed(7, dev)
+cfg = HamtConfig(hamt_precision="bf16", pretrain_tasks={"mlm", "sap", "sar", "sprel", "mrc", "itm"})
+model = MultiStepNavImagePreTraining(cfg).to(dev).train()
+named = list(model.named_parameters())
+print(f"parameters: {sum(p.numel() for _, p in named)/1e6:.1f} M")
+opt = AdamW([{"params": [p for n, p in named if not any(nd in n for nd in NO_DECAY)], "weight_decay": 0.01},
+             {"params": [p for n, p in named if any(nd in n for nd in NO_DECAY)], "weight_decay": 0.0}], lr=5e-5, betas=(0.9, 0.98))
+opt.materialize()
+sched = TaskSchedule(cyclic=True)
+g = torch.Generator(device=dev); g.manual_seed(3)
+img = lambda *s: torch.randn(*s, device=dev, generator=g)
+batches = {}
+def get(step):
+    task = sched.task_at(step)
+    if task not in batches:
+        b = make_batch(task, B, cfg, seed=50 + step, txt_len=L, hist_len=T, mlm_exact=9 if task == "mlm" else None, device=dev)
+        n = b["txt_ids"].shape[0]
+        for k in ("hist_img_fts", "hist_pano_img_fts", "ob_img_fts"):
+            b.pop(k, None)
+        b["hist_images"], b["hist_pano_images"] = img(n, T, 3, 224, 224), img(n, T, V, 3, 224, 224)
+        if task in ("sap", "sar", "sprel"):
+            b["ob_images"], b["ob_v_exists"] = img(n, V, 3, 224, 224), torch.ones(n, V, dtype=torch.bool, device=dev)
+        if task == "itm":
+            r = make_itm_rng(b, seed=step)
+            b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+        batches[task] = b
+    return task, batches[task]
+
+def step(s):
+    task, b = get(s)
+    loss = model(b, task, True).mean()
+    loss.backward()
+    clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)
+    opt.step(); opt.zero_grad(); ops.advance_rng_epoch(dev)
+    return task, b["txt_ids"].shape[0]
+
+for s in range(12):
+    step(s)
+torch.cuda.synchronize()
+per = {}
+n_pano = 0
+t0 = time.perf_counter()
+for s in range(steps):
+    t1 = time.perf_counter()
+    task, n = step(12 + s)
+    torch.cuda.synchronize()
+    per.setdefault(task, []).append(time.perf_counter() - t1)
+    n_pano += n
+dt = time.perf_counter() - t0
+VIT_GF = 35.1
+print(f"B={B}: {steps} steps in {dt*1e3:.1f} ms = {dt/steps*1e3:.1f} ms/step, {n_pano/dt:.1f} panorama-steps/s "
+      f"({n_pano*T*V/dt:.0f} no-grad views/s + gradient views); peak HBM {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+for k, v in per.items():
+    n = batches[k]["txt_ids"].shape[0]
+    ng = n * T * V; wg = n * T + (n * V if "ob_images" in batches[k] else 0)
+    ms = sum(v) / len(v) * 1e3
+    print(f"  {k:6s} {ms:8.1f} ms/step  ({ng} no-grad + {wg} gradient views; backbone ~{(ng + 3 * wg) * VIT_GF / ms:6.1f} TFLOP/s if it were all of the step)")

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libhamt_hip.so")
 HAMT_F32, HAMT_BF16 = 0, 1
 PREC_BF16, PREC_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_ACCUM, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
-EPI_GELU_GRAD, EPI_MUL_AUX, EPI_ADD_AUX = 128, 256, 512
+EPI_GELU_GRAD, EPI_MUL_AUX, EPI_ADD_AUX, EPI_DROPOUT = 128, 256, 512, 1024
 
 vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 
@@ -23,7 +23,8 @@ vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 class GemmDesc(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldaux", i32),
                 ("a_kmajor", i32), ("b_kmajor", i32), ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
-                ("dtype_aux", i32), ("prec", i32), ("epilogue", i32), ("alpha", f32), ("ka_rows", i32), ("kb_rows", i32)]
+                ("dtype_aux", i32), ("prec", i32), ("epilogue", i32), ("alpha", f32), ("ka_rows", i32), ("kb_rows", i32),
+                ("p_drop", f32), ("call_id", u32), ("rng", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -52,6 +53,7 @@ SIGNATURES = {
     "hamt_gemm_ksplit": [C.POINTER(GemmDesc)],
     "hamt_gemm_ws": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, sz, vp],
     "hamt_cast_pad_bf16": [i32, i32, i32, i32, vp, i32, vp, i32, vp],
+    "hamt_cast_pad_bf16_dropout": [i32, i32, i32, vp, i32, vp, i32, f32, u32, vp, vp],
     "hamt_cast_transpose": [i32, i32, vp, i32, i32, vp, i32, i32, vp],
     "hamt_wgrad_grouped": [i32, C.POINTER(WgradDesc), vp, sz, vp],
     "hamt_smallk_wgrad": [i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp],

@@ -37,9 +37,10 @@ NO_SHADOW = os.environ.get("HAMT_NO_SHADOW") is not None
 
 def _zeros_or_empty(rows_total, rows_valid, cols, device, dtype=torch.bfloat16):
     """buffer whose rows >= rows_valid must read as finite zeros (reduction padding of the k-strided GEMM operands)"""
+    t = torch.empty(rows_total, cols, dtype=dtype, device=device)
     if rows_total != rows_valid:
-        return torch.zeros(rows_total, cols, dtype=dtype, device=device)
-    return torch.empty(rows_total, cols, dtype=dtype, device=device)
+        t[rows_valid:].zero_()
+    return t
 
 
 def _x16_of(x, x2):

@@ -8,7 +8,9 @@ wants.  LayerNorm emits ONLY the bf16 image of its output (no fp32 y, no copy of
 what backward needs); the residual add rides in the last GEMM's epilogue (HAMT_EPI_ADD_AUX); GELU and its derivative come
 from one erf evaluation in fc1's epilogue; in backward the residual gradient is added inside the LayerNorm-backward
 kernel (hamt_ln_bwd_add); weight / bias gradients are queued for the grouped end-of-pass launch (wgrad.py).
-Used when the branch dropouts (proj_drop / mlp drop) are off; attention-probability dropout is handled in the kernel.
+The branch dropouts (proj_drop, Mlp.drop after the activation and after fc2) ride in the producing GEMM's epilogue
+(HAMT_EPI_DROPOUT); backward re-creates the mask while casting dy to its bf16 operand image (hamt_cast_pad_bf16_dropout),
+and the post-activation mask is folded into the stored gelu'.  Attention-probability dropout is handled in the kernel.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import torch
 
 from . import _lib as L
 from .blocks import _attn_desc, _wgrad, _zeros_or_empty
-from .ops import _p, _rup, _stream, cast_pad16, gemm, next_call_id, rng_state, weight_operand
+from .ops import _p, _rup, _stream, cast_pad16, cast_pad16_dropout, gemm, next_call_id, rng_state, weight_operand
 
 
 def _ln16(x2, gamma, beta, eps):
@@ -48,7 +50,7 @@ def _ln_bwd_add(dln, x2, mean, rstd, gamma, eps, dy2):
 
 class PreLnAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, heads, p_attn, eps, gamma, beta, wqkv, bqkv, wproj, bproj):
+    def forward(ctx, x, heads, p_attn, p_proj, eps, gamma, beta, wqkv, bqkv, wproj, bproj):
         B, S, D = x.shape
         M = B * S
         dev = x.device
@@ -66,20 +68,21 @@ class PreLnAttnFn(torch.autograd.Function):
         L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), None, _p(ctx16), _p(lse), _p(rng_state(dev)), _stream()),
                 "hamt_attn_small_fwd")
         y = torch.empty(M, D, dtype=torch.float32, device=dev)
-        gemm(ctx16[:M], weight_operand(wproj, "bf16"), y, bias=bproj.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach())
+        cid_p = next_call_id() if p_proj > 0.0 else 0
+        gemm(ctx16[:M], weight_operand(wproj, "bf16"), y, bias=bproj.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach(), drop=(p_proj, cid_p))
         ctx.save_for_backward(x2, y16, qkv16, ctx16, lse, mean, rstd, gamma, wqkv, bqkv, wproj, bproj)
-        ctx.meta = (B, S, D, M, heads, float(p_attn), float(eps), cid)
+        ctx.meta = (B, S, D, M, heads, float(p_attn), float(eps), cid, float(p_proj), cid_p)
         return y.view(B, S, D)
 
     @staticmethod
     def backward(ctx, dy):
         x2, y16, qkv16, ctx16, lse, mean, rstd, gamma, wqkv, bqkv, wproj, bproj = ctx.saved_tensors
-        B, S, D, M, heads, p_attn, eps, cid = ctx.meta
+        B, S, D, M, heads, p_attn, eps, cid, p_proj, cid_p = ctx.meta
         dev = dy.device
         Mp = y16.shape[0]
         dy2 = dy.reshape(M, D)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dy16 = cast_pad16(dy2, D)
+        dy16 = cast_pad16_dropout(dy2, p_proj, cid_p) if p_proj > 0.0 else cast_pad16(dy2, D)
         dctx16 = torch.empty(Mp, D, dtype=torch.bfloat16, device=dev)
         gemm(dy16[:M], weight_operand(wproj, "bf16"), dctx16[:M], b_kmajor=True)
         dwp, dbp = _wgrad(wproj, bproj, dy16, ctx16, M)
@@ -93,12 +96,12 @@ class PreLnAttnFn(torch.autograd.Function):
         gemm(dqkv16[:M], weight_operand(wqkv, "bf16"), dln, b_kmajor=True)
         dwq, dbq = _wgrad(wqkv, bqkv, dqkv16, y16, M)
         dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2)
-        return dx.view(B, S, D), None, None, None, dgamma, dbeta, dwq, dbq, dwp, dbp
+        return dx.view(B, S, D), None, None, None, None, dgamma, dbeta, dwq, dbq, dwp, dbp
 
 
 class PreLnMlpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, gamma, beta, w1, b1, w2, b2):
+    def forward(ctx, x, p_drop, eps, gamma, beta, w1, b1, w2, b2):
         shp = x.shape
         D = shp[-1]
         x2 = x.reshape(-1, D)
@@ -110,32 +113,33 @@ class PreLnMlpFn(torch.autograd.Function):
         Mp = y16.shape[0]
         g16 = _zeros_or_empty(Mp, M, I, dev)
         pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(fc1), from the same erf evaluation as gelu
-        gemm(y16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre)
+        cid1, cid2 = (next_call_id(), next_call_id()) if p_drop > 0.0 else (0, 0)
+        gemm(y16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre, drop=(p_drop, cid1))
         y = torch.empty(M, D, dtype=torch.float32, device=dev)
-        gemm(g16[:M], weight_operand(w2, "bf16"), y, bias=b2.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach())
+        gemm(g16[:M], weight_operand(w2, "bf16"), y, bias=b2.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach(), drop=(p_drop, cid2))
         ctx.save_for_backward(x2, y16, g16, pre, mean, rstd, gamma, w1, b1, w2, b2)
-        ctx.meta = (shp, M, D, I, float(eps))
+        ctx.meta = (shp, M, D, I, float(eps), float(p_drop), cid2)
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, y16, g16, pre, mean, rstd, gamma, w1, b1, w2, b2 = ctx.saved_tensors
-        shp, M, D, I, eps = ctx.meta
+        shp, M, D, I, eps, p_drop, cid2 = ctx.meta
         dev = dy.device
         Mp = y16.shape[0]
         dy2 = dy.reshape(M, D)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dy16 = cast_pad16(dy2, D)
+        dy16 = cast_pad16_dropout(dy2, p_drop, cid2) if p_drop > 0.0 else cast_pad16(dy2, D)
         dh16 = _zeros_or_empty(Mp, M, I, dev)
-        gemm(dy16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_AUX, aux=pre)       # dG * gelu'
+        gemm(dy16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_AUX, aux=pre)       # dG * (masked) gelu'
         dw2, db2 = _wgrad(w2, b2, dy16, g16, M)
         dln = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(dh16[:M], weight_operand(w1, "bf16"), dln, b_kmajor=True)
         dw1, db1 = _wgrad(w1, b1, dh16, y16, M)
         dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2)
-        return dx.view(shp), None, dgamma, dbeta, dw1, db1, dw2, db2
+        return dx.view(shp), None, None, dgamma, dbeta, dw1, db1, dw2, db2
 
 
-def usable(prec: str, x: torch.Tensor, *drops) -> bool:
+def usable(prec: str, x: torch.Tensor) -> bool:
     from . import blocks
-    return blocks.ENABLED and prec == "bf16" and x.is_cuda and x.shape[-1] % 64 == 0 and all(p == 0.0 for p in drops)
+    return blocks.ENABLED and prec == "bf16" and x.is_cuda and x.shape[-1] % 64 == 0

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(Attn16Args a) {
   }
   const RngKey key = rng_key(a.rng, d.call_id);
   const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + qrow) ^ key.k0);   // same mask stream as the single-pass kernels
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 of[4];
 #pragma unroll
@@ -169,15 +170,16 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(Attn16Args a) {
       float rs = 0.f;
       float p[4][4];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < 4; ++kb) {
+        float ds4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (d.p_drop > 0.f) drop_scale4(key, rowh, (uint32_t)((k0 + 16 * kb + 4 * g) >> 2), d.p_drop, inv_keep, ds4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float e = (kb < nkb) ? expf(sf[kb][r] - mn) : 0.f;
+          const float e = (kb < nkb) ? expf(sf[kb][r] - mn) : 0.f;
           rs += e;
-          if (d.p_drop > 0.f)
-            e *= drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + qrow) * d.Sk + (k0 + 16 * kb + 4 * g + r), d.p_drop, inv_keep);
-          p[kb][r] = e;
+          p[kb][r] = e * ds4[r];
         }
+      }
       l_run = l_run * alpha + xg_sum(rs);
 #pragma unroll
       for (int db = 0; db < 4; ++db)
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(Attn16Args a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) { qf[s] = rfrag(Qs, ql, 32 * s + 8 * g); df[s] = rfrag(dOs, ql, 32 * s + 8 * g); }
         const float lse_q = lse_s[ql], delta_q = delta_s[ql];
+        const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + qq) ^ key.k0);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           if (kb >= nkb && kb < ((nkb + 1) & ~1)) {   // the 32-wide k-step of dQ also reads this (all-padding) key block
@@ -274,6 +277,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(Attn16Args a) {
               sf = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s + 8 * g), qf[s], sf);      // S^T[key][q]
               dpf = MFMA16(rfrag(Vs, 16 * kb + l15, 32 * s + 8 * g), df[s], dpf);    // dP^T[key][q] = V dO^T
             }
+            float ds4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (d.p_drop > 0.f) drop_scale4(key, rowh, (uint32_t)((k0 + 16 * kb + 4 * g) >> 2), d.p_drop, inv_keep, ds4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int kl = 16 * kb + 4 * g + r, kk = k0 + kl;
@@ -281,8 +286,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(Attn16Args a) {
               if (kk < d.Sk && qq < d.Sq) {
                 const float mk = a.mask ? a.mask[(size_t)b * d.Sk + kk] : 0.f;
                 const float p = expf(sf[r] * d.scale + mk - lse_q);
-                float dsc = 1.0f;
-                if (d.p_drop > 0.f) dsc = drop_scale(key, ((uint64_t)(b * d.heads + h) * d.Sq + qq) * d.Sk + kk, d.p_drop, inv_keep);
+                const float dsc = ds4[r];
                 pd = p * dsc;
                 ds = p * (dpf[r] * dsc - delta_q) * d.scale;
               }
@@ -433,7 +437,9 @@ __device__ __forceinline__ void stage_mask(const float* mask, int b, int Sk, int
   for (int i = t; i < sk16; i += nt) mk_s[i] = i < Sk ? (mask ? mask[(size_t)b * Sk + i] : 0.f) : -INFINITY;
 }
 
-template <typename TI, typename TO, int KB>   // KB: number of 16-key blocks staged and processed (2, 4, 6, 8) >= ceil(Sk / 16)
+// KB: number of 16-key blocks staged and processed (even, <= 16) >= ceil(Sk / 16); IT: staging pieces per thread and matrix.
+// One workgroup per (head, batch row, chunk of 128 queries): any Sq, Sk <= 256.
+template <typename TI, typename TO, int KB, int IT>
 __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   const hamt_attn_desc& d = a.d;
@@ -446,20 +452,21 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
   const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
   const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
-  Raw8<TI> rk[2], rv[2];                               // the launcher guarantees 8 * SKP <= 2 * nt
-  rows_load<TI, 2>(K, d.ldk, d.Sk, t, nt, rk);
-  rows_load<TI, 2>(V, d.ldv, d.Sk, t, nt, rv);
-  const int qrow = 16 * w + l15;                       // the ONE query row this lane owns
+  Raw8<TI> rk[IT], rv[IT];                             // the launcher guarantees 8 * SKP <= IT * nt
+  rows_load<TI, IT>(K, d.ldk, d.Sk, t, nt, rk);
+  rows_load<TI, IT>(V, d.ldv, d.Sk, t, nt, rv);
+  const int q0 = 128 * blockIdx.z;
+  const int qrow = q0 + 16 * w + l15;                  // the ONE query row this lane owns
   const bool qok = qrow < d.Sq;
   bf16x8 qf[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)   // clamped, not branched (rows >= Sq are never stored)
     qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : d.Sq - 1) * d.ldq + 32 * s + 8 * g);
   stage_mask(a.mask, b, d.Sk, SKP, mk_s, t, nt);
-  rows_store<TI, 2>(rk, SKP, Ks, t, nt);
-  rows_store<TI, 2>(rv, SKP, Vs, t, nt);
+  rows_store<TI, IT>(rk, SKP, Ks, t, nt);
+  rows_store<TI, IT>(rv, SKP, Vs, t, nt);
   __syncthreads();
-  if (16 * w >= d.Sq) return;                          // waves that only helped staging (no barrier below)
+  if (q0 + 16 * w >= d.Sq || w >= 8) return;           // waves that only helped staging (no barrier below)
   const RngKey key = rng_key(a.rng, d.call_id);
   const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
   const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + qrow) ^ key.k0);
@@ -641,18 +648,37 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   }
 }
 
+template <typename TI, typename TO, int KB, int IT>
+void launch_s128_fwd_kb(const Attn16Args& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  static bool raised = false;                      // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (lds > 64 * 1024 && !raised) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_s128_fwd_kernel<TI, TO, KB, IT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, KB, IT>), grid, block, lds, s, a);
+}
+
 template <typename TI, typename TO>
 void launch_s128_fwd(const Attn16Args& a, hipStream_t s) {
   const hamt_attn_desc& d = a.d;
   const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16;
-  const int kb = nkb <= 2 ? 2 : nkb <= 4 ? 4 : nkb <= 6 ? 6 : 8;
-  const int nw = nqb > kb ? nqb : kb;                  // >= 4 threads per staged key row: 2 pieces per thread and matrix
-  const dim3 grid(d.heads, d.B), block(64 * nw);
+  const int kb = nkb <= 2 ? 2 : (nkb + 1) & ~1;
+  const int it = kb > 8 ? 4 : 2;
+  const int need = 2 * kb / it;                        // waves that make 8 * 16 kb staging pieces = it per thread
+  const int nqw = nqb < 8 ? nqb : 8;                   // one wave per 16 queries of the chunk
+  const int nw = nqw > need ? nqw : need;
+  const dim3 grid(d.heads, d.B, (d.Sq + 127) / 128), block(64 * nw);
   const size_t lds = (size_t)2 * kb * 16 * AST * sizeof(bf16_t) + (size_t)kb * 16 * sizeof(float);
-  if (kb == 2) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 2>), grid, block, lds, s, a);
-  else if (kb == 4) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 4>), grid, block, lds, s, a);
-  else if (kb == 6) hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 6>), grid, block, lds, s, a);
-  else hipLaunchKernelGGL((attn_s128_fwd_kernel<TI, TO, 8>), grid, block, lds, s, a);
+  switch (kb) {
+    case 2: launch_s128_fwd_kb<TI, TO, 2, 2>(a, grid, block, lds, s); break;
+    case 4: launch_s128_fwd_kb<TI, TO, 4, 2>(a, grid, block, lds, s); break;
+    case 6: launch_s128_fwd_kb<TI, TO, 6, 2>(a, grid, block, lds, s); break;
+    case 8: launch_s128_fwd_kb<TI, TO, 8, 2>(a, grid, block, lds, s); break;
+    case 10: launch_s128_fwd_kb<TI, TO, 10, 4>(a, grid, block, lds, s); break;
+    case 12: launch_s128_fwd_kb<TI, TO, 12, 4>(a, grid, block, lds, s); break;
+    case 14: launch_s128_fwd_kb<TI, TO, 14, 4>(a, grid, block, lds, s); break;
+    default: launch_s128_fwd_kb<TI, TO, 16, 4>(a, grid, block, lds, s); break;
+  }
 }
 
 template <typename TI, typename TO, int NB>
@@ -678,7 +704,15 @@ void launch_s128_bwd(const Attn16Args& a, hipStream_t s) {
   else launch_s128_bwd_nb<TI, TO, 8>(a, grid, block, lds, s);
 }
 
-bool use_s128(const hamt_attn_desc* d) {
+// single-pass forward: every key of a head in LDS and one score row in registers (any Sq, in chunks of 128 queries);
+// backward: the whole head's P~ / dS in LDS.  Both draw the same dropout masks as the tiled kernels, so the forward of
+// one family and the backward of the other form a valid pair (ViT: S = 197).
+bool use_s128_fwd(const hamt_attn_desc* d) {
+  static const bool off = getenv("HAMT_NO_ATTN_S128") != nullptr;
+  static const bool off_wide = getenv("HAMT_NO_ATTN_WIDE") != nullptr;
+  return !off && d->Sk <= (off_wide ? 128 : 256) && (d->Sq <= 128 || !off_wide);
+}
+bool use_s128_bwd(const hamt_attn_desc* d) {
   static const bool off = getenv("HAMT_NO_ATTN_S128") != nullptr;
   return !off && d->Sq <= 128 && d->Sk <= 128;
 }
@@ -690,7 +724,7 @@ void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* 
   Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng};
   dim3 grid((d->Sq + T64 - 1) / T64, d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
-  if (use_s128(d)) {
+  if (use_s128_fwd(d)) {
     if (!ib && !ob) launch_s128_fwd<float, float>(a, s);
     else if (ib && ob) launch_s128_fwd<bf16_t, bf16_t>(a, s);
     else if (ib) launch_s128_fwd<bf16_t, float>(a, s);
@@ -708,7 +742,7 @@ void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* 
   Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng};
   dim3 grid(d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
-  if (use_s128(d)) {
+  if (use_s128_bwd(d)) {
     if (!ib && !ob) launch_s128_bwd<float, float>(a, s);
     else if (ib && ob) launch_s128_bwd<bf16_t, bf16_t>(a, s);
     else if (ib) launch_s128_bwd<bf16_t, float>(a, s);

@@ -155,6 +155,27 @@ __global__ void cast_pad_kernel(int R, int C, int Rpad, int Cpad, const float* _
     *(uint4*)(y + (size_t)r * ldy + c) = o;
   }
 }
+__global__ void cast_pad_dropout_kernel(int R, int C, int Rpad, const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, float p,
+                                        uint32_t call_id, const uint64_t* __restrict__ rng) {
+  const RngKey key = rng_key(rng, call_id);
+  const float inv_keep = 1.0f / (1.0f - p);
+  const int c8 = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)Rpad * c8; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c8), c = (int)(i % c8) * 8;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R) {
+      const float* xr = x + (size_t)r * ldx + c;
+      float v[8], f0[4], f1[4];
+      if ((((uintptr_t)xr) & 15) == 0) { const float4 a = *(const float4*)xr, b = *(const float4*)(xr + 4); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+      else for (int j = 0; j < 8; ++j) v[j] = xr[j];
+      const uint32_t rowh = hamt_mix32((uint32_t)r ^ key.k0);
+      drop_scale4(key, rowh, (uint32_t)(c >> 2), p, inv_keep, f0);
+      drop_scale4(key, rowh, (uint32_t)(c >> 2) + 1u, p, inv_keep, f1);
+      o = make_uint4(pack_bf2(v[0] * f0[0], v[1] * f0[1]), pack_bf2(v[2] * f0[2], v[3] * f0[3]), pack_bf2(v[4] * f1[0], v[5] * f1[1]), pack_bf2(v[6] * f1[2], v[7] * f1[3]));
+    }
+    *(uint4*)(y + (size_t)r * ldy + c) = o;
+  }
+}
 __global__ void fill_where_zero_kernel(size_t n, const int64_t* __restrict__ flag, float* __restrict__ x, float value) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     if (flag[i] == 0) x[i] = value;
@@ -318,6 +339,14 @@ extern "C" int hamt_cast_pad_bf16(int R, int C, int Rpad, int Cpad, const float*
   if (Rpad == 0 || Cpad == 0) return HAMT_OK;
   hipLaunchKernelGGL(cast_pad_kernel, dim3(nblocks((size_t)Rpad * Cpad / 8)), dim3(256), 0, as_stream(stream), R, C, Rpad, Cpad, x, ldx, (bf16_t*)y, ldy);
   HAMT_CHECK_LAUNCH("hamt_cast_pad_bf16");
+  return HAMT_OK;
+}
+extern "C" int hamt_cast_pad_bf16_dropout(int R, int C, int Rpad, const float* x, int ldx, void* y, int ldy, float p, uint32_t call_id,
+                                          const uint64_t* rng, void* stream) {
+  HAMT_CHECK_ARG(x && y && rng && C % 8 == 0 && Rpad >= R && ldy >= C && ldy % 8 == 0 && p >= 0.0f && p < 1.0f, "hamt_cast_pad_bf16_dropout: bad argument");
+  if (Rpad == 0 || C == 0) return HAMT_OK;
+  hipLaunchKernelGGL(cast_pad_dropout_kernel, dim3(nblocks((size_t)Rpad * C / 8)), dim3(256), 0, as_stream(stream), R, C, Rpad, x, ldx, (bf16_t*)y, ldy, p, call_id, rng);
+  HAMT_CHECK_LAUNCH("hamt_cast_pad_bf16_dropout");
   return HAMT_OK;
 }
 extern "C" int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, void* stream) {

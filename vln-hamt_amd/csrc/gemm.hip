@@ -430,6 +430,10 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
   HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
   HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
   HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX | HAMT_EPI_ADD_AUX)) || aux, "hamt_gemm: epilogue needs aux");
+  if (d->epilogue & HAMT_EPI_DROPOUT) {
+    HAMT_CHECK_ARG(d->rng && d->p_drop >= 0.0f && d->p_drop < 1.0f, "hamt_gemm: EPI_DROPOUT needs rng and 0 <= p_drop < 1");
+    HAMT_CHECK_ARG(getenv("HAMT_NO_FAST") == nullptr && hamt_gemm_fast_eligible(d, A, B), "hamt_gemm: EPI_DROPOUT is implemented by the bf16 MFMA path only (bf16 operands, K %% 64 == 0)");
+  }
   const int ka = (d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K, kb = (d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K;
   GemmArgs g{d->M, d->N, d->K, d->lda, d->ldb, ka, kb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha, A, B, C, bias, aux};
   hipStream_t s = as_stream(stream);

@@ -41,6 +41,9 @@ struct GemmArgsF {
   int ksplit;      // number of K slices (grid.y); > 1 => raw fp32 partials to `part`
   float* part;
   int ka_max, kb_max;   // last valid reduction row of a K-strided A / B (rows beyond are clamped to it)
+  float p_drop;         // HAMT_EPI_DROPOUT
+  uint32_t call_id;
+  const uint64_t* rng;
 };
 
 namespace {
@@ -179,9 +182,22 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
     else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(v[j]); else ((float*)g.aux)[ia + j] = v[j]; }
   }
   if (epi & HAMT_EPI_GELU) { for (int j = 0; j < W; ++j) v[j] = gelu_erf(v[j]); }
+  float keep[W];
+  if (epi & HAMT_EPI_DROPOUT) {   // col % 4 == 0: W / 4 groups of the row's mask stream
+    const RngKey key = rng_key(g.rng, g.call_id);
+    const uint32_t rowh = hamt_mix32((uint32_t)row ^ key.k0);
+    const float inv_keep = 1.0f / (1.0f - g.p_drop);
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      float f[4];
+      drop_scale4(key, rowh, (uint32_t)(col >> 2) + q, g.p_drop, inv_keep, f);
+      for (int j = 0; j < 4; ++j) keep[q * 4 + j] = f[j];
+    }
+  }
   if (epi & HAMT_EPI_GELU_GRAD) {
     float dg[W];
     for (int j = 0; j < W; ++j) gelu_and_grad(v[j], v[j], dg[j]);
+    if (epi & HAMT_EPI_DROPOUT) for (int j = 0; j < W; ++j) dg[j] *= keep[j];
     if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, dg); else st_f<W>((float*)g.aux + ia, dg); }
     else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]); else ((float*)g.aux)[ia + j] = dg[j]; }
   }
@@ -193,6 +209,7 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
       v[j] *= (epi & HAMT_EPI_MUL_AUX) ? h[j] : ((epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h[j]) : (h[j] > 0.0f ? 1.0f : 0.0f));
   }
   if (epi & HAMT_EPI_RELU) { for (int j = 0; j < W; ++j) v[j] = fmaxf(v[j], 0.0f); }
+  if (epi & HAMT_EPI_DROPOUT) { for (int j = 0; j < W; ++j) v[j] *= keep[j]; }
   if (epi & HAMT_EPI_ADD_AUX) {   // residual add
     float h[W];
     if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
@@ -448,6 +465,9 @@ bool launch_256(const GemmArgsF& g, hipStream_t s) {
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
   else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT);
   else return false;
 #undef HAMT_L
   return true;
@@ -466,6 +486,8 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
   else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT);
   else HAMT_L(-1);
 #undef HAMT_L
 }
@@ -515,7 +537,8 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
                            float* ws, size_t ws_bytes, hipStream_t s) {
   GemmArgsF g{d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->ldaux, d->dtype_c, d->dtype_aux, d->epilogue, d->alpha,
               (const bf16_t*)A, (const bf16_t*)B, C, bias, aux, 1, nullptr,
-              ((d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K) - 1, ((d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K) - 1};
+              ((d->ka_rows > 0 && d->ka_rows < d->K) ? d->ka_rows : d->K) - 1, ((d->kb_rows > 0 && d->kb_rows < d->K) ? d->kb_rows : d->K) - 1,
+              d->p_drop, d->call_id, d->rng};
   const int ks = ws ? hamt_gemm_fast_ksplit(d, ws_bytes) : 1;
   const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   static const int force_bm = getenv("HAMT_FAST_BM") ? atoi(getenv("HAMT_FAST_BM")) : 0;

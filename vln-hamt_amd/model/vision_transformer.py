@@ -93,11 +93,11 @@ class Block(nn.Module):
         a, m = self.attn, self.mlp
         pd = float(a.proj_drop.p) if self.training else 0.0
         md = float(m.drop.p) if self.training else 0.0
-        if x.dim() == 3 and blocks_preln.usable(a.prec, x, pd, md):       # one autograd Function per half block
+        if x.dim() == 3 and blocks_preln.usable(a.prec, x):       # one autograd Function per half block
             pa = float(a.attn_drop.p) if self.training else 0.0
-            x = blocks_preln.PreLnAttnFn.apply(x, a.num_heads, pa, self.norm1.eps, self.norm1.weight, self.norm1.bias,
+            x = blocks_preln.PreLnAttnFn.apply(x, a.num_heads, pa, pd, self.norm1.eps, self.norm1.weight, self.norm1.bias,
                                                a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias)
-            return blocks_preln.PreLnMlpFn.apply(x, self.norm2.eps, self.norm2.weight, self.norm2.bias,
+            return blocks_preln.PreLnMlpFn.apply(x, md, self.norm2.eps, self.norm2.weight, self.norm2.bias,
                                                  m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
         x = self.attn(ops.layer_norm(x, None, self.norm1, want16=True), residual=x)
         return self.mlp(ops.layer_norm(x, None, self.norm2, want16=True), residual=x)

@@ -103,8 +103,9 @@ def _operand(t: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------ raw GEMM
 def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, aux=None, prec="bf16", alpha=1.0,
-         k_red=None):
-    """out[M,N] = epi(alpha * op(a) @ op(b)); 2-D views with unit inner stride (strided rows allowed)."""
+         k_red=None, drop=None):
+    """out[M,N] = epi(alpha * op(a) @ op(b)); 2-D views with unit inner stride (strided rows allowed).
+    drop = (p, call_id): HAMT_EPI_DROPOUT on the epilogue value (before the residual add)."""
     _chk(a, "gemm")
     a, b = _operand(a), _operand(b)
     M, N = out.shape
@@ -119,7 +120,10 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, au
         assert a.dtype == torch.float32 and b.dtype == torch.float32
     d = L.GemmDesc(M, N, K, _ld(a), _ld(b), _ld(out), _ld(aux) if aux is not None else 0, int(a_kmajor), int(b_kmajor),
                    _dt(a), _dt(b), _dt(out), _dt(aux) if aux is not None else 0, _prec(prec),
-                   epilogue | (L.EPI_BIAS if bias is not None else 0), alpha, ka if ka < K else 0, kb if kb < K else 0)
+                   epilogue | (L.EPI_BIAS if bias is not None else 0), alpha, ka if ka < K else 0, kb if kb < K else 0, 0.0, 0, None)
+    if drop is not None and drop[0] > 0.0:
+        d.epilogue |= L.EPI_DROPOUT
+        d.p_drop, d.call_id, d.rng = float(drop[0]), int(drop[1]), rng_state(out.device).data_ptr()
     lib = L.load()
     ks = 1
     if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16:
@@ -186,6 +190,17 @@ def cast_pad16(x2: torch.Tensor, cpad: Optional[int] = None, rpad: Optional[int]
         x2 = x2.contiguous()
     y = torch.empty(rpad, cpad, dtype=torch.bfloat16, device=x2.device)
     L.check(L.load().hamt_cast_pad_bf16(R, Cc, rpad, cpad, _p(x2), _ld(x2), _p(y), cpad, _stream()), "hamt_cast_pad_bf16")
+    return y
+
+
+def cast_pad16_dropout(x2: torch.Tensor, p: float, call_id: int) -> torch.Tensor:
+    """bf16 [Rpad,C] image of x2 * keep-mask of the HAMT_EPI_DROPOUT GEMM with the same call id (C % 8 == 0)."""
+    R, Cc = x2.shape
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty(_rup(R), Cc, dtype=torch.bfloat16, device=x2.device)
+    L.check(L.load().hamt_cast_pad_bf16_dropout(R, Cc, y.shape[0], _p(x2), _ld(x2), _p(y), Cc, float(p), int(call_id),
+                                                _p(rng_state(x2.device)), _stream()), "hamt_cast_pad_bf16_dropout")
     return y
 
 
