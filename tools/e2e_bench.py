@@ -3,7 +3,7 @@
 (T*36 panorama views no-grad, T history views + 36 observation views with gradient) -> HAMT trunk -> loss -> backward
 -> clip 5.0 -> flat AdamW over all 261 M parameters.  The reference runs this at train_batch_size 1, max_txt_len 60
 (pretrain_r2r_e2e.json) with the 5:1:1:1:2:2 task mix; its Ralamb+Lookahead optimiser is outside the hot-path scope,
-AdamW stands in.  Eager launches.  usage: e2e_bench.py [batch=2] [steps=12]"""
+AdamW stands in.  usage: e2e_bench.py [batch=2] [steps=12] [graph]   (graph: whole-step hipGraph replay per task)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +17,7 @@ from vln_hamt_amd.synth import make_batch, make_itm_rng
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+use_graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
 T, V, L = 5, 36, 60
 dev = torch.device("cuda", 0)
 ops.manual_seed(7, dev)
@@ -47,8 +48,16 @@ def get(step):
         batches[task] = b
     return task, batches[task]
 
+graphed = None
+if use_graph:
+    from vln_hamt_amd.graph import GraphedTrainStep
+    graphed = GraphedTrainStep(model, opt, max_grad_norm=5.0)
+
 def step(s):
     task, b = get(s)
+    if graphed is not None:
+        graphed.step(task, b, task)
+        return task, b["txt_ids"].shape[0]
     loss = model(b, task, True).mean()
     loss.backward()
     clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)
@@ -69,7 +78,7 @@ for s in range(steps):
     n_pano += n
 dt = time.perf_counter() - t0
 VIT_GF = 35.1
-print(f"B={B}: {steps} steps in {dt*1e3:.1f} ms = {dt/steps*1e3:.1f} ms/step, {n_pano/dt:.1f} panorama-steps/s "
+print(f"B={B}{' (hipGraph replay)' if use_graph else ''}: {steps} steps in {dt*1e3:.1f} ms = {dt/steps*1e3:.1f} ms/step, {n_pano/dt:.1f} panorama-steps/s "
       f"({n_pano*T*V/dt:.0f} no-grad views/s + gradient views); peak HBM {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 for k, v in per.items():
     n = batches[k]["txt_ids"].shape[0]
