@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0          # HBM3E peak, same guide
 H, FFN, L_TXT, T_HIST, V = 768, 3072, 80, 5, 36
 
 
@@ -126,6 +127,61 @@ def time_gemm_family(model, cfg, batch, device, iters=5):
     return {"kernel": f"gemm_fast_kernel<64|128, BIAS, NT>: the {len(calls)} forward projection GEMMs of one SAP pass, B={batch} (eager re-issue: "
                       "includes host launch gaps for the small ones)", "achieved": round(tf, 2), "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / max(1, len(calls)), 2)}
+
+
+def time_xattn_probe(batch, device, reps=20):
+    """The cross-modal attention kernels (vilmodel.py:327-348 inside the x-layers) at the step's own shapes: text queries over
+    the 6 history + 37 observation tokens and the reverse, 12 heads of 64, bf16, dropout 0.1, key mask.  They are HBM /
+    latency bound (40 flop per byte: the MFMA roofline is out of reach by construction), so the bound is HBM:
+    algorithmic bytes = Q + K + V + O (+ dO, dQ, dK, dV for backward) once each.  Timed as a hipGraph of `reps` launches
+    (an eager loop would measure the host's launch rate)."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as Lb, ops
+    lib, p = Lb.load(), ops._p
+    rng = ops.rng_state(device)
+    res = {}
+    st = torch.cuda.Stream()
+    for name, Sq, Sk in (("text<-vision", L_TXT, T_HIST + 1 + V + 1), ("vision<-text", T_HIST + 1 + V + 1, L_TXT)):
+        q = torch.randn(batch * Sq, H, device=device).to(torch.bfloat16)
+        kv = torch.randn(batch * Sk, 2 * H, device=device).to(torch.bfloat16)
+        k, v = kv[:, :H], kv[:, H:]
+        o, do = torch.empty_like(q), torch.randn(batch * Sq, H, device=device).to(torch.bfloat16)
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        lse = torch.empty(batch * 12 * Sq, device=device)
+        mask = torch.zeros(batch, Sk, device=device)
+        d = Lb.AttnDesc(batch, 12, Sq, Sk, 64, H, 2 * H, 2 * H, H, Lb.HAMT_BF16, Lb.HAMT_BF16, 0.125, 0.1, 7, Lb.PREC_BF16)
+
+        def fwd():
+            Lb.check(lib.hamt_attn_small_fwd(C.byref(d), p(q), p(k), p(v), p(mask), p(o), p(lse), p(rng), ops._stream()), "attn fwd")
+
+        def bwd():
+            Lb.check(lib.hamt_attn_small_bwd(C.byref(d), p(q), p(k), p(v), p(mask), p(o), p(do), p(lse), None, p(dq), p(dkv[:, :H]),
+                                             p(dkv[:, H:]), p(rng), ops._stream()), "attn bwd")
+        nb_f = 2.0 * (2 * q.numel() + kv.numel())
+        nb_b = 2.0 * (4 * q.numel() + 2 * kv.numel())
+        for tag, fn, nbytes in (("fwd", fwd, nb_f), ("bwd", bwd, nb_b)):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                fn()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    for _ in range(reps):
+                        fn()
+                g.replay()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(st)
+                for _ in range(5):
+                    g.replay()
+                e.record(st)
+                torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 1e3 / (5 * reps)
+            flops = 4.0 * batch * 12 * Sq * Sk * 64 * (1.0 if tag == "fwd" else 2.5)
+            res[f"{name} {tag}"] = {"Sq": Sq, "Sk": Sk, "avg_launch_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
+                                    "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "tflops": round(flops / us / 1e6, 1)}
+    return {"kernel": f"attn_s128_fwd/bwd_kernel (x-layer cross attention, B={batch}, 12 heads x 64, bf16, dropout 0.1)", "bound": "hbm",
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "cases": res}
 
 
 def time_wgrad_roofline(model, cfg, batch, device, iters=10):
@@ -239,7 +295,7 @@ def main():
     from vln_hamt_amd import ops
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
-    from vln_hamt_amd.parallel import (OverlappedGradSync, TaskSchedule, allreduce_grads, barrier, broadcast_params, init_distributed,
+    from vln_hamt_amd.parallel import (OverlappedGradSync, TaskSchedule, allreduce_grads, barrier, broadcast_params, default_wire, init_distributed,
                                        max_over_ranks, sum_over_ranks)
     from vln_hamt_amd.synth import make_batch, make_itm_rng
 
@@ -263,7 +319,8 @@ def main():
     # gradient exchange: flat-arena RCCL all-reduces, range by range behind the grouped weight-gradient GEMMs
     grad_sync = None
     if dist_on:
-        grad_sync = allreduce_grads if os.environ.get("HAMT_NO_OVERLAP") else OverlappedGradSync(opt, n_groups=4)
+        wire = default_wire(args.prec)                  # bf16 mode: bf16 on the wire (DDP bf16_compress_hook arithmetic)
+        grad_sync = (lambda o: allreduce_grads(o, wire)) if os.environ.get("HAMT_NO_OVERLAP") else OverlappedGradSync(opt, n_groups=int(os.environ.get("HAMT_SYNC_GROUPS", 4)), wire=wire)
     net = model
 
     sched = TaskSchedule(cyclic=True) if args.task == "mix" else None
@@ -353,7 +410,7 @@ def main():
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
-                       "parallelism": f"dp{world}" + (" (flat-arena RCCL all-reduce" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
+                       "parallelism": f"dp{world}" + (f" (flat-arena RCCL all-reduce, {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
                        "launch": "hipGraph replay" if graphed is not None else "eager"},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
@@ -364,6 +421,7 @@ def main():
         out["roofline"]["traffic"] = WGRAD_TRAFFIC_BYTES.get(args.batch)
         out["roofline_probe_ffn1"] = time_gemm_probe(args.batch, device)
         out["roofline_probe_fwd_gemms"] = time_gemm_family(model, cfg, args.batch, device)
+        out["roofline_probe_xattn"] = time_xattn_probe(args.batch, device)
         log("roofline probe done; timing the CPU oracle baseline")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)

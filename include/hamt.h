@@ -225,6 +225,11 @@ int hamt_patchify(int N, int C, int H, int W, int P, const float* x, void* y, in
 int hamt_add3(size_t n, const float* a, const float* b, const float* c, float* out, void* stream);
 int hamt_dropout(size_t n, const float* x, float* y, float p, uint32_t call_id, const uint64_t* rng, void* stream);
 int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* stream);
+/* Gradient wire format of the data-parallel exchange (the stock DDP bf16_compress_hook's arithmetic: divide by the world
+ * size, round to bf16, all-reduce(SUM) in bf16, widen): y[i] = bf16(x[i] * scale) and x[i] = fp32(y[i]).  x (fp32) and y
+ * (bf16) must sit at the same element offset modulo 4 of 16-byte aligned bases (a mirrored staging arena). */
+int hamt_wire_pack_bf16(size_t n, const float* x, void* y, float scale, void* stream);
+int hamt_wire_unpack_bf16(size_t n, const void* y, float* x, void* stream);
 /* x[i] = value where flag[i] == 0  (A16 in-place masked_fill_(nav_types == 0, -inf), pretrain_cmt.py:177;
  * its backward zeroes the gradient at the same positions) */
 int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, void* stream);

@@ -97,6 +97,16 @@ def _worker(rank, world, port, out_dir):
         got = flat[o:o + p.numel()].view(p.shape)
         want = grads[k] if grads[k] is not None else torch.zeros_like(got)
         assert float((got - want).abs().max()) <= 1e-6 * gscale, k
+    # 2c) bf16 wire format (the DDP bf16_compress_hook arithmetic): same averages to bf16 resolution, on a view that
+    #     starts at an odd arena offset
+    flat_b = torch.zeros(n + 3)
+    for p, o in zip(local.params, offs):
+        if p.grad is not None:
+            flat_b[3 + o:3 + o + p.numel()] = p.grad.reshape(-1)
+    allreduce_mean_(flat_b[3:], wire="bf16")
+    assert float(flat_b[:3].abs().max()) == 0.0
+    err = float((flat_b[3:] - flat).abs().max())
+    assert 0.0 < err <= 2.0 ** -7 * gscale, err
     # 3) reductions used by bench.py
     assert max_over_ranks(float(rank + 1), "cpu") == float(world)
     assert sum_over_ranks(2.0, "cpu") == 2.0 * world

@@ -339,11 +339,13 @@ def test_graph_replay_matches_eager_steps(tiny):
     assert worst < 2e-5, worst      # total parameter movement over the 9 steps is ~9e-3
 
 
-def test_overlapped_grad_sync_matches_single_process_steps(tiny):
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_overlapped_grad_sync_matches_single_process_steps(tiny, wire):
     """The multi-GPU step (parallel.OverlappedGradSync: forward/backward graph, grouped weight gradients launched from a
     stored plan with the arena all-reduces on a side stream, update graph) with a one-rank RCCL group == the plain
     single-process steps, both through graphs and eagerly.  One rank makes the collective an identity, so any difference
-    is plumbing: missing / doubled gradients, wrong accumulate flags, stream ordering."""
+    is plumbing: missing / doubled gradients, wrong accumulate flags, stream ordering.  wire = bf16: the gradients cross
+    the (one-rank) exchange rounded to bf16, so the parameters agree to that resolution only."""
     import torch.distributed as dist
     from vln_hamt_amd.graph import GraphedTrainStep
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
@@ -390,7 +392,7 @@ def test_overlapped_grad_sync_matches_single_process_steps(tiny):
             m2, o2 = make()
             o2.materialize()
             broadcast_params(o2)
-            sync = OverlappedGradSync(o2, n_groups=3)
+            sync = OverlappedGradSync(o2, n_groups=3, wire=wire)
             try:
                 n0 = wgrad.stats["problems"]
                 if use_graph:
@@ -412,8 +414,10 @@ def test_overlapped_grad_sync_matches_single_process_steps(tiny):
             worst = 0.0
             for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
                 worst = max(worst, float((a - b).abs().max()))
-            print(f"[overlapped sync, graph={use_graph}] worst parameter difference after {len(seq)} steps: {worst:.2e}")
-            assert worst < 2e-5, (use_graph, worst)
+            print(f"[overlapped sync, graph={use_graph}, wire={wire}] worst parameter difference after {len(seq)} steps: {worst:.2e}")
+            assert worst < (2e-5 if wire == "fp32" else 2e-4), (use_graph, worst)
+            if wire == "bf16":
+                assert worst > 0.0
     finally:
         if created:
             dist.destroy_process_group()

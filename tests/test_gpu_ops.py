@@ -589,3 +589,22 @@ def test_linear_with_residual_epilogue(prec):
     close(r.grad, go, 0.0, "d residual")
     gr = bf16_round(go) if prec == "bf16" else go
     close(x.grad, gr.double() @ wr.double(), 2e-5 if prec == "fp32" else 3e-3, "dx")
+
+
+@pytest.mark.parametrize("off,n", [(0, 1 << 20), (3, 1000003), (1, 2), (2, 7), (5, 4097)])
+def test_wire_pack_unpack_bf16(off, n):
+    """hamt_wire_pack_bf16 / _unpack_bf16 on views at odd arena offsets: y = bf16(x * scale) (round to nearest even, as
+    torch), untouched neighbours, exact widening back."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as L, ops
+    lib = L.load()
+    base = torch.randn(off + n + 5, device=DEV)
+    stage = torch.full((off + n + 5,), 7.0, device=DEV, dtype=torch.bfloat16)
+    x, y = base[off:off + n], stage[off:off + n]
+    L.check(lib.hamt_wire_pack_bf16(n, ops._p(x), ops._p(y), 0.125, ops._stream()), "pack")
+    assert torch.equal(y, (x * 0.125).to(torch.bfloat16))
+    assert float((stage[:off].float() - 7).abs().sum()) == 0 and float((stage[off + n:].float() - 7).abs().sum()) == 0
+    keep = base.clone()
+    L.check(lib.hamt_wire_unpack_bf16(n, ops._p(y), ops._p(x), ops._stream()), "unpack")
+    assert torch.equal(x, y.float())
+    assert torch.equal(base[:off], keep[:off]) and torch.equal(base[off + n:], keep[off + n:])

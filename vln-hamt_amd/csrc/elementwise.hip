@@ -135,6 +135,28 @@ __global__ void cast_bf16_kernel(size_t n8, size_t n, const float* __restrict__ 
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[n8 * 8 + threadIdx.x] = f2bf(x[n8 * 8 + threadIdx.x]);
 }
+// Gradient wire format (parallel.py): y = bf16(x * scale) and back.  x and y share their element offset inside mirrored,
+// 256-byte aligned arenas, so `head` scalar elements bring both to vector alignment (float4 / 4 x bf16).
+__global__ void wire_pack_kernel(size_t n, size_t head, const float* __restrict__ x, bf16_t* __restrict__ y, float scale) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = (n - head) / 4, tail0 = head + n4 * 4;
+  for (size_t i = tid; i < n4; i += nth) {
+    const float4 a = *(const float4*)(x + head + i * 4);
+    *(uint2*)(y + head + i * 4) = make_uint2(pack_bf2(a.x * scale, a.y * scale), pack_bf2(a.z * scale, a.w * scale));
+  }
+  if (tid < head) y[tid] = f2bf(x[tid] * scale);
+  if (tid < n - tail0) y[tail0 + tid] = f2bf(x[tail0 + tid] * scale);
+}
+__global__ void wire_unpack_kernel(size_t n, size_t head, const bf16_t* __restrict__ y, float* __restrict__ x) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = (n - head) / 4, tail0 = head + n4 * 4;
+  for (size_t i = tid; i < n4; i += nth) {
+    const uint2 u = *(const uint2*)(y + head + i * 4);
+    *(float4*)(x + head + i * 4) = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+  if (tid < head) x[tid] = bf2f(y[tid]);
+  if (tid < n - tail0) x[tail0 + tid] = bf2f(y[tail0 + tid]);
+}
 // fp32 [R][C] -> bf16 [R][Cpad], columns >= C zero filled (reduction-dimension padding for the fast GEMM)
 __global__ void cast_pad_kernel(int R, int C, int Rpad, int Cpad, const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy) {
   const int c8 = Cpad >> 3;
@@ -332,6 +354,26 @@ extern "C" int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* strea
   if (n == 0) return HAMT_OK;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblocks(n / 8 + 1)), dim3(256), 0, as_stream(stream), n / 8, n, x, (bf16_t*)y);
   HAMT_CHECK_LAUNCH("hamt_cast_f32_bf16");
+  return HAMT_OK;
+}
+extern "C" int hamt_wire_pack_bf16(size_t n, const float* x, void* y, float scale, void* stream) {
+  HAMT_CHECK_ARG(x && y, "hamt_wire_pack_bf16: null pointer");
+  if (n == 0) return HAMT_OK;
+  size_t head = (4 - (((uintptr_t)x / 4) & 3)) & 3;
+  if (head > n) head = n;
+  HAMT_CHECK_ARG(((uintptr_t)((const bf16_t*)y + head) % 8) == 0 || n - head < 4, "hamt_wire_pack_bf16: x and y must share their offset modulo 4 elements");
+  hipLaunchKernelGGL(wire_pack_kernel, dim3(nblocks(n / 4 + 1)), dim3(256), 0, as_stream(stream), n, head, x, (bf16_t*)y, scale);
+  HAMT_CHECK_LAUNCH("hamt_wire_pack_bf16");
+  return HAMT_OK;
+}
+extern "C" int hamt_wire_unpack_bf16(size_t n, const void* y, float* x, void* stream) {
+  HAMT_CHECK_ARG(x && y, "hamt_wire_unpack_bf16: null pointer");
+  if (n == 0) return HAMT_OK;
+  size_t head = (4 - (((uintptr_t)x / 4) & 3)) & 3;
+  if (head > n) head = n;
+  HAMT_CHECK_ARG(((uintptr_t)((const bf16_t*)y + head) % 8) == 0 || n - head < 4, "hamt_wire_unpack_bf16: x and y must share their offset modulo 4 elements");
+  hipLaunchKernelGGL(wire_unpack_kernel, dim3(nblocks(n / 4 + 1)), dim3(256), 0, as_stream(stream), n, head, (const bf16_t*)y, x);
+  HAMT_CHECK_LAUNCH("hamt_wire_unpack_bf16");
   return HAMT_OK;
 }
 extern "C" int hamt_cast_pad_bf16(int R, int C, int Rpad, int Cpad, const float* x, int ldx, void* y, int ldy, void* stream) {

@@ -81,11 +81,55 @@ def wrap_ddp(model, local_rank: int):
     return DDP(model, find_unused_parameters=True)
 
 
-def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20) -> torch.Tensor:
-    """In-place average of a flat tensor over all ranks, in `chunk_elems`-element (128 MiB fp32) all-reduces."""
+# Wire format of the gradient exchange: "fp32" (DDP's default arithmetic) or "bf16" (the stock DDP bf16_compress_hook's:
+# divide by the world size, round to bf16, all-reduce(SUM) in bf16, widen back) -- half the bytes per xGMI link.
+# `default_wire(prec)` picks bf16 for the bf16 compute mode (whose weight gradients are products of bf16 images anyway)
+# unless HAMT_GRAD_WIRE says otherwise.
+_staging: dict = {}
+
+
+def default_wire(prec: str = "bf16") -> str:
+    w = os.environ.get("HAMT_GRAD_WIRE")
+    if w is not None:
+        assert w in ("fp32", "bf16"), w
+        return w
+    return "bf16" if prec == "bf16" else "fp32"
+
+
+def _stage_for(flat: torch.Tensor) -> torch.Tensor:
+    """bf16 mirror of the storage `flat` views (same element offsets), allocated once per arena"""
+    st = flat.untyped_storage()
+    key = (st.data_ptr(), st.nbytes(), str(flat.device))
+    buf = _staging.get(key)
+    if buf is None:
+        buf = _staging[key] = torch.empty(st.nbytes() // 4, dtype=torch.bfloat16, device=flat.device)
+    o = flat.storage_offset()
+    return buf[o:o + flat.numel()]
+
+
+def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20, wire: str = "fp32") -> torch.Tensor:
+    """In-place average of a flat fp32 tensor over all ranks, in `chunk_elems`-element all-reduces (128 MiB fp32 / 64 MiB
+    bf16 messages)."""
     if not (dist.is_available() and dist.is_initialized()):
         return flat
     world = dist.get_world_size()
+    if wire == "bf16":
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        stage = _stage_for(flat)
+        if flat.is_cuda:
+            import ctypes as C
+            from . import _lib as L
+            from .ops import _p, _stream
+            lib = L.load()
+            L.check(lib.hamt_wire_pack_bf16(flat.numel(), _p(flat), _p(stage), 1.0 / world, _stream()), "hamt_wire_pack_bf16")
+            for o in range(0, flat.numel(), chunk_elems):
+                dist.all_reduce(stage[o:o + chunk_elems], op=dist.ReduceOp.SUM)
+            L.check(lib.hamt_wire_unpack_bf16(flat.numel(), _p(stage), _p(flat), _stream()), "hamt_wire_unpack_bf16")
+        else:                                   # host tensors (gloo tests of the protocol): same arithmetic with torch ops
+            stage.copy_(flat * (1.0 / world))
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+            flat.copy_(stage)
+        return flat
     avg = dist.get_backend() == "nccl"          # RCCL reduces with the 1/world scale fused; gloo has no AVG
     for o in range(0, flat.numel(), chunk_elems):
         c = flat[o:o + chunk_elems]
@@ -97,12 +141,12 @@ def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20) -> torch.Te
     return flat
 
 
-def allreduce_grads(optimizer) -> None:
+def allreduce_grads(optimizer, wire: str | None = None) -> None:
     """Average this step's gradients over the ranks: pack what autograd produced into the optimizer's flat arena
     (the grouped weight gradients are already there) and all-reduce the arena.  Call between backward and clip/step."""
     if not optimizer._packed:
         optimizer._pack_grads()
-    allreduce_mean_(optimizer._flat_g)
+    allreduce_mean_(optimizer._flat_g, wire=wire or default_wire("fp32"))
 
 
 class OverlappedGradSync:
@@ -116,14 +160,22 @@ class OverlappedGradSync:
 
     so that RCCL moves range g over xGMI while group g+1 multiplies.  Works eagerly (the queue's end-of-backward
     callback runs the whole sequence) and with graph.GraphedTrainStep (forward/backward/pack graph, then this sequence
-    launched eagerly from a stored plan, then the update graph).  Use as the `grad_sync` callable."""
+    launched eagerly from a stored plan, then the update graph).  Use as the `grad_sync` callable.
+
+    Tried and dropped: capturing the groups into the step graph with progress flags (a one-lane kernel
+    on the communication stream polling a word the graph sets after each group) and a single graph whose optimizer part
+    polls an "exchange done" word.  Both work when the polling kernel and the kernels it waits for sit on different
+    hardware queues, and stall until the poll times out when HIP maps the two streams onto the same queue (4 hardware
+    queues for 6 streams here) -- not something to ship to an 8-GPU job."""
 
     overlapped = True
 
-    def __init__(self, optimizer, n_groups: int = 4):
+    def __init__(self, optimizer, n_groups: int = 4, wire: str = "fp32"):
         from . import wgrad
-        self.opt, self.n_groups = optimizer, n_groups
+        self.opt, self.n_groups, self.wire = optimizer, n_groups, wire
         self.comm = torch.cuda.Stream()
+        self.lanes = [torch.cuda.Stream() for _ in range(int(os.environ.get("HAMT_SYNC_LANES", 2)))]
+        self.alternate = os.environ.get("HAMT_SYNC_ONE_LANE") is None
         self.mode = "eager"                # "eager": run at flush; "plan": only build the plan (graph capture)
         self.plan = None
         self.done = False
@@ -156,29 +208,47 @@ class OverlappedGradSync:
         return p
 
     def run(self, plan):
-        """Launch the plan's groups on the current stream with the arena all-reduces on the communication stream."""
+        """Launch the plan's groups with the arena all-reduces on the communication stream.  Consecutive groups go to two
+        alternating compute streams: group g+1's tiles fill the CUs that group g's last round leaves idle (a quarter of
+        the tiles per launch is ~1.5 rounds of the chip: run back to back the four launches cost 40 % more than one),
+        while range g's all-reduce still starts as soon as group g itself has finished."""
         from . import wgrad
         flat = self.opt._flat_g
         main = torch.cuda.current_stream()
         pending = sorted(plan.ranges, key=lambda r: r[2])
         k = 0
 
+        done = []
+
         def reduce_ready(after):
             nonlocal k
-            first = True
             while k < len(pending) and pending[k][2] <= after:
-                if first:
+                lo, hi, _, touched = pending[k]
+                if touched:
+                    for g in touched:          # every group that writes into the range (they may sit on both lanes)
+                        self.comm.wait_event(done[g])
+                else:
                     self.comm.wait_stream(main)
-                    first = False
-                lo, hi, _ = pending[k]
                 with torch.cuda.stream(self.comm):
-                    allreduce_mean_(flat[lo:hi])
+                    allreduce_mean_(flat[lo:hi], wire=self.wire)
                 k += 1
 
         reduce_ready(-1)
+        lanes = self.lanes if self.alternate else [main]
+        for ln in lanes:
+            if ln is not main:
+                ln.wait_stream(main)
         for g in range(len(plan.groups)):
-            wgrad.launch_group(plan, g)
+            ln = lanes[g % len(lanes)]
+            for d in plan.deps[g]:                 # a buffer written by group d and accumulated into by group g
+                ln.wait_event(done[d])
+            with torch.cuda.stream(ln):
+                wgrad.launch_group(plan, g)
+            done.append(ln.record_event())
             reduce_ready(g)
+        for ln in lanes:
+            if ln is not main:
+                main.wait_stream(ln)
         main.wait_stream(self.comm)
 
     def __call__(self, optimizer):
@@ -187,7 +257,7 @@ class OverlappedGradSync:
         if self.done:
             self.done = False
             return
-        allreduce_grads(optimizer)
+        allreduce_grads(optimizer, self.wire)
 
 
 def broadcast_params(optimizer, src: int = 0) -> None:

@@ -173,13 +173,15 @@ def flush():
 class Plan:
     """The queued weight gradients of one backward pass, resolved against the optimizer's flat gradient arena and cut
     into `n_groups` launch groups in arena order, so that a caller can all-reduce the arena range of group g while
-    group g+1 is still computing (parallel.OverlappedGradSync).  `ranges` = [(lo, hi, after_group)]: arena elements
-    [lo, hi) are final once launch group `after_group` has run (-1: final before any group)."""
+    group g+1 is still computing (parallel.OverlappedGradSync).  `ranges` = [(lo, hi, after_group, groups)]: arena
+    elements [lo, hi) are final once every launch group in `groups` has run (`after_group` = the last of them, -1 /
+    empty: final before any group; groups may run concurrently on two streams, so "the last one" alone is not enough)."""
 
     def __init__(self):
         self.groups: List[tuple] = []      # (ctypes desc array, count)
         self.tables: List[torch.Tensor] = []   # per-group device scratch for the launch tables (re-used every replay)
         self.ranges: List[tuple] = []
+        self.deps: List[set] = []          # deps[g]: earlier groups that wrote a buffer group g accumulates into
         self.keep: list = []               # operand tensors: alive as long as the plan (graph replays re-use their memory)
 
 
@@ -215,14 +217,18 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
         acc += f
     # a buffer written twice in the pass: the second write must land in a LATER launch than the first
     last_group: dict = {}
+    dep_pairs = set()
     for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
-        gmin = max(last_group.get(ow, -1), last_group.get(ob, -1) if ob is not None else -1) + 1
+        prev = [last_group[o] for o in (ow, ob) if o is not None and o in last_group]
+        gmin = max(prev, default=-1) + 1
         group_of[i] = max(group_of[i], gmin)
+        dep_pairs.update((group_of[i], g) for g in prev)
         last_group[ow] = group_of[i]
         if ob is not None:
             last_group[ob] = group_of[i]
     ng = max(group_of) + 1
     plan = Plan()
+    plan.deps = [{d for (g, d) in dep_pairs if g == gg} for gg in range(ng)]
     written: dict = {}
     per_group: List[list] = [[] for _ in range(ng)]
     for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
@@ -249,13 +255,14 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
     bounds = [0] + lows[1:] + [n_total]
     for r in range(len(bounds) - 1):
         lo, hi = bounds[r], bounds[r + 1]
-        after = -1
+        after, touched = -1, set()
         for g, grp in enumerate(per_group):
             for (ow, ob, w, b, *_rest) in grp:
                 if lo <= ow < hi or (ob is not None and lo <= ob < hi):
                     after = max(after, g)
+                    touched.add(g)
         if hi > lo:
-            plan.ranges.append((lo, hi, after))
+            plan.ranges.append((lo, hi, after, frozenset(touched)))
     for (ow, ob, w, b, *_r) in probs:       # publish .grad (arena views) so that "has a gradient" == "is active"
         if w.grad is None:
             w.grad = w._hamt_grad_slot
