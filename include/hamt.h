@@ -225,6 +225,14 @@ int hamt_patchify(int N, int C, int H, int W, int P, const float* x, void* y, in
 int hamt_add3(size_t n, const float* a, const float* b, const float* c, float* out, void* stream);
 int hamt_dropout(size_t n, const float* x, float* y, float p, uint32_t call_id, const uint64_t* rng, void* stream);
 int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* stream);
+/* Device-side batch collation (replaces the host loops of pretrain_src/data/common.py:5-29 `pad_tensors` /
+ * `gen_seq_masks` and torch's pad_sequence as the six *_collate functions of data/r2r_tasks.py use them).  The host packs
+ * the ragged per-sample rows back to back (no padding) into one pinned buffer and copies it once; on the device
+ *   dst[b][t][:] = t < len_b ? src[prefix[b] + t][:] : pad_byte repeated      (rows of row_bytes bytes, any dtype)
+ *   mask[b][t]   = t < len_b + add,   lens_out[b] = len_b + add               (bool bytes / int64; lens_out may be NULL)
+ * with prefix[0..B] (int32, DEVICE) the exclusive prefix sum of the sample lengths in rows.  Bit exact by construction. */
+int hamt_unpack_padded(const void* src, const int32_t* prefix, int B, int maxlen, int row_bytes, int pad_byte, void* dst, void* stream);
+int hamt_seq_masks(const int32_t* prefix, int add, int B, int maxlen, uint8_t* mask, int64_t* lens_out, void* stream);
 /* Gradient wire format of the data-parallel exchange (the stock DDP bf16_compress_hook's arithmetic: divide by the world
  * size, round to bf16, all-reduce(SUM) in bf16, widen): y[i] = bf16(x[i] * scale) and x[i] = fp32(y[i]).  x (fp32) and y
  * (bf16) must sit at the same element offset modulo 4 of 16-byte aligned bases (a mirrored staging arena). */

@@ -12,6 +12,8 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
   canon_pretrain.npz  R2R-canon full config (B=2, L=80, T=5): per-task logits/losses + probes
   optim_tiny.npz      3 steps of clip(5.0) + reference AdamW + warmup schedule on the tiny model
   tiny_finetune.npz   NavCMT language / history / visual modes (incl. no_lang_ca)
+  vit.npz             ViT backbone features / gradients from the reference's VisionTransformer class
+  collate.npz         outputs of the reference's six *_collate functions on seeded ragged samples
 Weights always come from oracle.hamt_oracle.make_state_dict (numpy PCG64), never from random init.
 """
 import hashlib
@@ -371,8 +373,40 @@ def gen_vit():
     print("vit.npz:", len(store), "arrays")
 
 
+COLLATE_CASES = [("mlm", 5, 11, False), ("mrc", 4, 12, False), ("itm", 3, 13, False), ("sap", 5, 14, False), ("sap", 3, 15, True),
+                 ("sar", 4, 16, False), ("sprel", 4, 17, False), ("sprel", 2, 18, True)]
+COLLATE_DIMS = dict(feat=8, ang=4, prob=10, max_txt=12, max_hist=4, views=36)
+
+
+def gen_collate():
+    """Row N4 (batch collation): the reference's own six *_collate functions (r2r_tasks.py) on seeded ragged samples from
+    vln_hamt_amd.synth.make_samples (small feature widths; incl. the all-first-step `hist = None` branch).  The fixture
+    holds the expected outputs; the inputs are regenerated from the recipe (task, n, seed, COLLATE_DIMS)."""
+    from vln_hamt_amd.synth import make_samples
+    from oracle.collate_oracle import COLLATE
+    ref = ref_shim.import_collate()
+    store = {}
+    for task, n, seed, first in COLLATE_CASES:
+        tag = f"{task}{seed}"
+        exp = getattr(ref, f"{task}_collate")(make_samples(task, n, seed, first_step=first, **COLLATE_DIMS))
+        got = COLLATE[task](make_samples(task, n, seed, first_step=first, **COLLATE_DIMS))
+        assert set(exp) == set(got), (set(exp) ^ set(got))
+        for k, v in exp.items():
+            if v is None:
+                assert got[k] is None, k
+                store[f"{tag}/{k}/none"] = np.zeros(0)
+            elif torch.is_tensor(v):
+                a = v.numpy()
+                assert a.dtype == got[k].dtype and np.array_equal(a, got[k]), (tag, k, a.dtype, got[k].dtype)   # oracle == reference, bit exact
+                store[f"{tag}/{k}"] = a
+            else:                                   # keys the collate leaves as python lists
+                store[f"{tag}/{k}/list"] = np.asarray(len(v))
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **store)
+    print("collate.npz:", len(store), "arrays; oracle restatement bit-exact on", len(COLLATE_CASES), "cases")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate"]
     for w in which:
-        {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit}[w]()
+        {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate}[w]()

@@ -139,3 +139,21 @@ def import_vit():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def import_collate():
+    """-> the reference's pretrain_src/data/r2r_tasks.py module (the six *_collate functions), loaded under a synthetic
+    package so that data/__init__.py -- which imports the jsonlines / h5py readers this image lacks -- is not executed."""
+    sys.dont_write_bytecode = True
+    d = os.path.join(REF, "pretrain_src", "data")
+    pkg = types.ModuleType("_ref_data")
+    pkg.__path__ = [d]
+    sys.modules["_ref_data"] = pkg
+    out = None
+    for name in ("common", "r2r_tasks"):
+        spec = importlib.util.spec_from_file_location(f"_ref_data.{name}", os.path.join(d, f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        out = mod
+    return out

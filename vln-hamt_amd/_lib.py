@@ -76,6 +76,8 @@ SIGNATURES = {
     "hamt_add3": [sz, vp, vp, vp, vp, vp],
     "hamt_dropout": [sz, vp, vp, f32, u32, vp, vp],
     "hamt_cast_f32_bf16": [sz, vp, vp, vp],
+    "hamt_unpack_padded": [vp, vp, i32, i32, i32, i32, vp, vp],
+    "hamt_seq_masks": [vp, i32, i32, i32, vp, vp, vp],
     "hamt_wire_pack_bf16": [C.c_size_t, vp, vp, f32, vp],
     "hamt_wire_unpack_bf16": [C.c_size_t, vp, vp, vp],
     "hamt_fill_where_zero": [sz, vp, vp, f32, vp],

@@ -135,6 +135,28 @@ __global__ void cast_bf16_kernel(size_t n8, size_t n, const float* __restrict__ 
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[n8 * 8 + threadIdx.x] = f2bf(x[n8 * 8 + threadIdx.x]);
 }
+// Device-side batch collation (data/collate.py; replaces the host loops of pretrain_src/data/common.py:5-29): ragged rows
+// packed back to back -> zero/pattern padded [B][maxlen][row]; prefix[b] = first packed row of sample b.
+template <typename V>
+__global__ void unpack_padded_kernel(const V* __restrict__ src, const int32_t* __restrict__ prefix, int B, int maxlen, int row_v, V padv,
+                                     V* __restrict__ dst) {
+  const size_t per = (size_t)maxlen * row_v, total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const size_t r = i - (size_t)b * per;
+    const int t = (int)(r / row_v), c = (int)(r - (size_t)t * row_v);
+    const int p0 = prefix[b], len = prefix[b + 1] - p0;
+    dst[i] = t < len ? src[(size_t)(p0 + t) * row_v + c] : padv;
+  }
+}
+// mask[b][t] = t < len_b + add (common.py:22-29), lens_out[b] = len_b + add
+__global__ void seq_masks_kernel(const int32_t* __restrict__ prefix, int add, int B, int maxlen, uint8_t* __restrict__ mask, int64_t* __restrict__ lens_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * maxlen) return;
+  const int b = i / maxlen, t = i - b * maxlen, len = prefix[b + 1] - prefix[b] + add;
+  mask[i] = t < len ? 1 : 0;
+  if (t == 0 && lens_out) lens_out[b] = len;
+}
 // Gradient wire format (parallel.py): y = bf16(x * scale) and back.  x and y share their element offset inside mirrored,
 // 256-byte aligned arenas, so `head` scalar elements bring both to vector alignment (float4 / 4 x bf16).
 __global__ void wire_pack_kernel(size_t n, size_t head, const float* __restrict__ x, bf16_t* __restrict__ y, float scale) {
@@ -354,6 +376,28 @@ extern "C" int hamt_cast_f32_bf16(size_t n, const float* x, void* y, void* strea
   if (n == 0) return HAMT_OK;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblocks(n / 8 + 1)), dim3(256), 0, as_stream(stream), n / 8, n, x, (bf16_t*)y);
   HAMT_CHECK_LAUNCH("hamt_cast_f32_bf16");
+  return HAMT_OK;
+}
+extern "C" int hamt_unpack_padded(const void* src, const int32_t* prefix, int B, int maxlen, int row_bytes, int pad_byte, void* dst, void* stream) {
+  HAMT_CHECK_ARG(prefix && dst && B >= 0 && maxlen >= 0 && row_bytes > 0 && pad_byte >= 0 && pad_byte < 256, "hamt_unpack_padded: bad argument");
+  if (B == 0 || maxlen == 0) return HAMT_OK;
+  HAMT_CHECK_ARG(src, "hamt_unpack_padded: null source");
+  const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)row_bytes;
+  const uint32_t p4 = 0x01010101u * (uint32_t)pad_byte;
+  hipStream_t s = as_stream(stream);
+  const size_t total = (size_t)B * maxlen * row_bytes;
+  if (al % 16 == 0) hipLaunchKernelGGL((unpack_padded_kernel<uint4>), dim3(nblocks(total / 16)), dim3(256), 0, s, (const uint4*)src, prefix, B, maxlen, row_bytes / 16, make_uint4(p4, p4, p4, p4), (uint4*)dst);
+  else if (al % 8 == 0) hipLaunchKernelGGL((unpack_padded_kernel<uint2>), dim3(nblocks(total / 8)), dim3(256), 0, s, (const uint2*)src, prefix, B, maxlen, row_bytes / 8, make_uint2(p4, p4), (uint2*)dst);
+  else if (al % 4 == 0) hipLaunchKernelGGL((unpack_padded_kernel<uint32_t>), dim3(nblocks(total / 4)), dim3(256), 0, s, (const uint32_t*)src, prefix, B, maxlen, row_bytes / 4, p4, (uint32_t*)dst);
+  else hipLaunchKernelGGL((unpack_padded_kernel<uint8_t>), dim3(nblocks(total)), dim3(256), 0, s, (const uint8_t*)src, prefix, B, maxlen, row_bytes, (uint8_t)pad_byte, (uint8_t*)dst);
+  HAMT_CHECK_LAUNCH("hamt_unpack_padded");
+  return HAMT_OK;
+}
+extern "C" int hamt_seq_masks(const int32_t* prefix, int add, int B, int maxlen, uint8_t* mask, int64_t* lens_out, void* stream) {
+  HAMT_CHECK_ARG(prefix && mask && B >= 0 && maxlen >= 0, "hamt_seq_masks: bad argument");
+  if (B == 0 || maxlen == 0) return HAMT_OK;
+  hipLaunchKernelGGL(seq_masks_kernel, dim3((B * maxlen + 255) / 256), dim3(256), 0, as_stream(stream), prefix, add, B, maxlen, mask, lens_out);
+  HAMT_CHECK_LAUNCH("hamt_seq_masks");
   return HAMT_OK;
 }
 extern "C" int hamt_wire_pack_bf16(size_t n, const float* x, void* y, float scale, void* stream) {

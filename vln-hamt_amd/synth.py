@@ -157,3 +157,46 @@ def make_itm_rng(batch: dict, seed: int = 0, num_neg_trajs: int = 4) -> dict:
     dev = batch["hist_masks"].device
     return {"neg_idxs": None if neg is None else torch.from_numpy(neg).to(dev),
             "shuffled_pos_ids": [t.to(dev) for t in tabs]}
+
+
+def make_samples(task: str, n: int, seed: int = 0, feat: int = 768, ang: int = 4, prob: int = 1000, max_txt: int = 80,
+                 max_hist: int = 5, views: int = 36, first_step: bool = False) -> list:
+    """`n` per-sample dicts as the reference's Dataset.__getitem__ returns them (r2r_tasks.py:69-93, 168-200, 243-266,
+    305-341, 398-437, 521-551): ragged torch tensors + python scalars, the input of the *_collate functions.
+    first_step=True: every history is empty (the `hist_img_fts = None` branch of the SAP/SAR/SPREL collates)."""
+    task = task.split("_")[0]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(max(4, max_txt // 4), max_txt + 1))
+        T = 0 if first_step else int(rng.integers(0 if task in ("sap", "sar", "sprel") else 1, max_hist + 1))
+        s = {"txt_ids": torch.from_numpy(rng.integers(1000, 29000, size=L)), "txt_lens": L}
+        if task == "mlm":
+            lab = np.full(L, -1, dtype=np.int64)
+            m = rng.random(L) < 0.15
+            lab[m] = s["txt_ids"].numpy()[m]
+            s["txt_labels"] = torch.from_numpy(lab)
+        if task in ("sap", "sar", "sprel"):
+            V = int(rng.integers(views - 4, views + 1)) + 1              # candidates + views (+ stop)
+            s["ob_img_fts"] = torch.from_numpy(rng.standard_normal((V, feat), dtype=np.float32))
+            s["ob_ang_fts"] = torch.from_numpy(_angles(rng, (V,)))
+            s["ob_nav_types"] = torch.from_numpy(rng.integers(0, 3, size=V))
+            s["ob_lens"] = V
+        s["hist_img_fts"] = torch.from_numpy(rng.standard_normal((T, feat), dtype=np.float32))
+        s["hist_ang_fts"] = torch.from_numpy(_angles(rng, (T,)))
+        s["hist_pano_img_fts"] = torch.from_numpy(rng.standard_normal((T, views, feat), dtype=np.float32))
+        s["hist_pano_ang_fts"] = torch.from_numpy(_angles(rng, (T, views)))
+        s["hist_lens"] = T
+        if task == "mrc":
+            s["hist_img_probs"] = torch.from_numpy(rng.random((T, prob), dtype=np.float32))
+            s["hist_mrc_masks"] = torch.from_numpy(rng.random(T) < 0.3)
+        if task == "sap":
+            s["ob_action_viewindex"] = int(rng.integers(0, s["ob_lens"]))
+        if task == "sar":
+            s["ob_action_angles"] = rng.uniform(-np.pi, np.pi, size=2)
+            s["ob_progress"] = float(rng.random())
+        if task == "sprel":
+            s["sp_anchor_idxs"] = int(rng.integers(0, views))
+            s["sp_targets"] = rng.uniform(-np.pi, np.pi, size=(views, 2)).astype(np.float32)
+        out.append(s)
+    return out
