@@ -112,12 +112,17 @@ class PreLnMlpFn(torch.autograd.Function):
         y16, mean, rstd = _ln16(x2, gamma.detach(), beta.detach(), eps)
         Mp = y16.shape[0]
         g16 = _zeros_or_empty(Mp, M, I, dev)
-        pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(fc1), from the same erf evaluation as gelu
         cid1, cid2 = (next_call_id(), next_call_id()) if p_drop > 0.0 else (0, 0)
-        gemm(y16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre, drop=(p_drop, cid1))
+        if any(ctx.needs_input_grad):
+            pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(fc1), from the same erf evaluation as gelu
+            gemm(y16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre, drop=(p_drop, cid1))
+        else:                                    # no-grad panorama pass (image_vilmodel.py:44-52): nobody reads gelu'
+            pre = None
+            gemm(y16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU, drop=(p_drop, cid1))
         y = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(g16[:M], weight_operand(w2, "bf16"), y, bias=b2.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach(), drop=(p_drop, cid2))
-        ctx.save_for_backward(x2, y16, g16, pre, mean, rstd, gamma, w1, b1, w2, b2)
+        if pre is not None:
+            ctx.save_for_backward(x2, y16, g16, pre, mean, rstd, gamma, w1, b1, w2, b2)
         ctx.meta = (shp, M, D, I, float(eps), float(p_drop), cid2)
         return y.view(shp)
 

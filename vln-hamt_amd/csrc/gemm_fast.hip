@@ -488,6 +488,8 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_DROPOUT);
   else HAMT_L(-1);
 #undef HAMT_L
 }
