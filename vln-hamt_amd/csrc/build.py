@@ -16,7 +16,7 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libhamt_hip.so")
 SOURCES = ["abi.hip", "gemm.hip", "gemm_fast.hip", "attn.hip", "attn16.hip", "norm.hip", "elementwise.hip", "loss.hip", "optim.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("HAMT_EXTRA_FLAGS", "").split()
 
 
 def hipcc():

@@ -46,6 +46,16 @@ struct GemmArgsF {
   const uint64_t* rng;
 };
 
+#ifdef HAMT_PROF   // cycle accounting of the main loop (tools/gemm_prof.py builds a private copy with -DHAMT_PROF)
+__device__ unsigned long long hamt_prof_acc[8];
+extern "C" int hamt_prof_fetch(unsigned long long* out8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(hamt_prof_acc), 64);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(hamt_prof_acc), z, 64); }
+  return 0;
+}
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(1))) const void gptr_t;
@@ -269,6 +279,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     for (int p = 0; p < NSTAGE - 1; ++p)
       if (p < nk) stage(p, p);
   }
+#ifdef HAMT_PROF
+  unsigned long long pf_wait = 0, pf_bar = 0, pf_dma = 0, pf_mma = 0, pf_t0 = __builtin_readcyclecounter();
+  const unsigned long long pf_start = pf_t0;
+#define HAMT_PF(acc) { const unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - pf_t0; pf_t0 = t_; }
+#else
+#define HAMT_PF(acc)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (NSTAGE == 1) {
       if (kt) __builtin_amdgcn_s_barrier();     // everyone is done reading tile kt-1
@@ -279,8 +296,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       // tile kt has landed when at most the loads of the (up to NSTAGE-2) younger tiles are still outstanding
       const int younger = min(NSTAGE - 2, nk - 1 - kt);
       if (younger >= 2) wait_vmcnt<2 * NLD>(); else if (younger == 1) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+      HAMT_PF(pf_wait)
       __builtin_amdgcn_s_barrier();             // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
+      HAMT_PF(pf_bar)
       if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);   // overwrites the slot of tile kt-1
+      HAMT_PF(pf_dma)
     }
     const bf16_t* As = lds + (kt % NSTAGE) * STAGE;
     const bf16_t* Bs = As + A_ELEMS;
@@ -307,7 +327,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
         }
       }
     }
+    HAMT_PF(pf_mma)
   }
+#ifdef HAMT_PROF
+  if (lane == 0) {
+    atomicAdd(&hamt_prof_acc[0], pf_wait); atomicAdd(&hamt_prof_acc[1], pf_bar); atomicAdd(&hamt_prof_acc[2], pf_dma);
+    atomicAdd(&hamt_prof_acc[3], pf_mma); atomicAdd(&hamt_prof_acc[4], __builtin_readcyclecounter() - pf_start); atomicAdd(&hamt_prof_acc[5], 1ull);
+    atomicAdd(&hamt_prof_acc[6], (unsigned long long)nk);
+  }
+#endif
   if constexpr (COLSUM) {
     if (do_cs && lane < 16) {
 #pragma unroll
