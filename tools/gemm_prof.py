@@ -16,7 +16,7 @@ from vln_hamt_amd import _lib as L, ops
 lib = L.load()
 if not hasattr(lib, "hamt_prof_fetch"):
     sys.exit("library was built without -DHAMT_PROF")
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 
 def fetch(reset=True):
     lib.hamt_prof_fetch(buf, int(reset))
@@ -37,7 +37,7 @@ import os, sys, ctypes as C
 sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
 import torch
 from vln_hamt_amd import _lib as L, ops
-lib = L.load(); buf = (C.c_ulonglong * 8)()
+lib = L.load(); buf = (C.c_ulonglong * 16)()
 a = torch.randn({M}, {K}, device="cuda").bfloat16(); b = torch.randn({N}, {K}, device="cuda").bfloat16()
 out = torch.empty({M}, {N}, device="cuda", dtype=torch.bfloat16)
 ops.gemm(a, b, out); lib.hamt_prof_fetch(buf, 1)
@@ -45,11 +45,11 @@ for _ in range({iters}): ops.gemm(a, b, out)
 lib.hamt_prof_fetch(buf, 1); print(" ".join(str(x) for x in buf))
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ))
-    vals = [int(x) for x in r.stdout.strip().split()[-8:]]
-    w, b_, d, m, tot, waves, nk = vals[:7]
+    vals = [int(x) for x in r.stdout.strip().split()[-16:]]
+    w, b_, d, m, tot, waves, nk, pro, epi = vals[:9]
     per = lambda x: x / max(nk, 1)
     print(f"nt {M}x{N}x{K} BM={bm:3d}: waves {waves:7d} k-tiles/wave {nk/max(waves,1):6.1f} | per k-tile cycles: dma-wait {per(w):7.0f}  barrier {per(b_):7.0f}  "
-          f"dma-issue {per(d):6.0f}  frag+mfma {per(m):7.0f}  | loop total/wave {tot/max(waves,1):9.0f}")
+          f"dma-issue {per(d):6.0f}  frag+mfma {per(m):7.0f}  | per wave: prologue {pro/max(waves,1):7.0f}  loop {tot/max(waves,1):9.0f}  epilogue {epi/max(waves,1):8.0f}")
 
 for shp in [(4096, 4096, 4096), (5120, 3072, 768), (5120, 2304, 768)]:
     for bm in (256, 128, 64):

@@ -47,11 +47,18 @@ struct GemmArgsF {
 };
 
 #ifdef HAMT_PROF   // cycle accounting of the main loop (tools/gemm_prof.py builds a private copy with -DHAMT_PROF)
-__device__ unsigned long long hamt_prof_acc[8];
+__device__ unsigned long long hamt_prof_rec[65536 * 10];   // per-wave records (no atomics inside the timed regions)
+__device__ unsigned int hamt_prof_n;
 extern "C" int hamt_prof_fetch(unsigned long long* out8, int reset) {
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out8, HIP_SYMBOL(hamt_prof_acc), 64);
-  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(hamt_prof_acc), z, 64); }
+  static unsigned long long rec[65536 * 10];     // out8: 16 sums over the recorded waves
+  unsigned int n = 0;
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(hamt_prof_n), 4);
+  if (n > 65536) n = 65536;
+  hipMemcpyFromSymbol(rec, HIP_SYMBOL(hamt_prof_rec), (size_t)n * 80);
+  for (int k = 0; k < 16; ++k) out8[k] = 0;
+  for (unsigned int i = 0; i < n; ++i) for (int k = 0; k < 9; ++k) out8[k] += rec[(size_t)i * 10 + k];
+  if (reset) { n = 0; hipMemcpyToSymbol(HIP_SYMBOL(hamt_prof_n), &n, 4); }
   return 0;
 }
 #endif
@@ -255,6 +262,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
   constexpr int NLD = (BM + BN) / (8 * NW);      // glds instructions per wave per stage
   __shared__ __attribute__((aligned(16))) bf16_t lds[NSTAGE * STAGE];
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w / WN, wn = w % WN;
+#ifdef HAMT_PROF
+  const unsigned long long pf_entry = __builtin_readcyclecounter();
+#endif
   const bool do_cs = COLSUM && db != nullptr && n0 == 0 && wn == 0;   // wave-uniform
   f32x4 cs[FM];
   if constexpr (COLSUM) {
@@ -330,11 +340,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     HAMT_PF(pf_mma)
   }
 #ifdef HAMT_PROF
-  if (lane == 0) {
-    atomicAdd(&hamt_prof_acc[0], pf_wait); atomicAdd(&hamt_prof_acc[1], pf_bar); atomicAdd(&hamt_prof_acc[2], pf_dma);
-    atomicAdd(&hamt_prof_acc[3], pf_mma); atomicAdd(&hamt_prof_acc[4], __builtin_readcyclecounter() - pf_start); atomicAdd(&hamt_prof_acc[5], 1ull);
-    atomicAdd(&hamt_prof_acc[6], (unsigned long long)nk);
-  }
+  const unsigned long long pf_loop_end = __builtin_readcyclecounter();
 #endif
   if constexpr (COLSUM) {
     if (do_cs && lane < 16) {
@@ -393,6 +399,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       } else epi_store<EPI, 8>(g, row, col, v8);
     }
   }
+#ifdef HAMT_PROF
+  {   // one record per wave: [dma wait, barrier, dma issue, fragments + MFMA, loop, 1, k-tiles, prologue, epilogue] in shader cycles
+    const unsigned long long pf_end = __builtin_readcyclecounter();
+    if (lane == 0) {
+      const unsigned int slot = atomicAdd(&hamt_prof_n, 1u);
+      if (slot < 65536u) {
+        unsigned long long* r = hamt_prof_rec + (size_t)slot * 10;
+        r[0] = pf_wait; r[1] = pf_bar; r[2] = pf_dma; r[3] = pf_mma; r[4] = pf_loop_end - pf_start; r[5] = 1; r[6] = (unsigned long long)nk;
+        r[7] = pf_start - pf_entry; r[8] = pf_end - pf_loop_end;
+      }
+    }
+  }
+#endif
 }
 
 // tile id -> (m0, n0) with the XCD-aware remap (blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous
