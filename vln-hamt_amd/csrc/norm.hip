@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
   if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float* __restrict__ dy,
+template <int NV, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(hamt_ln_desc d, const float* __restrict__ dy,
                                                      const float* __restrict__ z, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
                                                      float* __restrict__ dz, float* __restrict__ dx, bf16_t* __restrict__ dx16,
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int H = d.H;
   if (dx16 && blockIdx.x == 0)      // zero the reduction-padding rows [M, Mpad16) of the bf16 gradient image
-    for (int row = d.M + w; row < d.Mpad16; row += 4)
+    for (int row = d.M + w; row < d.Mpad16; row += NWV)
       for (int c = lane * 4; c < H; c += 256) *(uint2*)(dx16 + (size_t)row * H + c) = make_uint2(0u, 0u);
   const RngKey kpre = rng_key(rng, d.call_id), kpost = rng_key(rng, d.call_id ^ POST_SALT);
   const float ik_pre = d.p_pre > 0.f ? 1.0f / (1.0f - d.p_pre) : 1.0f, ik_post = d.p_post > 0.f ? 1.0f / (1.0f - d.p_post) : 1.0f;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     dxs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int row = blockIdx.x * 4 + w; row < d.M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * NWV + w; row < d.M; row += gridDim.x * NWV) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     float4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
@@ -151,9 +151,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(hamt_ln_desc d, const float
     }
   }
   // block partials: ws[block][0][H] = dgamma, ws[block][1][H] = dbeta, ws[block][2][H] = sum dx
-  __shared__ float4 red[4][3][NV * 64];
+  // (NWV waves per block keep enough rows in flight to cover the HBM latency -- 4 waves per CU ran at 2.1 TB/s -- while the
+  // number of partials, one per block, stays <= 256: first a tree over the upper waves, then the 4-wave stage)
+  __shared__ float4 red[NWV > 4 ? NWV / 2 : 4][3][NV * 64];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { red[w][0][i * 64 + lane] = dg[i]; red[w][1][i * 64 + lane] = db[i]; red[w][2][i * 64 + lane] = dxs[i]; }
+  for (int half = NWV / 2; half >= 4; half >>= 1) {
+    if (w >= half && w < 2 * half) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { red[w - half][0][i * 64 + lane] = dg[i]; red[w - half][1][i * 64 + lane] = db[i]; red[w - half][2][i * 64 + lane] = dxs[i]; }
+    }
+    __syncthreads();
+    if (w < half) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 a = red[w][0][i * 64 + lane], b = red[w][1][i * 64 + lane], c = red[w][2][i * 64 + lane];
+        dg[i].x += a.x; dg[i].y += a.y; dg[i].z += a.z; dg[i].w += a.w;
+        db[i].x += b.x; db[i].y += b.y; db[i].z += b.z; db[i].w += b.w;
+        dxs[i].x += c.x; dxs[i].y += c.y; dxs[i].z += c.z; dxs[i].w += c.w;
+      }
+    }
+    __syncthreads();
+  }
+  if (w < 4) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { red[w][0][i * 64 + lane] = dg[i]; red[w][1][i * 64 + lane] = db[i]; red[w][2][i * 64 + lane] = dxs[i]; }
+  }
   __syncthreads();
   if (w < 3) {
 #pragma unroll
@@ -217,13 +239,19 @@ static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, c
   HAMT_CHECK_ARG(!(d->p_pre > 0.f) || dx || dx16, "hamt_ln_bwd: p_pre > 0 needs dx or dx16");
   if (d->M == 0) return HAMT_OK;
   const int nv = (d->H + 255) / 256;
-  int nb = (d->M + 3) / 4;
+  // waves per block (measured, H = 768, incl. the reduce pass: M = 11520 42 -> 31 us, 5120 24 -> 22, 2368 17.6 -> 14.1 with
+  // 16 waves; 384 rows are fastest with 4)
+  static const int force_w = getenv("HAMT_LN_BWD_WAVES") ? atoi(getenv("HAMT_LN_BWD_WAVES")) : 0;
+  const int nwv = force_w ? force_w : (d->M >= 2048 ? 16 : (d->M >= 1024 ? 8 : 4));
+  int nb = (d->M + nwv - 1) / nwv;
   if (nb > 256) nb = 256;
   hipStream_t s = as_stream(stream);
   float* dxx = d->p_pre > 0.f ? dx : nullptr;
-#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, (bf16_t*)dx16, ws, rng, add)
+#define LAUNCH2(NV, W) hipLaunchKernelGGL((ln_bwd_kernel<NV, W>), dim3(nb), dim3(64 * W), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, (bf16_t*)dx16, ws, rng, add)
+#define LAUNCH(NV) { if (nwv == 16) LAUNCH2(NV, 16); else if (nwv == 8) LAUNCH2(NV, 8); else LAUNCH2(NV, 4); }
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
+#undef LAUNCH2
   if (dgamma || dbeta || dxsum)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(1024), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
