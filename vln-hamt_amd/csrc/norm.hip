@@ -11,6 +11,13 @@ void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumul
 
 namespace {
 
+// keep factors of the 4 consecutive elements (row, c .. c+3), c % 4 == 0: the 4-wide mask stream of common.h (one hash
+// pair per 4 elements instead of two hashes per element -- the LayerNorm-backward kernel spent 15 % of its time hashing)
+__device__ __forceinline__ void ln_keep4(RngKey k, int row, int c, float p, float inv_keep, float (&f)[4]) {
+  drop_scale4(k, hamt_mix32((uint32_t)row ^ k.k0), (uint32_t)(c >> 2), p, inv_keep, f);
+}
+
+
 constexpr uint32_t POST_SALT = 0x5bd1e995u;
 
 template <int NV>
@@ -39,8 +46,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
       const size_t o = (size_t)row * H + c;
       float4 a = *(const float4*)(x + o);
       if (d.p_pre > 0.f) {
-        a.x *= drop_scale(kpre, o, d.p_pre, ik_pre); a.y *= drop_scale(kpre, o + 1, d.p_pre, ik_pre);
-        a.z *= drop_scale(kpre, o + 2, d.p_pre, ik_pre); a.w *= drop_scale(kpre, o + 3, d.p_pre, ik_pre);
+        float f_[4]; ln_keep4(kpre, row, c, d.p_pre, ik_pre, f_);
+        a.x *= f_[0]; a.y *= f_[1]; a.z *= f_[2]; a.w *= f_[3];
       }
       if (res) { float4 r = *(const float4*)(res + o); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
       v[i] = a;
@@ -69,8 +76,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
       r.x = (v[i].x - mean) * rstd * g.x + b.x; r.y = (v[i].y - mean) * rstd * g.y + b.y;
       r.z = (v[i].z - mean) * rstd * g.z + b.z; r.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (d.p_post > 0.f) {
-        r.x *= drop_scale(kpost, o, d.p_post, ik_post); r.y *= drop_scale(kpost, o + 1, d.p_post, ik_post);
-        r.z *= drop_scale(kpost, o + 2, d.p_post, ik_post); r.w *= drop_scale(kpost, o + 3, d.p_post, ik_post);
+        float f_[4]; ln_keep4(kpost, row, c, d.p_post, ik_post, f_);
+        r.x *= f_[0]; r.y *= f_[1]; r.z *= f_[2]; r.w *= f_[3];
       }
       if (y) *(float4*)(y + o) = r;
       if (y16) *(uint2*)(y16 + o) = make_uint2(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w));
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(hamt_ln_desc d, const 
         const size_t o = (size_t)row * H + c;
         float4 a = *(const float4*)(dy + o);
         if (d.p_post > 0.f) {
-          a.x *= drop_scale(kpost, o, d.p_post, ik_post); a.y *= drop_scale(kpost, o + 1, d.p_post, ik_post);
-          a.z *= drop_scale(kpost, o + 2, d.p_post, ik_post); a.w *= drop_scale(kpost, o + 3, d.p_post, ik_post);
+          float f_[4]; ln_keep4(kpost, row, c, d.p_post, ik_post, f_);
+          a.x *= f_[0]; a.y *= f_[1]; a.z *= f_[2]; a.w *= f_[3];
         }
         const float4 zz = *(const float4*)(z + o);
         float4 h;
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(hamt_ln_desc d, const 
           *(float4*)(dz + o) = make_float4(r.x + q.x, r.y + q.y, r.z + q.z, r.w + q.w);
         } else *(float4*)(dz + o) = r;
         if (d.p_pre > 0.f) {
-          r.x *= drop_scale(kpre, o, d.p_pre, ik_pre); r.y *= drop_scale(kpre, o + 1, d.p_pre, ik_pre);
-          r.z *= drop_scale(kpre, o + 2, d.p_pre, ik_pre); r.w *= drop_scale(kpre, o + 3, d.p_pre, ik_pre);
+          float f_[4]; ln_keep4(kpre, row, c, d.p_pre, ik_pre, f_);
+          r.x *= f_[0]; r.y *= f_[1]; r.z *= f_[2]; r.w *= f_[3];
         }
         if (dx) *(float4*)(dx + o) = r;
         if (dx16) *(uint2*)(dx16 + o) = make_uint2(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w));
