@@ -184,55 +184,66 @@ def time_xattn_probe(batch, device, reps=20):
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "cases": res}
 
 
-def time_wgrad_roofline(model, cfg, batch, device, iters=10):
-    """Live HIP-event timing of the dominant kernel of the step (rocprofv3: wgrad_grouped_kernel<128>, profiles/): the
-    grouped weight-gradient launch of one SAP backward pass, re-issued from the very problem list the pass queued
-    (same operands, scratch outputs; the problems of the 256-square-tile class = one launch of
-    wgrad_grouped_kernel<256,256,2,4>).  Algorithmic FLOPs = sum over problems of 2*M*N*K."""
-    import ctypes as C
+def time_wgrad_roofline(model, cycle, batch, device, iters=3):
+    """Live HIP-event timing of the dominant kernel of the step (rocprofv3: wgrad_grouped_kernel<256,256,2,4>, profiles/):
+    for every step of one task-mix cycle (`cycle` = [(task, batch)] x 12, the very batches of the timed region) the
+    grouped weight-gradient launch of that backward pass is re-issued from the problem list the pass queued (same
+    operands, scratch outputs; the problems of the 256-square-tile class = ONE launch of the kernel per step), so the mean
+    launch duration is over the same population of launches as the rocprofv3 kernel-trace average.
+    Algorithmic FLOPs = sum over problems of 2*M*N*K."""
     from vln_hamt_amd import _lib as Lb, ops, wgrad
-    from vln_hamt_amd.synth import make_batch
-    b = make_batch("sap", batch, cfg, seed=4242, txt_len=L_TXT, hist_len=T_HIST, device=device)
-    items = []
-    prev = wgrad._handler[0]
-    wgrad.set_handler(items.extend)
-    try:
-        model(b, "sap", True).mean().backward()
-    finally:
-        wgrad.set_handler(prev)
-    for p_ in model.parameters():
-        p_.grad = None
-    items = [it for it in items if it[2].stride(0) >= 256 and it[3].stride(0) >= 256]   # the 256-square-tile launch class
-    n = len(items)
-    descs = (Lb.WgradDesc * n)()
-    keep, flops = [], 0.0
-    for i, (w, bb, dy16, x16) in enumerate(items):
-        dw = torch.empty(w.shape, dtype=torch.float32, device=device)
-        db = torch.empty(w.shape[0], dtype=torch.float32, device=device)
-        keep += [dw, db]
-        d = descs[i]
-        d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), (db.data_ptr() if bb is not None else None)
-        d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
-        flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
     lib = Lb.load()
-    tab = torch.empty(wgrad.table_entries(descs, n) * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
-    run = lambda: Lb.check(lib.hamt_wgrad_grouped(n, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
-    for _ in range(2):
-        run()
+    lists, keep = {}, []
+    for task, b in cycle:
+        if task in lists:
+            continue
+        items = []
+        prev = wgrad._handler[0]
+        wgrad.set_handler(items.extend)
+        try:
+            model(b, task, True).mean().backward()
+        finally:
+            wgrad.set_handler(prev)
+        for p_ in model.parameters():
+            p_.grad = None
+        items = [it for it in items if it[2].stride(0) >= 256 and it[3].stride(0) >= 256]   # the 256-square-tile launch class
+        n = len(items)
+        descs = (Lb.WgradDesc * n)()
+        flops = 0.0
+        for i, (w, bb, dy16, x16) in enumerate(items):
+            dw = torch.empty(w.shape, dtype=torch.float32, device=device)
+            db = torch.empty(w.shape[0], dtype=torch.float32, device=device)
+            keep += [dw, db, dy16, x16]
+            d = descs[i]
+            d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), (db.data_ptr() if bb is not None else None)
+            d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
+            flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
+        tab = torch.empty(wgrad.table_entries(descs, n) * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
+        lists[task] = (n, descs, tab, flops)
+
+    def run(task):
+        n, descs, tab, _ = lists[task]
+        Lb.check(lib.hamt_wgrad_grouped(n, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
+    for task, _ in cycle:
+        run(task)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
     s.record()
     for _ in range(iters):
-        run()
+        for task, _ in cycle:
+            run(task)
     e.record()
     torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
-    launches = 1
+    launches = iters * len(cycle)
+    ms = s.elapsed_time(e) / launches
+    flops = sum(lists[t][3] for t, _ in cycle) / len(cycle)        # mean per launch over the mix
     tf = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": f"wgrad_grouped_kernel<256,256,2,4> (bf16 MFMA, {n} weight-gradient problems of one SAP backward pass, B={batch})",
-            "flops_per_call": flops, "launches_per_call": launches, "avg_launch_us": round(ms * 1e3 / launches, 2)}
+            "kernel": f"wgrad_grouped_kernel<256,256,2,4> (bf16 MFMA; the weight-gradient problems of each backward pass of one "
+                      f"{len(cycle)}-step task-mix cycle, {min(v[0] for v in lists.values())}-{max(v[0] for v in lists.values())} problems per launch, B={batch})",
+            "flops_per_call": flops, "launches_per_call": 1, "avg_launch_us": round(ms * 1e3, 2),
+            "per_task_gflop": {t: round(v[3] / 1e9, 1) for t, v in lists.items()}}
 
 
 def cpu_baseline(budget_s=20.0, batch=16):
@@ -417,7 +428,11 @@ def main():
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
         }
-        out["roofline"] = time_wgrad_roofline(model, cfg, args.batch, device)
+        if args.task == "mix":
+            cycle = [get_batch(s_) for s_ in range(len(sched.cycle))]
+        else:
+            cycle = [get_batch(0)]
+        out["roofline"] = time_wgrad_roofline(model, cycle, args.batch, device)
         out["roofline"]["traffic"] = WGRAD_TRAFFIC_BYTES.get(args.batch)
         out["roofline_probe_ffn1"] = time_gemm_probe(args.batch, device)
         out["roofline_probe_fwd_gemms"] = time_gemm_family(model, cfg, args.batch, device)
