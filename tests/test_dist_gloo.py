@@ -120,3 +120,57 @@ def test_data_parallel_plumbing_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), f"ok{r}")) for r in range(world))
+
+
+def test_wgrad_plan_invariants_cpu():
+    import numpy as np
+    """Host logic of the overlapped exchange (wgrad.build_plan, no kernel runs): for a fake backward pass over an arena
+    with shared parameters -- (1) the ranges tile the arena exactly, (2) every group that writes into a range is in that
+    range's `groups` and `after` is the last of them, (3) a buffer written twice is written by strictly increasing groups
+    with the dependency recorded and the accumulate flag set on the later write, (4) work is split in arena order."""
+    from types import SimpleNamespace
+    from vln_hamt_amd import wgrad
+    rng = np.random.Generator(np.random.PCG64(3))
+    shapes = [(768, 768)] * 6 + [(3072, 768), (768, 3072), (2304, 768), (128, 768)]
+    n = sum(int(np.prod(s)) + s[0] for s in shapes) + 4096
+    flat_g = torch.zeros(n)
+    params, off = [], 512                       # leading 512 elements: "non-GEMM" parameters (LayerNorm etc.)
+    for s in shapes:
+        w = torch.nn.Parameter(torch.zeros(s)); b = torch.nn.Parameter(torch.zeros(s[0]))
+        w._hamt_grad_slot = flat_g[off:off + w.numel()].view(s); off += w.numel()
+        b._hamt_grad_slot = flat_g[off:off + s[0]]; off += s[0]
+        params.append((w, b))
+    K = 256
+    mk = lambda w: (torch.zeros(K, w.shape[0], dtype=torch.bfloat16), torch.zeros(K, w.shape[1], dtype=torch.bfloat16))
+    items = []
+    order = list(rng.permutation(len(params))) + [0, 0, 3]      # parameter 0 used three times, parameter 3 twice
+    for i in order:
+        w, b = params[i]
+        dy, x = mk(w)
+        items.append((w, b, dy, x))
+    plan = wgrad.build_plan(items, SimpleNamespace(_flat_g=flat_g), n_groups=4)
+    assert plan is not None and len(plan.groups) == len(plan.deps) == len(plan.tables)
+    base = flat_g.data_ptr()
+    # (1) ranges tile [0, n)
+    rs = sorted(plan.ranges)
+    assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:]))
+    # writers of every arena offset, per group
+    writes = {}
+    for g, (descs, cnt) in enumerate(plan.groups):
+        for i in range(cnt):
+            d = descs[i]
+            for ptr, acc in ((d.dw, d.accum_dw), (d.db, d.accum_db)):
+                if ptr:
+                    writes.setdefault((ptr - base) // 4, []).append((g, acc))
+    for lo, hi, after, groups in plan.ranges:
+        touching = {g for o, ws in writes.items() if lo <= o < hi for g, _ in ws}
+        assert touching == set(groups), (lo, hi, touching, groups)                     # (2)
+        assert after == (max(groups) if groups else -1)
+    for o, ws in writes.items():                                                        # (3)
+        gs = [g for g, _ in ws]
+        assert gs == sorted(gs) and len(set(gs)) == len(gs), (o, ws)
+        assert [a for _, a in ws] == [0] + [1] * (len(ws) - 1), (o, ws)
+        for g_prev, g_next in zip(gs[:-1], gs[1:]):
+            assert g_prev in plan.deps[g_next]
+    first = [min(o for o, ws in writes.items() if any(g == gg for g, _ in ws)) for gg in range(len(plan.groups))]
+    assert len(plan.groups) >= 4 and first[:4] == sorted(first[:4])                     # (4)
