@@ -34,6 +34,10 @@ class GraphedTrainStep:
         # the stream they were created on; if a later capture ran on a different stream their accumulation kernels
         # would execute outside the capture (run once, never replayed).
         self.stream = torch.cuda.Stream()
+        # (the warm-up step before each capture runs on that stream while the parameters' AccumulateGrad nodes may date
+        # from an earlier pass on the caller's stream: intended, and synchronised by wait_stream on both sides)
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.opt.materialize()
 
     def _eager(self, batch, task):
