@@ -218,6 +218,38 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(int nb, int H, cons
   }
 }
 
+// Same reduction for H % 64 == 0 with 16-byte loads: block = 64 columns (16 lanes x float4) x 16 phases; every thread keeps
+// its 16 (nb = 256) loads in flight before the first add.
+__global__ __launch_bounds__(256) void ln_bwd_reduce4_kernel(int nb, int H, const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dxsum) {
+  const int l16 = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + l16 * 4;            // < 3 * H by construction
+  const int which = c / H, col = c - which * H;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = ph; b0 < nb; b0 += 64) {              // 4 independent loads per trip
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + 16 * u;
+      v[u] = b < nb ? *(const float4*)(ws + ((size_t)b * 3 + which) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  __shared__ float4 red[16][16];
+  red[ph][l16] = s;
+  __syncthreads();
+  if (ph == 0) {
+    float* o = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    if (o) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float4 r = red[i][l16]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+      *(float4*)(o + col) = t;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
@@ -259,8 +291,11 @@ static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, c
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
 #undef LAUNCH2
-  if (dgamma || dbeta || dxsum)
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(1024), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
+  if (dgamma || dbeta || dxsum) {
+    const bool al = d->H % 64 == 0 && (((uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)dxsum | (uintptr_t)ws) % 16) == 0;
+    if (al) hipLaunchKernelGGL(ln_bwd_reduce4_kernel, dim3(3 * d->H / 64), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
+    else hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(1024), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
+  }
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
   return HAMT_OK;
 }
