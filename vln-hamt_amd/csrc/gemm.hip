@@ -358,6 +358,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int R, int N, cons
   }
 }
 
+// the same sum (slice order 0, 1, 2, ...) with 16-byte accesses and up to four slices in flight per thread
+__global__ __launch_bounds__(256) void reduce_partials4_kernel(int R, size_t n4, size_t N, const float* __restrict__ ws, float* __restrict__ out,
+                                                               int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r0 = 0; r0 < R; r0 += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = r0 + u < R ? *(const float4*)(ws + (size_t)(r0 + u) * N + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    float4* o = (float4*)(out + i * 4);
+    if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+    *o = s;
+  }
+}
+
 // dW[n][k] = sum_m dy[m][n] * x[m][k] for tiny K (the 4-wide angle features): K weighted column sums of dy, exact fp32.
 template <int KMAX>
 __global__ __launch_bounds__(256) void smallk_wgrad_partial_kernel(int M, int N, int K, const float* __restrict__ dy, int lddy,
@@ -405,6 +423,12 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
                            size_t ws_bytes, hipStream_t s);
 
 void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s) {
+  if (N % 4 == 0 && (((uintptr_t)ws | (uintptr_t)out) % 16) == 0) {
+    const size_t n4 = (size_t)N / 4;
+    const size_t b = (n4 + 255) / 256;
+    hipLaunchKernelGGL(reduce_partials4_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, R, n4, (size_t)N, ws, out, accumulate);
+    return;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, s, R, N, ws, out, accumulate);
 }
 
