@@ -583,3 +583,99 @@ def test_graphed_inference_rollout_matches_eager():
                                 ob_step_ids=torch.tensor([t], device=DEV), hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
                                 hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
         assert len(gv.graphs) == 3
+
+
+# ------------------------------------------------------------------------------------------- two ranks on one GPU
+def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
+    """One data-parallel rank (gloo carries the collectives of CUDA tensors, so two ranks can share the box's single
+    GPU): the product's multi-GPU step on this rank's own batches."""
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd.graph import GraphedTrainStep
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    from vln_hamt_amd.parallel import OverlappedGradSync, broadcast_params
+    from vln_hamt_amd.synth import make_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = tiny_cfg()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=5)
+    m = build(cfg, sd, "bf16", train=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    named = list(m.named_parameters())
+    o = AdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+               {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], lr=1e-3, betas=(0.9, 0.98), eps=1.0)
+    o.materialize()
+    broadcast_params(o)
+    sync = OverlappedGradSync(o, n_groups=3, wire=wire)
+    seq = ["sap", "mlm", "sap", "mrc", "mlm", "sap"]
+    batches = {t: make_batch(t, 4, cfg, seed=100 * rank + sum(map(ord, t)), txt_len=20, hist_len=4, ragged=True, device=DEV) for t in set(seq)}
+    try:
+        if use_graph:
+            gs = GraphedTrainStep(m, o, 5.0, grad_sync=sync)
+            for t in seq:
+                gs.step(t, batches[t], t)
+        else:
+            for t in seq:
+                m(batches[t], t, True).mean().backward()
+                sync(o)
+                clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+                o.step()
+                o.zero_grad()
+        torch.cuda.synchronize()
+        torch.save(o._flat_p.detach().cpu(), os.path.join(out_dir, f"params{rank}.pt"))
+    finally:
+        sync.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire,use_graph", [("fp32", False), ("fp32", True), ("bf16", False)])
+def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph):
+    """world_size = 2 for real: two processes, different batches, the product's overlapped exchange (gloo moves the
+    CUDA tensors) -- against one process that computes both ranks' gradients on the same weights, averages them,
+    clips and steps.  Both ranks must also end with identical parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd import wgrad
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    from vln_hamt_amd.synth import make_batch
+    if not wgrad.ENABLED:
+        pytest.skip("HAMT_NO_DEFER_WGRAD")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph), nprocs=2, join=True)
+    p0, p1 = torch.load(os.path.join(str(tmp_path), "params0.pt")), torch.load(os.path.join(str(tmp_path), "params1.pt"))
+    assert torch.equal(p0, p1), "ranks diverged"
+    # ---- reference: one process, both ranks' gradients per step
+    cfg = tiny_cfg()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=5)
+    m = build(cfg, sd, "bf16", train=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    named = list(m.named_parameters())
+    o = AdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+               {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], lr=1e-3, betas=(0.9, 0.98), eps=1.0)
+    o.materialize()
+    seq = ["sap", "mlm", "sap", "mrc", "mlm", "sap"]
+    bs = [{t: make_batch(t, 4, cfg, seed=100 * r + sum(map(ord, t)), txt_len=20, hist_len=4, ragged=True, device=DEV) for t in set(seq)} for r in range(2)]
+    for t in seq:
+        m(bs[0][t], t, True).mean().backward()
+        o._pack_grads()
+        g0 = o._flat_g.clone()
+        o.zero_grad()
+        m(bs[1][t], t, True).mean().backward()
+        o._pack_grads()
+        o._flat_g.add_(g0).mul_(0.5)
+        clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+        o.step()
+        o.zero_grad()
+    torch.cuda.synchronize()
+    ref = o._flat_p.detach().cpu()
+    worst = float((p0 - ref).abs().max())
+    print(f"[two ranks, wire={wire}, graph={use_graph}] worst parameter difference after {len(seq)} steps: {worst:.2e}")
+    assert worst < (2e-5 if wire == "fp32" else 2e-4), worst
