@@ -313,7 +313,7 @@ def main():
     rank, local_rank, world = init_distributed()
     assert world == args.gpus or world == 1, (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HAMT kernels have no CPU path"
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", (local_rank if world > 1 else 0) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     ops.manual_seed(1234 + rank, device)
 
@@ -421,7 +421,7 @@ def main():
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
-                       "parallelism": f"dp{world}" + (f" (flat-arena RCCL all-reduce, {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
+                       "parallelism": f"dp{world}" + (f" (flat-arena {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} all-reduce, {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
                        "launch": "hipGraph replay" if graphed is not None else "eager"},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),

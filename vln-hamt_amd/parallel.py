@@ -36,7 +36,9 @@ def init_distributed(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HAMT_DIST_BACKEND=gloo: functional testing of the multi-rank path with several ranks on ONE GPU (gloo stages
+            # CUDA tensors through the host; RCCL refuses two ranks per device)
+            backend = os.environ.get("HAMT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
