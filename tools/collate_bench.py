@@ -2,8 +2,8 @@
 """Row N4 measurement: host collation + PCIe transport of R2R pretrain batches (B per GPU, 768-d features, T <= 5, 36
 views, L <= 80), and the PCIe-INCLUSIVE training step.
 
-  1. reference-style: the oracle's collate (= the reference's host loops: zero fill + one slice copy per sample and
-     field) -> pin every tensor -> one H2D copy per tensor                       [oracle/ is the CPU baseline here]
+  1. reference-style: the host loops of the reference's collate (zero fill + one slice copy per sample and field,
+     data/common.py:5-20, restated below with torch ops) -> pin every tensor -> one H2D copy per tensor
   2. this repo: pack ragged rows into one buffer -> pin -> ONE H2D copy -> hamt_unpack_padded / hamt_seq_masks
   3. SAP training steps (hipGraph replay) fed by PrefetchLoader: every step's batch is collated on the host, crosses
      PCIe and is unpacked straight into the graph's static inputs, overlapped with the previous step
@@ -29,8 +29,32 @@ def timeit(fn, n=12):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
 
+def _pad(ts, lens=None, pad=0):
+    lens = [t.shape[0] for t in ts] if lens is None else lens
+    out = torch.full((len(ts), max(lens)) + tuple(ts[0].shape[1:]), pad, dtype=ts[0].dtype)
+    for i, (t, l) in enumerate(zip(ts, lens)):
+        out[i, :l] = t
+    return out
+
+def ref_collate(task, inputs):
+    """what the reference's *_collate functions do on the host, for the tensor fields (timing leg only)"""
+    b = {k: [x[k] for x in inputs] for k in inputs[0]}
+    out = {"txt_ids": _pad(b["txt_ids"]), "txt_masks": torch.arange(max(b["txt_lens"]))[None] < torch.tensor(b["txt_lens"])[:, None]}
+    if "txt_labels" in b:
+        out["txt_labels"] = _pad(b["txt_labels"], pad=-1)
+    for k in ("hist_img_fts", "hist_ang_fts", "hist_pano_img_fts", "hist_pano_ang_fts"):
+        out[k] = _pad(b[k], b["hist_lens"])
+    hl = torch.tensor(b["hist_lens"]) + 1
+    out["hist_masks"] = torch.arange(int(hl.max()))[None] < hl[:, None]
+    if "ob_img_fts" in b:
+        for k in ("ob_img_fts", "ob_ang_fts"):
+            out[k] = _pad(b[k], b["ob_lens"])
+        out["ob_nav_types"] = _pad(b["ob_nav_types"])
+        out["ob_masks"] = torch.arange(max(b["ob_lens"]))[None] < torch.tensor(b["ob_lens"])[:, None]
+    return out
+
+ORACLE = {t: (lambda inputs, t=t: {k: v.numpy() for k, v in ref_collate(t, inputs).items()}) for t in ("sap", "mlm")}
 for task in ("sap", "mlm"):
-    from oracle.collate_oracle import COLLATE as ORACLE
     def ref_style(i):
         b = ORACLE[task](draw(task, i))
         return {k: (torch.from_numpy(np.ascontiguousarray(v)).pin_memory().to(dev, non_blocking=True) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
