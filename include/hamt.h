@@ -186,6 +186,22 @@ int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const fl
 int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean, const float* rstd,
                     const float* gamma, const float* add, float* dz, float* dgamma, float* dbeta, float* ws,
                     void* stream);
+/* The second half of hamt_ln_bwd / hamt_ln_bwd_add on its own: sums the per-block partials a call with
+ * dgamma == dbeta == dxsum == NULL left in `ws` (same M, H) into dgamma / dbeta / dxsum (stored; any may be NULL).  The
+ * parameter gradients are not on the backward critical path, so the host runs this on an auxiliary stream. */
+int hamt_ln_bwd_reduce(int M, int H, const float* ws, float* dgamma, float* dbeta, float* dxsum, void* stream);
+/* The same for n calls at once (the end-of-backward form: one launch instead of one per LayerNorm; H % 64 == 0, pointers
+ * 16-byte aligned).  `descs` is a HOST array; `table`: DEVICE scratch of >= n * HAMT_LNRED_TABLE_ENTRY bytes, filled by
+ * small kernels from kernarg data (capturable; `descs` need not outlive the call). */
+typedef struct {
+  const float* ws;
+  float* dgamma; /* each may be NULL */
+  float* dbeta;
+  float* dxsum;
+  int M, H;
+} hamt_ln_reduce_desc;
+#define HAMT_LNRED_TABLE_ENTRY 48
+int hamt_ln_bwd_reduce_grouped(int n, const hamt_ln_reduce_desc* descs, void* table, size_t table_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * gather/scatter family (embedding lookups A1/A10/A11, boolean-mask compaction A15/A19

@@ -27,6 +27,13 @@ class GemmDesc(C.Structure):
                 ("p_drop", f32), ("call_id", u32), ("rng", C.c_void_p)]
 
 
+class LnReduceDesc(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dxsum", C.c_void_p), ("M", i32), ("H", i32)]
+
+
+LNRED_TABLE_ENTRY = 48
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("B", i32), ("heads", i32), ("Sq", i32), ("Sk", i32), ("d_head", i32), ("ldq", i32), ("ldk", i32),
                 ("ldv", i32), ("ldo", i32), ("dtype_qkv", i32), ("dtype_o", i32), ("scale", f32), ("p_drop", f32),
@@ -63,6 +70,8 @@ SIGNATURES = {
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd_add": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_ln_bwd_reduce": [i32, i32, vp, vp, vp, vp, vp],
+    "hamt_ln_bwd_reduce_grouped": [i32, vp, vp, sz, vp],
     "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
     "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
     "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],

@@ -167,6 +167,7 @@ class SelfAttnBlockFn(torch.autograd.Function):
         gemm(ctx16[:M], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
+        ctx.ln_params = (gamma, beta, bo)          # their gradients come from the LayerNorm-backward partials (ops._ln_bwd)
         ctx.meta = (B, S, H, M, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
         ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
@@ -181,7 +182,7 @@ class SelfAttnBlockFn(torch.autograd.Function):
         dev = dy.device
         Mp = x16.shape[0]
         dz, _, dx16, dgamma, dbeta, dbo = _ln_bwd(dy.reshape(M, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
-                                                  cid_ln, False, True, True)
+                                                  cid_ln, False, True, True, params=ctx.ln_params)
         dctx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev)
         gemm(dx16[:M], weight_operand(wo, "bf16"), dctx16[:M], b_kmajor=True)
         dwo, _ = _wgrad(wo, None, dx16, ctx16, M)
@@ -226,6 +227,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         gemm(ctx16[:Mq], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
+        ctx.ln_params = (gamma, beta, bo)
         ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
         ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
@@ -241,7 +243,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         Mqp, Mkp = x16.shape[0], c16.shape[0]
         dev = dy.device
         dz, _, dx16, dgamma, dbeta, dbo = _ln_bwd(dy.reshape(Mq, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
-                                                  cid_ln, False, True, True)
+                                                  cid_ln, False, True, True, params=ctx.ln_params)
         dctx16 = torch.empty(Mqp, H, dtype=torch.bfloat16, device=dev)
         gemm(dx16[:Mq], weight_operand(wo, "bf16"), dctx16[:Mq], b_kmajor=True)
         dwo, _ = _wgrad(wo, None, dx16, ctx16, Mq)
@@ -278,6 +280,7 @@ class FfnBlockFn(torch.autograd.Function):
         gemm(g16[:M], weight_operand(w2, "bf16"), o, bias=b2.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma)
+        ctx.ln_params = (gamma, beta, b2)
         ctx.meta = (shp, M, H, I, float(p_hidden), float(eps), cid_ln)
         ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
@@ -292,7 +295,7 @@ class FfnBlockFn(torch.autograd.Function):
         dev = dy.device
         Mp = x16.shape[0]
         dz, _, dx16, dgamma, dbeta, db2 = _ln_bwd(dy.reshape(M, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
-                                                  cid_ln, False, True, True)
+                                                  cid_ln, False, True, True, params=ctx.ln_params)
         dh16 = _zeros_or_empty(Mp, M, I, dev)
         gemm(dx16[:M], weight_operand(w2, "bf16"), dh16[:M], b_kmajor=True, epilogue=L.EPI_MUL_AUX, aux=pre)     # dG * gelu'(pre)
         dw2, _ = _wgrad(w2, None, dx16, g16, M)

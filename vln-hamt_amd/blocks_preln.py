@@ -36,15 +36,22 @@ def _ln16(x2, gamma, beta, eps):
     return y16, mean, rstd
 
 
-def _ln_bwd_add(dln, x2, mean, rstd, gamma, eps, dy2):
-    """(LayerNorm-backward(dln) + dy2, dgamma, dbeta)"""
+def _ln_bwd_add(dln, x2, mean, rstd, gamma, eps, dy2, params=None):
+    """(LayerNorm-backward(dln) + dy2, dgamma, dbeta); with `params` = (gamma, beta) PARAMETERS their gradients are summed by the
+    grouped end-of-pass launch and published there (returned as None), as in ops._ln_bwd"""
+    from .ops import _can_defer_ln, _defer_ln_reduce
     M, D = x2.shape
-    dx = torch.empty(M, D, dtype=torch.float32, device=x2.device)
-    red = torch.empty(2, D, dtype=torch.float32, device=x2.device)
-    ws = torch.empty(3 * 256 * D, dtype=torch.float32, device=x2.device)
+    dev = x2.device
+    dx = torch.empty(M, D, dtype=torch.float32, device=dev)
+    red = torch.empty(3, D, dtype=torch.float32, device=dev)
+    ws = torch.empty(3 * 256 * D, dtype=torch.float32, device=dev)
     d = L.LnDesc(M, D, float(eps), 0.0, 0.0, 0, 0)
-    L.check(L.load().hamt_ln_bwd_add(C.byref(d), _p(dln), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dy2), _p(dx), _p(red[0]), _p(red[1]),
-                                     _p(ws), _stream()), "hamt_ln_bwd_add")
+    defer = params is not None and _can_defer_ln((params[0], params[1], None), dev, D)
+    L.check(L.load().hamt_ln_bwd_add(C.byref(d), _p(dln), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dy2), _p(dx),
+                                     None if defer else _p(red[0]), None if defer else _p(red[1]), _p(ws), _stream()), "hamt_ln_bwd_add")
+    if defer:
+        _defer_ln_reduce(M, D, ws, red, False, (params[0], params[1], None), dev)
+        return dx, None, None
     return dx, red[0], red[1]
 
 
@@ -71,6 +78,7 @@ class PreLnAttnFn(torch.autograd.Function):
         cid_p = next_call_id() if p_proj > 0.0 else 0
         gemm(ctx16[:M], weight_operand(wproj, "bf16"), y, bias=bproj.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach(), drop=(p_proj, cid_p))
         ctx.save_for_backward(x2, y16, qkv16, ctx16, lse, mean, rstd, gamma, wqkv, bqkv, wproj, bproj)
+        ctx.ln_params = (gamma, beta)
         ctx.meta = (B, S, D, M, heads, float(p_attn), float(eps), cid, float(p_proj), cid_p)
         return y.view(B, S, D)
 
@@ -95,7 +103,7 @@ class PreLnAttnFn(torch.autograd.Function):
         dln = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(dqkv16[:M], weight_operand(wqkv, "bf16"), dln, b_kmajor=True)
         dwq, dbq = _wgrad(wqkv, bqkv, dqkv16, y16, M)
-        dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2)
+        dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2, params=ctx.ln_params)
         return dx.view(B, S, D), None, None, None, None, dgamma, dbeta, dwq, dbq, dwp, dbp
 
 
@@ -123,6 +131,7 @@ class PreLnMlpFn(torch.autograd.Function):
         gemm(g16[:M], weight_operand(w2, "bf16"), y, bias=b2.detach(), epilogue=L.EPI_ADD_AUX, aux=x2.detach(), drop=(p_drop, cid2))
         if pre is not None:
             ctx.save_for_backward(x2, y16, g16, pre, mean, rstd, gamma, w1, b1, w2, b2)
+        ctx.ln_params = (gamma, beta)
         ctx.meta = (shp, M, D, I, float(eps), float(p_drop), cid2)
         return y.view(shp)
 
@@ -141,7 +150,7 @@ class PreLnMlpFn(torch.autograd.Function):
         dln = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(dh16[:M], weight_operand(w1, "bf16"), dln, b_kmajor=True)
         dw1, db1 = _wgrad(w1, b1, dh16, y16, M)
-        dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2)
+        dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2, params=ctx.ln_params)
         return dx.view(shp), None, None, dgamma, dbeta, dw1, db1, dw2, db2
 
 

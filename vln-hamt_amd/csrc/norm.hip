@@ -250,6 +250,48 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce4_kernel(int nb, int H, cons
   }
 }
 
+// Grouped form of the reduction: entry e owns blocks [e * bpe, (e + 1) * bpe) (bpe = 3 * Hmax / 64; blocks beyond an entry's
+// own 3 * H / 64 exit).  The entry table is written into device memory by tiny kernels from kernarg chunks, like the
+// grouped weight-gradient launch, so the call is capturable and `descs` need not outlive it.
+struct LnRedEntry { const float* ws; float* dgamma; float* dbeta; float* dxsum; int nb, H, pad0, pad1; };
+constexpr int LNRED_CHUNK = 64;                  // entries per kernarg chunk (64 x 48 B)
+struct LnRedChunk { LnRedEntry e[LNRED_CHUNK]; };
+__global__ void ln_red_table_write_kernel(LnRedChunk c, LnRedEntry* tab, int off, int cnt) {
+  if ((int)threadIdx.x < cnt) tab[off + threadIdx.x] = c.e[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void ln_bwd_reduce_grouped_kernel(const LnRedEntry* __restrict__ tab, int bpe) {
+  const LnRedEntry q = tab[blockIdx.x / bpe];
+  const int blk = blockIdx.x % bpe;
+  const int H = q.H, nb = q.nb;
+  if (blk * 64 >= 3 * H) return;
+  const int l16 = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int c = blk * 64 + l16 * 4;
+  const int which = c / H, col = c - which * H;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = ph; b0 < nb; b0 += 64) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + 16 * u;
+      v[u] = b < nb ? *(const float4*)(q.ws + ((size_t)b * 3 + which) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  __shared__ float4 red[16][16];
+  red[ph][l16] = s;
+  __syncthreads();
+  if (ph == 0) {
+    float* o = which == 0 ? q.dgamma : (which == 1 ? q.dbeta : q.dxsum);
+    if (o) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float4 r = red[i][l16]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+      *(float4*)(o + col) = t;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
@@ -270,6 +312,22 @@ extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* r
   return HAMT_OK;
 }
 
+// waves per block and number of blocks (= partials) of the backward kernel for M rows (measured, H = 768, incl. the reduce
+// pass: M = 11520 42 -> 31 us, 5120 24 -> 22, 2368 17.6 -> 14.1 with 16 waves; 384 rows are fastest with 4)
+static void ln_bwd_geometry(int M, int* nwv_out, int* nb_out) {
+  static const int force_w = getenv("HAMT_LN_BWD_WAVES") ? atoi(getenv("HAMT_LN_BWD_WAVES")) : 0;
+  const int nwv = force_w ? force_w : (M >= 2048 ? 16 : (M >= 1024 ? 8 : 4));
+  int nb = (M + nwv - 1) / nwv;
+  if (nb > 256) nb = 256;
+  *nwv_out = nwv;
+  *nb_out = nb;
+}
+static void ln_bwd_reduce_launch(int nb, int H, const float* ws, float* dgamma, float* dbeta, float* dxsum, hipStream_t s) {
+  const bool al = H % 64 == 0 && (((uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)dxsum | (uintptr_t)ws) % 16) == 0;
+  if (al) hipLaunchKernelGGL(ln_bwd_reduce4_kernel, dim3(3 * H / 64), dim3(256), 0, s, nb, H, ws, dgamma, dbeta, dxsum);
+  else hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 63) / 64), dim3(1024), 0, s, nb, H, ws, dgamma, dbeta, dxsum);
+}
+
 static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
                        const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                        float* dbeta, float* dxsum, float* ws, const uint64_t* rng, const float* add, void* stream) {
@@ -278,12 +336,8 @@ static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, c
   HAMT_CHECK_ARG(!(d->p_pre > 0.f) || dx || dx16, "hamt_ln_bwd: p_pre > 0 needs dx or dx16");
   if (d->M == 0) return HAMT_OK;
   const int nv = (d->H + 255) / 256;
-  // waves per block (measured, H = 768, incl. the reduce pass: M = 11520 42 -> 31 us, 5120 24 -> 22, 2368 17.6 -> 14.1 with
-  // 16 waves; 384 rows are fastest with 4)
-  static const int force_w = getenv("HAMT_LN_BWD_WAVES") ? atoi(getenv("HAMT_LN_BWD_WAVES")) : 0;
-  const int nwv = force_w ? force_w : (d->M >= 2048 ? 16 : (d->M >= 1024 ? 8 : 4));
-  int nb = (d->M + nwv - 1) / nwv;
-  if (nb > 256) nb = 256;
+  int nwv, nb;
+  ln_bwd_geometry(d->M, &nwv, &nb);
   hipStream_t s = as_stream(stream);
   float* dxx = d->p_pre > 0.f ? dx : nullptr;
 #define LAUNCH2(NV, W) hipLaunchKernelGGL((ln_bwd_kernel<NV, W>), dim3(nb), dim3(64 * W), 0, s, *d, dy, z, mean, rstd, gamma, dz, dxx, (bf16_t*)dx16, ws, rng, add)
@@ -291,11 +345,7 @@ static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, c
   switch (nv) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
 #undef LAUNCH2
-  if (dgamma || dbeta || dxsum) {
-    const bool al = d->H % 64 == 0 && (((uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)dxsum | (uintptr_t)ws) % 16) == 0;
-    if (al) hipLaunchKernelGGL(ln_bwd_reduce4_kernel, dim3(3 * d->H / 64), dim3(256), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
-    else hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * d->H + 63) / 64), dim3(1024), 0, s, nb, d->H, ws, dgamma, dbeta, dxsum);
-  }
+  if (dgamma || dbeta || dxsum) ln_bwd_reduce_launch(nb, d->H, ws, dgamma, dbeta, dxsum, s);
   HAMT_CHECK_LAUNCH("hamt_ln_bwd");
   return HAMT_OK;
 }
@@ -311,4 +361,44 @@ extern "C" int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const flo
                                float* dbeta, float* ws, void* stream) {
   HAMT_CHECK_ARG(add && d && !(d->p_pre > 0.f) && !(d->p_post > 0.f), "hamt_ln_bwd_add: needs `add`, and no dropout inside the LayerNorm");
   return ln_bwd_impl(d, dy, z, mean, rstd, gamma, dz, nullptr, nullptr, dgamma, dbeta, nullptr, ws, nullptr, add, stream);
+}
+
+extern "C" int hamt_ln_bwd_reduce(int M, int H, const float* ws, float* dgamma, float* dbeta, float* dxsum, void* stream) {
+  HAMT_CHECK_ARG(ws && M >= 0 && H % 4 == 0 && H >= 4 && H <= 1024, "hamt_ln_bwd_reduce: bad argument");
+  if (M == 0 || !(dgamma || dbeta || dxsum)) return HAMT_OK;
+  int nwv, nb;
+  ln_bwd_geometry(M, &nwv, &nb);
+  ln_bwd_reduce_launch(nb, H, ws, dgamma, dbeta, dxsum, as_stream(stream));
+  HAMT_CHECK_LAUNCH("hamt_ln_bwd_reduce");
+  return HAMT_OK;
+}
+
+extern "C" int hamt_ln_bwd_reduce_grouped(int n, const hamt_ln_reduce_desc* descs, void* table, size_t table_bytes, void* stream) {
+  HAMT_CHECK_ARG(n >= 0 && (n == 0 || (descs && table)), "hamt_ln_bwd_reduce_grouped: bad argument");
+  if (n == 0) return HAMT_OK;
+  HAMT_CHECK_ARG((size_t)n * sizeof(LnRedEntry) <= table_bytes, "hamt_ln_bwd_reduce_grouped: table too small (%zu bytes needed)", (size_t)n * sizeof(LnRedEntry));
+  hipStream_t s = as_stream(stream);
+  LnRedEntry* tab = (LnRedEntry*)table;
+  int hmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const hamt_ln_reduce_desc& d = descs[i];
+    HAMT_CHECK_ARG(d.ws && d.M > 0 && d.H % 64 == 0 && d.H <= 1024, "hamt_ln_bwd_reduce_grouped: entry %d: needs ws, M > 0, H %% 64 == 0 (H = %d)", i, d.H);
+    HAMT_CHECK_ARG((((uintptr_t)d.ws | (uintptr_t)d.dgamma | (uintptr_t)d.dbeta | (uintptr_t)d.dxsum) % 16) == 0, "hamt_ln_bwd_reduce_grouped: entry %d: pointers must be 16-byte aligned", i);
+    hmax = d.H > hmax ? d.H : hmax;
+  }
+  for (int b0 = 0; b0 < n; b0 += LNRED_CHUNK) {
+    LnRedChunk ch;
+    const int cnt = n - b0 < LNRED_CHUNK ? n - b0 : LNRED_CHUNK;
+    for (int i = 0; i < cnt; ++i) {
+      const hamt_ln_reduce_desc& d = descs[b0 + i];
+      int nwv, nb;
+      ln_bwd_geometry(d.M, &nwv, &nb);
+      ch.e[i] = LnRedEntry{d.ws, d.dgamma, d.dbeta, d.dxsum, nb, d.H, 0, 0};
+    }
+    hipLaunchKernelGGL(ln_red_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, b0, cnt);
+  }
+  const int bpe = 3 * hmax / 64;
+  hipLaunchKernelGGL(ln_bwd_reduce_grouped_kernel, dim3(n * bpe), dim3(256), 0, s, tab, bpe);
+  HAMT_CHECK_LAUNCH("hamt_ln_bwd_reduce_grouped");
+  return HAMT_OK;
 }

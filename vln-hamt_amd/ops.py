@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional
 
 import torch
@@ -511,8 +512,29 @@ def _ln_fwd(x2, r2, gamma, beta, eps, p_pre, p_post, want16):
     return y, y16, z, mean, rstd, cid
 
 
-def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_dx16, want_dxsum):
-    """-> (dz, dx32 | None, dx16 | None, dgamma, dbeta, dxsum | None)"""
+LN_DEFER = os.environ.get("HAMT_NO_DEFER_LNRED") is None      # ablation: reduce the parameter-gradient partials in line
+
+
+def _defer_ln_reduce(M, H, ws, red, want_dxsum, params, dev):
+    """The partials are in `ws`: queue their summation for the ONE grouped launch at the end of the pass (wgrad.flush) and
+    the publication of the results as the parameters' gradients."""
+    from . import wgrad
+    gamma_p, beta_p, bias_p = params
+    wgrad.defer_ln_reduce(ws, red, M, H, want_dxsum, [(gamma_p, red[0]), (beta_p, red[1]), (bias_p, red[2] if want_dxsum else None)])
+
+
+def _can_defer_ln(params, dev, H=64):
+    from . import wgrad
+    if not (LN_DEFER and wgrad.ENABLED and params is not None and dev.type == "cuda" and H % 64 == 0):
+        return False
+    return all(p is None or (isinstance(p, torch.Tensor) and p.is_leaf) for p in params)
+
+
+def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_dx16, want_dxsum, params=None):
+    """-> (dz, dx32 | None, dx16 | None, dgamma, dbeta, dxsum | None).  `params` = (gamma, beta, bias) PARAMETERS (bias:
+    of the dense layer whose output fed the LayerNorm, or None): the per-block partials of their gradients are then
+    summed by ONE grouped launch at the end of the pass (54 tiny reductions leave the critical path of a step), published
+    there as `.grad` (wgrad.defer_ln_reduce) and returned as None here."""
     M, H = dy2.shape
     dev = dy2.device
     dz = torch.empty(M, H, dtype=torch.float32, device=dev)
@@ -522,9 +544,14 @@ def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_
     red = torch.empty(3, H, dtype=torch.float32, device=dev)      # stored (not accumulated) by the reduce kernel
     ws = torch.empty(3 * 256 * H, dtype=torch.float32, device=dev)
     d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp)
+    defer = _can_defer_ln(params, dev, H)
     L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dx16),
-                                 _p(red[0]), _p(red[1]), _p(red[2]) if want_dxsum else None, _p(ws), _p(rng_state(dev)), _stream()),
+                                 None if defer else _p(red[0]), None if defer else _p(red[1]),
+                                 _p(red[2]) if (want_dxsum and not defer) else None, _p(ws), _p(rng_state(dev)), _stream()),
             "hamt_ln_bwd")
+    if defer:
+        _defer_ln_reduce(M, H, ws, red, want_dxsum, params, dev)
+        return dz, dx, dx16, None, None, None
     return dz, dx, dx16, red[0], red[1], (red[2] if want_dxsum else None)
 
 
@@ -540,6 +567,7 @@ class LnFn(torch.autograd.Function):
         r2 = residual.reshape(-1, H).contiguous() if residual is not None else None
         y, y16, z, mean, rstd, cid = _ln_fwd(x2, r2, gamma.detach(), beta.detach(), eps, p_pre, p_post, want16)
         ctx.save_for_backward(z, mean, rstd, gamma)
+        ctx.ln_params = (gamma, beta, None)
         ctx.args = (float(eps), float(p_pre), float(p_post), cid, residual is not None, x.shape)
         if y16 is not None:
             ctx.mark_non_differentiable(y16)
@@ -553,7 +581,8 @@ class LnFn(torch.autograd.Function):
         z, mean, rstd, gamma = ctx.saved_tensors
         eps, p_pre, p_post, cid, has_res, xshape = ctx.args
         dy2 = dy.reshape(z.shape).contiguous()
-        dz, dx, _, dgamma, dbeta, _ = _ln_bwd(dy2, z, mean, rstd, gamma.detach(), eps, p_pre, p_post, cid, True, False, False)
+        dz, dx, _, dgamma, dbeta, _ = _ln_bwd(dy2, z, mean, rstd, gamma.detach(), eps, p_pre, p_post, cid, True, False, False,
+                                              params=ctx.ln_params)
         gx = (dx if dx is not None else dz).view(xshape)
         return gx, (dz.view(xshape) if has_res else None), dgamma, dbeta, None, None, None, None
 

@@ -30,6 +30,8 @@ from . import _lib as L
 ENABLED = os.environ.get("HAMT_NO_DEFER_WGRAD") is None     # ablation switch: compute every dW immediately
 
 _items: List[tuple] = []
+_vecs: List[tuple] = []      # (parameter, gradient tensor): published as .grad at flush
+_lnred: List[tuple] = []     # (ws, red, M, H, want_dxsum): LayerNorm-backward partials to sum in one grouped launch at flush
 _scheduled = [False]
 _handler = [None]            # optional consumer of the queued items (multi-GPU overlap, parallel.OverlappedGradSync)
 stats = {"flushes": 0, "problems": 0}
@@ -64,9 +66,24 @@ def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: t
     if b is not None and not b.requires_grad:
         b = None
     _items.append((w, b, dy16, x16))
+    _schedule()
+
+
+def _schedule():
     if not _scheduled[0]:
         _scheduled[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(flush)
+
+
+def defer_ln_reduce(ws, red, M, H, want_dxsum, pairs):
+    """LayerNorm backward left its per-block partials in `ws` (ops._ln_bwd): sum them into `red` ([3, H]: dgamma, dbeta,
+    column sums of dx) in the grouped launch at the end of the pass, then publish `pairs` = [(parameter, row of red)] as
+    `.grad` (added to an existing one).  The Function's backward returns None for these parameters."""
+    _lnred.append((ws, red, M, H, want_dxsum))
+    for p, t in pairs:
+        if p is not None and t is not None and p.requires_grad:
+            _vecs.append((p, t))
+    _schedule()
 
 
 def table_entries(descs, n: int) -> int:
@@ -92,6 +109,8 @@ def pending() -> int:
 def reset():
     """Drop queued work (after an exception inside a backward pass left the queue behind)."""
     _items.clear()
+    _vecs.clear()
+    _lnred.clear()
     _scheduled[0] = False
 
 
@@ -118,13 +137,30 @@ def flush():
     """Launch everything queued and publish the results as ``.grad``.  Runs as the autograd engine's end-of-pass
     callback (on the caller's current stream); harmless to call when the queue is empty."""
     from .ops import _stream
-    items = list(_items)
+    items, vecs, lnred = list(_items), list(_vecs), list(_lnred)
     _items.clear()
+    _vecs.clear()
+    _lnred.clear()
     _scheduled[0] = False
-    if not items:
+    if not items and not lnred:
         return
     from . import streams
     streams.join_all()                # operands queued by backward nodes that ran on the second compute stream
+    if lnred:                         # every LayerNorm's dgamma / dbeta / bias-gradient partials: one launch
+        n = len(lnred)
+        descs = (L.LnReduceDesc * n)()
+        cur = torch.cuda.current_stream()
+        for i, (ws, red, M, H, want_dxsum) in enumerate(lnred):
+            ws.record_stream(cur)         # (allocated under whichever compute stream ran that LayerNorm backward)
+            red.record_stream(cur)
+            d = descs[i]
+            d.ws, d.dgamma, d.dbeta, d.dxsum, d.M, d.H = ws.data_ptr(), red[0].data_ptr(), red[1].data_ptr(), (red[2].data_ptr() if want_dxsum else None), M, H
+        table = torch.empty(n * L.LNRED_TABLE_ENTRY, dtype=torch.uint8, device=lnred[0][0].device)
+        L.check(L.load().hamt_ln_bwd_reduce_grouped(n, descs, table.data_ptr(), table.numel(), _stream()), "hamt_ln_bwd_reduce_grouped")
+        for p, t in vecs:
+            p.grad = t if p.grad is None else p.grad + t
+    if not items:
+        return
     if _handler[0] is not None:
         stats["flushes"] += 1
         stats["problems"] += len(items)
