@@ -174,7 +174,7 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         (5120, 768, 768, 0, True, 0), (5120, 768, 3072, 0, False, 0), (5120, 3072, 768, 1, True, 1), (384, 768, 768, 0, True, 0),
         (2368 + 64 - 2368 % 64, 104, 136, 0, True, 0), (64, 8, 128, 1, False, 0), (11520, 768, 768, 0, True, 1), (640, 2304, 768, 0, True, 0),
     ]
-    specs = specs * 6      # > one kernarg table (40 problems) => several launches
+    specs = specs * 6      # > one kernarg table (60 entries) => several table-write launches
     keep, refs = [], []
     descs = (L.WgradDesc * len(specs))()
     for i, (K, M, N, aw, wdb, ab) in enumerate(specs):

@@ -434,13 +434,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
 // split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
-constexpr int WG_MAX = 40;                       // table entries carried by one kernarg block
+constexpr int WG_MAX = 60;                       // table entries carried by one kernarg block
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
 };
 struct WgradChunk { WgradProb p[WG_MAX]; };
-// The problem table lives in caller-provided device memory and is WRITTEN BY KERNELS whose kernargs carry it 40 entries
+// The problem table lives in caller-provided device memory and is WRITTEN BY KERNELS whose kernargs carry it 60 entries
 // at a time: no host buffer has to outlive the call, so the whole sequence is hipGraph-capturable as is.
 __global__ void wgrad_table_write_kernel(WgradChunk c, WgradProb* tab, int off, int cnt) {
   if ((int)threadIdx.x < cnt) tab[off + threadIdx.x] = c.p[threadIdx.x];
