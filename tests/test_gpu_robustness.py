@@ -1,0 +1,197 @@
+"""-m gpu: state-handling regressions of the host side (graph replay inputs, weight shadows, optimizer checkpoints, the deferred
+weight-gradient queue after a failed backward pass).  The arithmetic itself is covered by test_gpu_model / test_gpu_ops."""
+import warnings
+
+import pytest
+import torch
+
+from _util import load_npz, tiny_cfg
+from test_gpu_model import DEV, build
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
+    store = load_npz("tiny_pretrain.npz")
+    cfg = tiny_cfg()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=int(store["meta/sd_seed"]))
+    return store, cfg, sd
+
+
+def _model_opt(cfg, sd, eps=1.0, p_drop=0.0):
+    from vln_hamt_amd.optim import AdamW
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    m = build(cfg, sd, "bf16", train=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = p_drop
+    named = list(m.named_parameters())
+    groups = [{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+              {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}]
+    return m, AdamW(groups, lr=1e-3, betas=(0.9, 0.98), eps=eps)
+
+
+def _eager_step(m, o, b, task):
+    from vln_hamt_amd.optim import clip_grad_norm_
+    loss = m(b, task, True).mean()
+    loss.backward()
+    clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+    o.step()
+    o.zero_grad()
+    return float(loss)
+
+
+def _worst(m1, m2):
+    return max(float((a - b).abs().max()) for (_, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()))
+
+
+def test_graph_step_trains_on_the_batch_it_is_given(tiny):
+    """a replay must run on the batch passed to step(), not on the batch the key was captured with."""
+    from vln_hamt_amd import _lib as L
+    from vln_hamt_amd.graph import GraphedTrainStep
+    from vln_hamt_amd.synth import make_batch
+    _, cfg, sd = tiny
+    bs = [make_batch("sap", 4, cfg, seed=50 + i, txt_len=20, hist_len=4, device=DEV) for i in range(4)]
+    m1, o1 = _model_opt(cfg, sd)
+    l1 = [_eager_step(m1, o1, b, "sap") for b in bs]
+    m2, o2 = _model_opt(cfg, sd)
+    gs = GraphedTrainStep(m2, o2, 5.0)
+    l2 = [float(gs.step("sap", b, "sap")) for b in bs]          # ONE key, four different batches
+    torch.cuda.synchronize()
+    assert len(gs.graphs) == 1
+    assert max(abs(a - b) for a, b in zip(l1, l2)) < 1e-4, (l1, l2)
+    assert len({round(x, 5) for x in l2}) == 4, l2                  # the four batches really differ
+    w = _worst(m1, m2)
+    assert w < 2e-5, w
+    # the captured step's own inputs can be filled by the caller: nothing to copy then
+    st = gs.static_batch("sap")
+    for k, v in bs[0].items():
+        if torch.is_tensor(v):
+            st[k].copy_(v)
+    gs.step("sap", st, "sap")
+    # a batch of another shape under the same key is an error, not a silent replay of the captured shape
+    other = make_batch("sap", 2, cfg, seed=9, txt_len=20, hist_len=4, device=DEV)
+    with pytest.raises(L.HamtError, match="key_for"):
+        gs.step("sap", other, "sap")
+    assert GraphedTrainStep.key_for("sap", other) != GraphedTrainStep.key_for("sap", bs[0])
+    # MLM without the index list cannot be captured (nonzero() = host sync + data-dependent shape)
+    mlm = make_batch("mlm", 4, cfg, seed=1, txt_len=20, hist_len=4, device=DEV)
+    mlm.pop("txt_label_idx", None)
+    with pytest.raises(L.HamtError, match="txt_label_idx"):
+        gs.step("mlm", mlm, "mlm")
+
+
+def test_weight_shadow_follows_in_place_parameter_writes(tiny):
+    """load_state_dict / p.data.copy_ after materialize() must not leave the GEMMs on a stale bf16 shadow."""
+    from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd.synth import make_batch
+    _, cfg, sd = tiny
+    b = make_batch("sap", 4, cfg, seed=3, txt_len=20, hist_len=4, device=DEV)
+    sd2 = make_state_dict(pretrain_param_shapes(cfg), seed=77)
+    m, o = _model_opt(cfg, sd)
+    o.materialize()
+    m.eval()
+    with torch.no_grad():
+        before = m(b, "sap", False).clone()
+        m.load_state_dict(sd2)                                      # in-place copies into views of the arena
+        after = m(b, "sap", False).clone()
+    ref = build(cfg, sd2, "bf16")
+    with torch.no_grad():
+        want = ref(b, "sap", False)
+    fin = torch.isfinite(want)
+    assert float((before[fin] - want[fin]).abs().max()) > 1e-3       # the two weight sets do differ
+    assert torch.equal(after[fin], want[fin]), float((after[fin] - want[fin]).abs().max())
+    # after one optimizer step the arena shadow is current again and used again
+    m.train()
+    _eager_step(m, o, b, "sap")
+    w = m.bert.encoder.layer[0].attention.self.query.weight
+    from vln_hamt_amd import ops
+    assert ops.arena16_valid(w, w._hamt_arena16)
+    assert torch.equal(ops.weight_operand(w, "bf16").float(), w.detach().to(torch.bfloat16).float())
+
+
+def test_optimizer_state_dict_roundtrip(tiny, tmp_path):
+    """moments and per-parameter step counts live in flat arenas; state_dict()/load_state_dict() must carry
+    them in the reference optimizer's layout (optim/adamw.py:76-84) so that a resume continues the same trajectory."""
+    from vln_hamt_amd.synth import make_batch
+    _, cfg, sd = tiny
+    bs = [make_batch(t, 4, cfg, seed=11 + i, txt_len=20, hist_len=4, device=DEV) for i, t in enumerate(["sap", "sar", "sap", "sar", "sap", "sar"])]
+    tasks = ["sap", "sar", "sap", "sar", "sap", "sar"]
+    m1, o1 = _model_opt(cfg, sd, eps=1e-6)
+    for b, t in zip(bs[:3], tasks[:3]):
+        _eager_step(m1, o1, b, t)
+    osd = o1.state_dict()
+    named = dict(m1.named_parameters())
+    n_state = len(osd["state"])
+    assert 0 < n_state < len(named)                                  # heads of other tasks never stepped: no state, like the reference
+    some = next(iter(osd["state"].values()))
+    assert set(some) == {"step", "exp_avg", "exp_avg_sq"} and some["step"] in (1, 2, 3)
+    path = tmp_path / "train_state.pt"
+    torch.save({"model": m1.state_dict(), "optim": osd}, path)
+    for b, t in zip(bs[3:], tasks[3:]):
+        _eager_step(m1, o1, b, t)
+    ck = torch.load(path)
+    m2, o2 = _model_opt(cfg, sd, eps=1e-6)
+    o2.materialize()
+    m2.load_state_dict(ck["model"])
+    o2.load_state_dict(ck["optim"])
+    for b, t in zip(bs[3:], tasks[3:]):
+        _eager_step(m2, o2, b, t)
+    torch.cuda.synchronize()
+    w = _worst(m1, m2)
+    assert w < 1e-6, w                                               # same kernels, same inputs (dropout off)
+    m3, o3 = _model_opt(cfg, sd, eps=1e-6)                           # a resume WITHOUT the optimizer state diverges measurably
+    m3.load_state_dict(ck["model"])
+    for b, t in zip(bs[3:], tasks[3:]):
+        _eager_step(m3, o3, b, t)
+    assert _worst(m1, m3) > 1e-4
+
+
+def test_wgrad_queue_recovers_after_a_failed_backward(tiny):
+    """an exception inside backward must not leave the deferred-weight-gradient queue switched off."""
+    from vln_hamt_amd import wgrad
+    from vln_hamt_amd.synth import make_batch
+    _, cfg, sd = tiny
+    b = make_batch("sap", 4, cfg, seed=5, txt_len=20, hist_len=4, device=DEV)
+    m, o = _model_opt(cfg, sd)
+    m0, o0 = _model_opt(cfg, sd)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    # fail late in the pass: the text embedding's backward raises after the whole trunk has queued its problems
+    h = m.bert.embeddings.register_forward_hook(lambda mod, i, out: Boom.apply(out))
+    with pytest.raises(RuntimeError, match="boom"):
+        m(b, "sap", True).mean().backward()
+    h.remove()
+    assert wgrad.pending(DEV) > 0                                    # the dead pass left its queue behind
+    o.zero_grad()
+    assert wgrad.pending(DEV) == 0                                   # zero_grad() outside a backward pass drops it
+    for p in m.parameters():
+        p.grad = None
+    # second failure, this time NOT cleaned up by the caller: the next pass must notice the orphan itself
+    h = m.bert.embeddings.register_forward_hook(lambda mod, i, out: Boom.apply(out))
+    with pytest.raises(RuntimeError, match="boom"):
+        m(b, "sap", True).mean().backward()
+    h.remove()
+    for p in m.parameters():
+        p.grad = None
+    n0 = wgrad.stats["dropped_stale"]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        l1 = _eager_step(m, o, b, "sap")
+    assert wgrad.stats["dropped_stale"] > n0 and any("did not finish" in str(w.message) for w in rec)
+    l0 = _eager_step(m0, o0, b, "sap")
+    torch.cuda.synchronize()
+    assert abs(l1 - l0) < 1e-6
+    w = _worst(m, m0)
+    assert w < 1e-6, w                                               # every weight gradient of the good pass was computed
+    assert m.bert.encoder.layer[0].attention.self.query.weight.grad is None and wgrad.pending(DEV) == 0

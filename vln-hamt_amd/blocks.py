@@ -54,7 +54,7 @@ def _packed(ws, bs):
     """If the parameters `ws` (and biases `bs`) are adjacent in the optimizer's arena return ([sumN,K] bf16 view,
     [sumN] fp32 bias view), else None."""
     a0 = getattr(ws[0], "_hamt_arena16", None)
-    if NO_PACKED or a0 is None or a0[1]._version != a0[2]:
+    if NO_PACKED or a0 is None or not all(getattr(w, "_hamt_arena16", None) is not None and ops.arena16_valid(w, w._hamt_arena16) for w in ws):
         return None
     flat_p = a0[1]
     K = ws[0].shape[1]

@@ -8,6 +8,7 @@ before each replay), lazily cached weight shadows are invalidated before capture
 """
 from __future__ import annotations
 
+import copy
 import time
 
 import torch
@@ -58,7 +59,33 @@ class GraphedTrainStep:
         self.opt.launch_step()
         ops.advance_rng_epoch(dev)
 
+    @staticmethod
+    def key_for(task, batch):
+        """A capture key that distinguishes everything a captured step bakes in: the task and every tensor's shape / dtype
+        (incl. the data-dependent lengths of `txt_label_idx` / `hist_mrc_idx`)."""
+        return (task,) + tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+
+    def static_batch(self, key):
+        """The captured step's own input tensors: a loader may write the next batch straight into them (data.collate's
+        `out=`), in which case step() has nothing to copy."""
+        return self.graphs[key][4]
+
+    @staticmethod
+    def _check_capturable(batch, task):
+        need = {"mlm": "txt_label_idx", "mrc": "hist_mrc_idx"}
+        for t, k in need.items():
+            if task.startswith(t) and batch.get(k) is None:
+                raise ops.L.HamtError(f"GraphedTrainStep: task '{task}' needs batch['{k}'] (the masked positions as an index list, "
+                                      "as data.collate emits it): without it the model derives them with nonzero(), a host "
+                                      "synchronisation and a data-dependent shape that cannot be captured")
+
     def _capture(self, key, batch, task):
+        self._check_capturable(batch, task)
+        src = batch
+        batch = copy.copy(src)                 # the graph's static inputs: replays read THESE tensors (step() refills them)
+        for k, v in src.items():
+            if torch.is_tensor(v):
+                batch[k] = v.clone()
         dev = next(self.model.parameters()).device
         cur = torch.cuda.current_stream()
         side = self.stream
@@ -103,15 +130,43 @@ class GraphedTrainStep:
         self.opt._packed = False
         for p in self.opt._params:             # the captured gradient buffers stay alive inside the graph's pool
             p.grad = None
-        self.graphs[key] = (g, loss_c, active, plan)
+        self.graphs[key] = (g, loss_c, active, plan, batch)
         return loss
 
+    @staticmethod
+    def _refill(static, batch, key):
+        """Copy `batch` into the captured step's static inputs (same keys, shapes and dtypes, or a loud error: a captured
+        graph replays the launches of ITS shapes whatever the caller passes)."""
+        if static is batch:
+            return
+        tk = {k for k, v in batch.items() if torch.is_tensor(v)}
+        sk = {k for k, v in static.items() if torch.is_tensor(v)}
+        if tk != sk:
+            raise ops.L.HamtError(f"GraphedTrainStep.step: batch keys differ from the captured batch of key {key!r}: "
+                                  f"missing {sorted(sk - tk)}, unexpected {sorted(tk - sk)}")
+        for k in tk:
+            v, s_ = batch[k], static[k]
+            if v is s_ or (v.data_ptr() == s_.data_ptr() and v.shape == s_.shape):
+                continue
+            if v.shape != s_.shape or v.dtype != s_.dtype:
+                raise ops.L.HamtError(f"GraphedTrainStep.step: batch['{k}'] is {tuple(v.shape)} {v.dtype}, the graph captured under "
+                                      f"key {key!r} has {tuple(s_.shape)} {s_.dtype}; use a key that separates them "
+                                      "(GraphedTrainStep.key_for) so that the new shape is captured on its own")
+            s_.copy_(v, non_blocking=True)
+
     def step(self, key, batch, task):
-        """One optimisation step (param_groups' lr must be set by the caller).  Returns the (static) loss tensor."""
+        """One optimisation step on `batch` (param_groups' lr must be set by the caller).  Returns the (static) loss tensor.
+
+        Contract: the first call with a `key` runs the step eagerly once and captures it; later calls with that key COPY
+        `batch` into the captured step's static input tensors (on the current stream) and replay -- the batch must have the
+        captured keys, shapes and dtypes (HamtError otherwise; `key_for(task, batch)` builds a key that guarantees it).
+        Tensors that already ARE the static inputs (`static_batch(key)`, e.g. filled by the loader) are not copied.  MLM /
+        MRC batches must carry their masked-position index lists (`txt_label_idx` / `hist_mrc_idx`)."""
         ent = self.graphs.get(key)
         if ent is None:
             return self._capture(key, batch, task)
-        g, loss_c, active, plan = ent
+        g, loss_c, active, plan, static = ent
+        self._refill(static, batch, key)
         self.opt.prepare_step(active)
         g.replay()
         if self.grad_sync is not None:

@@ -25,10 +25,14 @@ _call_counter = [0]
 
 def rng_state(device) -> torch.Tensor:
     """Per-device dropout RNG words [seed, epoch] (uint64 stored as int64)."""
-    key = torch.device(device).index or 0
+    d = torch.device(device)
+    key = d.index
+    if key is None:                      # "cuda" without an index means the CURRENT device (cuda:LOCAL_RANK), not cuda:0
+        key = torch.cuda.current_device() if d.type == "cuda" else 0
     t = _rng_state.get(key)
     if t is None:
-        t = torch.tensor([0x243F6A8885A308D3 & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        t = torch.tensor([0x243F6A8885A308D3 & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
+                         device=torch.device(d.type, key) if d.type == "cuda" else d)
         _rng_state[key] = t
     return t
 
@@ -153,14 +157,21 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def arena16_valid(w: torch.Tensor, a) -> bool:
+    """Is the optimizer's bf16 shadow `a` (= w._hamt_arena16) still the image of `w`?  The arena's version counter moves
+    with the optimizer's own updates; an in-place write to the parameter itself (load_state_dict, p.data.copy_, re-init:
+    `p.data` is a view of the arena with its OWN version counter) moves only the parameter's, so both are compared."""
+    return a[1]._version == a[2] and w._version == a[3] and a[1].data_ptr() <= w.data_ptr() < a[1].data_ptr() + a[1].numel() * 4
+
+
 def weight_operand(w: torch.Tensor, prec: str) -> torch.Tensor:
     """GEMM B-operand for a parameter: fp32 master in fp32 mode, cached bf16 shadow in bf16 mode.
     The shadow is refreshed when the parameter's version counter or storage changes."""
     wd = w.detach()
     if prec == "fp32":
         return wd
-    a = getattr(w, "_hamt_arena16", None)       # (bf16 view, fp32 arena, arena version at last sync): optim.AdamW
-    if a is not None and a[1]._version == a[2] and a[1].data_ptr() <= w.data_ptr() < a[1].data_ptr() + a[1].numel() * 4:
+    a = getattr(w, "_hamt_arena16", None)       # (bf16 view, fp32 arena, arena version, parameter version at last sync): optim.AdamW
+    if a is not None and arena16_valid(w, a):
         return a[0]
     c = getattr(w, "_hamt_w16", None)
     key = (w._version, _cache_epoch[0])

@@ -103,7 +103,7 @@ class AdamW(Optimizer):
         ver = self._flat_p._version
         for p, o in zip(self._params, self._offs):
             if p.dim() >= 2:
-                p._hamt_arena16 = (self._flat_p16[o:o + p.numel()].view(p.shape), self._flat_p, ver)
+                p._hamt_arena16 = (self._flat_p16[o:o + p.numel()].view(p.shape), self._flat_p, ver, p._version)
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow arena from the fp32 masters (after loading / broadcasting parameters in place)."""
@@ -196,6 +196,46 @@ class AdamW(Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
         self._packed = False
+        from .. import wgrad
+        dev = self.param_groups[0]["params"][0].device
+        if dev.type == "cuda" and torch._C._current_graph_task_id() < 0 and wgrad.pending(dev):
+            wgrad.reset(dev)                     # leftovers of a backward pass that raised: never carry them into the next step
+
+    # ---------------------------------------------------------------- checkpointing (utils/save.py:42-45 saves optimizer.state_dict())
+    def state_dict(self):
+        """The reference optimizer's layout (optim/adamw.py:76-84): per stepped parameter {'step', 'exp_avg', 'exp_avg_sq'}
+        (copies of the arena slots), plus param_groups -- what ModelSaver writes to train_state_*.pt."""
+        if not self._built:
+            return super().state_dict()
+        self.state.clear()
+        for i, (p, o) in enumerate(zip(self._params, self._offs)):
+            if self._steps[i] > 0:
+                n = p.numel()
+                self.state[p] = {"step": int(self._steps[i]), "exp_avg": self._flat_m[o:o + n].view(p.shape).clone(),
+                                 "exp_avg_sq": self._flat_v[o:o + n].view(p.shape).clone()}
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Restore moments and per-parameter step counts into the arenas (and re-derive the bf16 weight shadow: resuming
+        normally follows a model.load_state_dict)."""
+        super().load_state_dict(state_dict)
+        self.materialize()
+        self._flat_m.zero_()
+        self._flat_v.zero_()
+        self._steps[:] = 0
+        for i, (p, o) in enumerate(zip(self._params, self._offs)):
+            st = self.state.get(p)
+            if st:
+                n = p.numel()
+                self._flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self._flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self._steps[i] = int(st["step"])
+        self.state.clear()
+        self.refresh_shadow()
 
     @property
     def active_mask(self):

@@ -65,14 +65,16 @@ class TaskSchedule:
                 cyc.append(t)
             self.cycle = cyc
         else:
-            self.rng = np.random.Generator(np.random.PCG64(seed))
+            self.seed = int(seed)
             w = np.array([ratios[t] for t in self.tasks], dtype=np.float64)
             self.p = w / w.sum()
 
     def task_at(self, step: int) -> str:
         if self.cyclic:
             return self.cycle[step % len(self.cycle)]
-        return self.tasks[int(self.rng.choice(len(self.tasks), p=self.p))]
+        # a pure function of (seed, step): ranks agree whatever the order / number of calls each of them makes
+        rng = np.random.Generator(np.random.PCG64([self.seed, int(step)]))
+        return self.tasks[int(rng.choice(len(self.tasks), p=self.p))]
 
 
 def wrap_ddp(model, local_rank: int):
@@ -191,12 +193,9 @@ class OverlappedGradSync:
         from . import wgrad
         plan = wgrad.build_plan(items, self.opt, self.n_groups)
         if plan is None:                   # some parameter lives outside the arena: plain semantics
-            wgrad.set_handler(None)
-            try:
-                wgrad._items.extend(items)
-                wgrad.flush()
-            finally:
-                wgrad.set_handler(self._on_flush)
+            ps = wgrad._Pass()
+            ps.items = list(items)
+            wgrad._flush_pass(ps, None)
             return
         if self.mode == "plan":
             self.plan = plan

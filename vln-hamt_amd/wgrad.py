@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
+import warnings
 from typing import List, Optional
 
 import torch
@@ -29,17 +31,100 @@ from . import _lib as L
 
 ENABLED = os.environ.get("HAMT_NO_DEFER_WGRAD") is None     # ablation switch: compute every dW immediately
 
-_items: List[tuple] = []
-_vecs: List[tuple] = []      # (parameter, gradient tensor): published as .grad at flush
-_lnred: List[tuple] = []     # (ws, red, M, H, want_dxsum): LayerNorm-backward partials to sum in one grouped launch at flush
-_scheduled = [False]
-_handler = [None]            # optional consumer of the queued items (multi-GPU overlap, parallel.OverlappedGradSync)
-stats = {"flushes": 0, "problems": 0}
+stats = {"flushes": 0, "problems": 0, "dropped_stale": 0}
 
 
-def set_handler(fn):
-    """Route the end-of-pass item list [(w, b, dy16, x16), ...] to `fn` instead of launching it here (None: default)."""
-    _handler[0] = fn
+class _Pass:
+    """What one backward pass (one autograd graph task) has queued so far."""
+    __slots__ = ("items", "vecs", "lnred")
+
+    def __init__(self):
+        self.items: List[tuple] = []     # (w, b, dy16, x16)
+        self.vecs: List[tuple] = []      # (parameter, gradient tensor): published as .grad at flush
+        self.lnred: List[tuple] = []     # (ws, red, M, H, want_dxsum): LayerNorm-backward partials, one grouped launch at flush
+
+
+class WgradQueue:
+    """The deferred work of the backward passes of ONE device (one process per GPU: one queue per process in practice;
+    the autograd engine runs a device's backward nodes on that device's worker thread and the end-of-pass callbacks on
+    the thread that called .backward(), so the queue cannot be thread-local).  Work is keyed by the autograd graph-task
+    id of the pass that queued it, so a pass that died mid-way (an exception in some backward node: its end-of-pass callback never runs)
+    cannot leak its operands into the next pass or switch the next pass's flush off: the next pass to queue something
+    finds the orphan, drops it (counted in stats["dropped_stale"]) and warns.  `handler` (optional) consumes the item
+    list of a pass instead of the default launch (parallel.OverlappedGradSync)."""
+
+    def __init__(self):
+        self.passes: dict = {}           # graph-task id -> _Pass
+        self.handler = None
+        self.dropped: set = set()        # ids whose work was dropped as stale (a nested outer pass would find itself here)
+
+    def current(self) -> _Pass:
+        tid = torch._C._current_graph_task_id()
+        if tid < 0:
+            raise L.HamtError("wgrad: weight gradients can only be deferred from inside a backward pass")
+        ps = self.passes.get(tid)
+        if ps is None:
+            for old in list(self.passes):            # orphans of passes that never reached their end-of-pass callback
+                n = len(self.passes[old].items) + len(self.passes[old].lnred)
+                del self.passes[old]
+                self.dropped.add(old)
+                stats["dropped_stale"] += n
+                warnings.warn(f"hamt wgrad: dropped {n} queued weight-gradient problems of an earlier backward pass that did "
+                              "not finish (exception inside backward?)", RuntimeWarning)
+            ps = self.passes[tid] = _Pass()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self.flush(tid))
+        return ps
+
+    def pending(self) -> int:
+        return sum(len(p.items) for p in self.passes.values())
+
+    def reset(self):
+        """Drop queued work (after an exception inside a backward pass left the queue behind)."""
+        self.passes.clear()
+
+    @torch.no_grad()
+    def flush(self, tid=None):
+        """Launch everything pass `tid` queued and publish the results as ``.grad``.  Runs as the autograd engine's
+        end-of-pass callback (on the caller's current stream); harmless when nothing is queued."""
+        if tid is None:                              # explicit call: whatever is queued, oldest pass first
+            for t in sorted(self.passes):
+                self.flush(t)
+            return
+        if tid in self.dropped:
+            self.dropped.discard(tid)
+            raise L.HamtError("wgrad: the deferred weight gradients of this backward pass were dropped as stale by a backward "
+                              "pass nested inside it; nested backward passes are not supported on the bf16 path "
+                              "(HAMT_NO_DEFER_WGRAD=1 computes every weight gradient in line)")
+        ps = self.passes.pop(tid, None)
+        if ps is None:
+            return
+        _flush_pass(ps, self.handler)
+
+
+_queues: dict = {}
+_queues_lock = threading.Lock()
+
+
+def queue(device=None) -> WgradQueue:
+    """the queue of `device` (default: the current CUDA device; inside a backward node that is the node's device)"""
+    idx = torch.device(device).index if device is not None else None
+    if idx is None:
+        idx = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    q = _queues.get(idx)
+    if q is None:
+        with _queues_lock:
+            q = _queues.setdefault(idx, WgradQueue())
+    return q
+
+
+def set_handler(fn, device=None):
+    """Route the end-of-pass item list [(w, b, dy16, x16), ...] of the passes on `device` to `fn` instead of launching
+    it here (None: default)."""
+    queue(device).handler = fn
+
+
+def get_handler(device=None):
+    return queue(device).handler
 
 
 def eligible(w: torch.Tensor, dy16: torch.Tensor, x16: torch.Tensor) -> bool:
@@ -65,25 +150,18 @@ def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: t
     """Queue dW (+ db when `b` is a parameter that needs a gradient).  Must be called from inside a backward pass."""
     if b is not None and not b.requires_grad:
         b = None
-    _items.append((w, b, dy16, x16))
-    _schedule()
-
-
-def _schedule():
-    if not _scheduled[0]:
-        _scheduled[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush)
+    queue(dy16.device).current().items.append((w, b, dy16, x16))
 
 
 def defer_ln_reduce(ws, red, M, H, want_dxsum, pairs):
     """LayerNorm backward left its per-block partials in `ws` (ops._ln_bwd): sum them into `red` ([3, H]: dgamma, dbeta,
     column sums of dx) in the grouped launch at the end of the pass, then publish `pairs` = [(parameter, row of red)] as
     `.grad` (added to an existing one).  The Function's backward returns None for these parameters."""
-    _lnred.append((ws, red, M, H, want_dxsum))
+    ps = queue(ws.device).current()
+    ps.lnred.append((ws, red, M, H, want_dxsum))
     for p, t in pairs:
         if p is not None and t is not None and p.requires_grad:
-            _vecs.append((p, t))
-    _schedule()
+            ps.vecs.append((p, t))
 
 
 def table_entries(descs, n: int) -> int:
@@ -102,16 +180,18 @@ def launch(descs, n: int, table: Optional[torch.Tensor] = None):
     L.check(L.load().hamt_wgrad_grouped(n, descs, table.data_ptr(), table.numel(), _stream()), "hamt_wgrad_grouped")
 
 
-def pending() -> int:
-    return len(_items)
+def pending(device=None) -> int:
+    return queue(device).pending()
 
 
-def reset():
-    """Drop queued work (after an exception inside a backward pass left the queue behind)."""
-    _items.clear()
-    _vecs.clear()
-    _lnred.clear()
-    _scheduled[0] = False
+def reset(device=None):
+    """Drop the device's queued work (after an exception inside a backward pass left the queue behind)."""
+    queue(device).reset()
+
+
+def flush(device=None):
+    """Launch whatever is queued for the device (normally the end-of-pass callback does; see WgradQueue.flush)."""
+    queue(device).flush()
 
 
 def _target(p: torch.Tensor, targets: dict, fresh: list):
@@ -133,15 +213,9 @@ def _target(p: torch.Tensor, targets: dict, fresh: list):
 
 
 @torch.no_grad()
-def flush():
-    """Launch everything queued and publish the results as ``.grad``.  Runs as the autograd engine's end-of-pass
-    callback (on the caller's current stream); harmless to call when the queue is empty."""
+def _flush_pass(ps: _Pass, handler):
     from .ops import _stream
-    items, vecs, lnred = list(_items), list(_vecs), list(_lnred)
-    _items.clear()
-    _vecs.clear()
-    _lnred.clear()
-    _scheduled[0] = False
+    items, vecs, lnred = ps.items, ps.vecs, ps.lnred
     if not items and not lnred:
         return
     from . import streams
@@ -161,10 +235,10 @@ def flush():
             p.grad = t if p.grad is None else p.grad + t
     if not items:
         return
-    if _handler[0] is not None:
+    if handler is not None:
         stats["flushes"] += 1
         stats["problems"] += len(items)
-        _handler[0](items)
+        handler(items)
         return
     targets: dict = {}
     fresh: list = []
