@@ -25,6 +25,7 @@
 //     one XCD so that its operand panels cross the fabric once, bias sums fused in.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 void hamt_reduce_partials(int R, int N, const float* ws, float* out, int accumulate, hipStream_t s);
@@ -59,6 +60,16 @@ extern "C" int hamt_prof_fetch(unsigned long long* out8, int reset) {
   for (int k = 0; k < 16; ++k) out8[k] = 0;
   for (unsigned int i = 0; i < n; ++i) for (int k = 0; k < 9; ++k) out8[k] += rec[(size_t)i * 10 + k];
   if (reset) { n = 0; hipMemcpyToSymbol(HIP_SYMBOL(hamt_prof_n), &n, 4); }
+  return 0;
+}
+#endif
+
+#ifdef HAMT_PROF
+__device__ unsigned long long hamt_p8_prof[40];    // [group 0/1][phase 0..3][load, barrier 1, multiply, barrier 2] cycles, then [32..33] waves, [34..35] phases
+extern "C" int hamt_p8_prof_fetch(unsigned long long* out40, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out40, HIP_SYMBOL(hamt_p8_prof), 40 * 8);
+  if (reset) { unsigned long long z[40] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(hamt_p8_prof), z, 40 * 8); }
   return 0;
 }
 #endif
@@ -502,6 +513,234 @@ __global__ __launch_bounds__(512) void gemm_fast256_kernel(GemmArgsF g) {
   gemm_tile<256, EPI, A_KM, B_KM, 2, false, 256, 2, 4>(g, (bid / tiles_n) * 256, (bid % tiles_n) * 256, 0, g.K / BK, 0, nullptr, 0);
 }
 
+// ---------------------------------------------------------------- 256 x 256 tile, 8 waves, two phases per k-tile ("p8")
+// The schedule family of cdna_hip_programming.md section 5 (T3+T4: counted vmcnt, barrier-separated load / multiply
+// segments, the two wave rows running one barrier apart so that on every SIMD one wave multiplies while the other reads
+// LDS and issues DMA), with the phase length chosen from a cycle count of this kernel (tools/p8_prof.py): a multiply
+// segment of 16 MFMAs took ~330 cycles and every barrier ~58, 8 of each per k-tile = 3100 cycles for 2048 of MFMA issue;
+// 32 MFMAs per segment halves the barriers.
+//   * waves 2 (M) x 4 (N), each a 128 x 64 output = a0/a1 (64 rows each) x b0/b1 (32 columns each); phase A multiplies
+//     a0 x (b0, b1), phase B a1 x (b0, b1): 24 fragment reads per 64 MFMAs (a0 + b0 + b1, then a1);
+//   * a k-tile's operands are staged as four 16 KiB units of 128 rows x 64 k: X0 = the a0 rows of both wave rows,
+//     Y0 / Y1 = the b0 / b1 columns of the four wave columns, X1.  X0, Y0, Y1 die in phase A, X1 in phase B; every load
+//     segment ends with lgkmcnt(0) before its barrier, so a slot may be re-staged from the phase after its last read:
+//     phase B(t) issues X0, Y0 of k-tile t+2, phase A(t+1) issues Y1, X1 of k-tile t+2 -- every unit is in flight for at
+//     least two whole phases, 3-4 units stay in flight across the barriers (vmcnt(8) / vmcnt(6));
+//   * DMA addresses are 32-bit element offsets from a scalar base (one v_add / v_mad per piece);
+//   * the epilogue re-tiles the accumulators through wave-private LDS (no workgroup barrier) so that a lane stores 8
+//     consecutive columns.
+constexpr int P8_UNIT = 128 * BK;                // elements per unit (16 KiB)
+constexpr int P8_BUF = 4 * P8_UNIT;              // elements per k-tile buffer (64 KiB): [X0, Y0, Y1, X1]
+
+__device__ __forceinline__ void glds16_off(const bf16_t* base_uniform, unsigned byte_off, unsigned dst_uniform) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base_uniform), "s"(dst_uniform) : "memory", "m0");
+}
+
+// unit-local row / column r (0..127) of the `half`-th unit of an operand -> tile-local index.  GS = log2 of the group
+// size: A units are two groups of 64 rows (one per wave row), B units four groups of 32 columns (one per wave column).
+// GS = 7: the unit is one contiguous half of the tile (used for K-strided B operands, whose DMA pieces then read whole
+// 128-byte lines of the [K][N] rows; wave column wc then owns columns [32 wc, +32) and 128 + [32 wc, +32)).
+template <int GS> __device__ __forceinline__ int p8_index(int r, int half) {
+  if constexpr (GS == 7) return half * 128 + r;
+  else return ((r >> GS) << (GS + 1)) + (half << GS) + (r & ((1 << GS) - 1));
+}
+
+// Per-lane source description of one operand's two units (2 DMA pieces each), computed once per tile.
+//   K-contiguous: off[h][j] = byte offset of (row, chunk) at k = 0; a k-tile adds 128 bytes.
+//   K-strided:    col[h][j] = element column, kk[j] = k row within the tile; offset = min(k0 + kk, kmax) * ld + col.
+template <bool KM> struct P8Src { unsigned off[2][2]; int kk[2]; };
+
+template <bool KM, int GS>
+__device__ __forceinline__ void p8_src_init(P8Src<KM>& sd, int ld, int o0, int omax, int w, int lane) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (!KM) {     // image [128][64], chunk ^= row & 7
+        const int r = w * 16 + j * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (r & 7);
+        int gr = o0 + p8_index<GS>(r, h);
+        gr = gr < omax ? gr : omax;
+        sd.off[h][j] = ((unsigned)gr * (unsigned)ld + (unsigned)chunk * 8u) * 2u;
+      } else {                 // image [64][128], 16-byte chunk ^= col_swz<128>(k row)
+        const int kk = w * 8 + j * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ col_swz<128>(kk);
+        int c = o0 + p8_index<GS>(chunk * 8, h);
+        c = c < ld - 8 ? c : ld - 8;
+        sd.off[h][j] = (unsigned)c;
+        sd.kk[j] = kk;
+      }
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ void p8_issue(const P8Src<KM>& sd, const bf16_t* __restrict__ P, int ld, int kt, int kmax, unsigned dst, int h, int w) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if constexpr (!KM) {
+      glds16_off(P, sd.off[h][j] + (unsigned)kt * (BK * 2), dst + (unsigned)((w * 16 + j * 8) * BK * 2));
+    } else {
+      int gk = kt * BK + sd.kk[j];
+      gk = gk < kmax ? gk : kmax;
+      glds16_off(P, ((unsigned)gk * (unsigned)ld + sd.off[h][j]) * 2u, dst + (unsigned)((w * 8 + j * 4) * 128 * 2));
+    }
+  }
+}
+
+template <int N> __device__ __forceinline__ void p8_wait() {
+  static_assert(N == 0 || N == 2 || N == 6 || N == 8, "p8_wait");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+template <int EPI, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * P8_BUF];          // 128 KiB
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
+  const int nk = g.K / BK;
+  const unsigned lds0 = lds_base_of(lds);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bf_[4][2];
+
+  P8Src<A_KM> sa;
+  P8Src<B_KM> sb;
+  p8_src_init<A_KM, 6>(sa, g.lda, m0, g.M - 1, w, lane);
+  constexpr int BGS = B_KM ? 7 : 5;
+  p8_src_init<B_KM, BGS>(sb, g.ldb, n0, g.N - 1, w, lane);
+  auto slot = [&](int kt, int ty) { return lds0 + (unsigned)(((kt & 1) * P8_BUF + ty * P8_UNIT) * 2); };
+  auto issue_x = [&](int kt, int h) { p8_issue<A_KM>(sa, g.A, g.lda, kt, g.ka_max, slot(kt, h ? 3 : 0), h, w); };
+  auto issue_y = [&](int kt, int h) { p8_issue<B_KM>(sb, g.B, g.ldb, kt, g.kb_max, slot(kt, 1 + h), h, w); };
+  // prologue: k-tile 0 and X0, Y0 of k-tile 1; phase A(0) reads X0, Y0, Y1 of k-tile 0 (three younger units may be in flight)
+  issue_x(0, 0); issue_y(0, 0); issue_y(0, 1); issue_x(0, 1); issue_x(1, 0); issue_y(1, 0);
+  p8_wait<6>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+
+#ifdef HAMT_PROF
+  unsigned long long pf[4][4] = {}, pf_t = 0;
+#define P8_STAMP(P, i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (i) pf[P][i - 1] += t_ - pf_t; pf_t = t_; }
+#else
+#define P8_STAMP(P, i)
+#endif
+  // one phase: load segment | barrier | multiply segment | barrier.  MODE 0: steady state; 1: k-tile nk-2; 2: k-tile nk-1
+  auto phase = [&](int kt, auto pc, auto modec) {
+    constexpr int P = decltype(pc)::value, MODE = decltype(modec)::value;
+    const bf16_t* buf = lds + (kt & 1) * P8_BUF;
+    P8_STAMP(P, 0)
+    if constexpr (P == 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf_[j][s] = frag<B_KM, 128>(buf + 1 * P8_UNIT, 32 * wc + j * 16, s, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][s] = frag<A_KM, 128>(buf + 0 * P8_UNIT, 64 * wr + i * 16, s, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf_[2 + j][s] = frag<B_KM, 128>(buf + 2 * P8_UNIT, 32 * wc + j * 16, s, lane);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][s] = frag<A_KM, 128>(buf + 3 * P8_UNIT, 64 * wr + i * 16, s, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P == 0) {       // A(t): Y1, X1 of k-tile t+1; the next phase reads X1(t)
+      if constexpr (MODE < 2) { issue_y(kt + 1, 1); issue_x(kt + 1, 1); p8_wait<8>(); }
+      else p8_wait<0>();
+    } else {                      // B(t): X0, Y0 of k-tile t+2; the next phase reads X0, Y0, Y1 of k-tile t+1
+      if constexpr (MODE == 0) { issue_x(kt + 2, 0); issue_y(kt + 2, 0); p8_wait<6>(); }
+      else if constexpr (MODE == 1) p8_wait<2>();
+      else p8_wait<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    P8_STAMP(P, 1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    P8_STAMP(P, 2)
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int I0 = P * 4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j][s], af[i][s], acc[I0 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    P8_STAMP(P, 3)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    P8_STAMP(P, 4)
+  };
+  using std::integral_constant;
+  int kt = 0;
+  for (; kt < nk - 2; ++kt) {
+    phase(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    phase(kt, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+  }
+  phase(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+  phase(kt, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+  ++kt;
+  phase(kt, integral_constant<int, 0>{}, integral_constant<int, 2>{});
+  phase(kt, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balances the second wave row's extra barrier
+#ifdef HAMT_PROF
+  if (lane == 0) {
+    for (int p_ = 0; p_ < 4; ++p_) for (int q_ = 0; q_ < 4; ++q_) atomicAdd(&hamt_p8_prof[wr * 16 + p_ * 4 + q_], pf[p_][q_]);
+    atomicAdd(&hamt_p8_prof[32 + wr], 1ull);
+    atomicAdd(&hamt_p8_prof[34 + wr], (unsigned long long)nk);
+  }
+#endif
+
+  // epilogue: two passes (a0 rows, a1 rows) through this wave's own 16 KiB of LDS: [64][64] fp32, float4 slot ^= row & 7
+  float* ct = (float*)lds + w * 4096;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rl = i * 16 + (lane & 15), c4 = j * 4 + (lane >> 4);
+        *(f32x4*)(ct + rl * 64 + ((c4 ^ (rl & 7)) << 2)) = acc[4 * h + i][j];
+      }
+    const int c8 = lane & 7, col = n0 + p8_index<BGS>(32 * wc + (c8 & 3) * 8, c8 >> 2);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 8 + (lane >> 3), row = m0 + 128 * wr + 64 * h + rl;
+      const f32x4 lo = *(const f32x4*)(ct + rl * 64 + (((2 * c8) ^ (rl & 7)) << 2));
+      const f32x4 hi = *(const f32x4*)(ct + rl * 64 + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+      const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      epi_store<EPI, 8>(g, row, col, v8);
+    }
+  }
+}
+
+template <bool A_KM, bool B_KM>
+bool launch_p8(const GemmArgsF& g, hipStream_t s) {
+  const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256));
+  const int e = g.epi;
+#define HAMT_L(E) hipLaunchKernelGGL((gemm_p8_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g)
+  if (e == 0) HAMT_L(0);
+  else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
+  else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
+  else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
+  else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
+  else return false;
+#undef HAMT_L
+  return true;
+}
+
 template <bool A_KM, bool B_KM>
 bool launch_256(const GemmArgsF& g, hipStream_t s) {
   const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256));
@@ -601,6 +840,19 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
   g.ksplit = ks;
   g.part = ks > 1 ? ws : nullptr;
   const dim3 g64(((d->M + 63) / 64) * ((d->N + BN - 1) / BN), ks), g128(((d->M + 127) / 128) * ((d->N + BN - 1) / BN), ks);
+  // 256-square two-phase kernel (one 8-wave workgroup per CU): by estimated time.  Measured on MI355X (tools/gemm_sweep.py,
+  // tools/p8_probe.py): a p8 tile costs ~6 us + 1.55 us per k-tile whatever the grid, the 64/128-row tiles run the
+  // step's shapes at ~620 TFLOP/s.  HAMT_P8=0 / 1 = never / whenever eligible.
+  static const int p8 = getenv("HAMT_P8") ? atoi(getenv("HAMT_P8")) : -1;
+  if (ks == 1 && p8 != 0 && !force_bm && d->K >= 128 && !d->a_kmajor && (!d->b_kmajor || d->ldb >= 256)) {
+    const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const double t_p8 = (double)((t256 + 255) / 256) * (6.0 + 1.55 * (d->K / BK));
+    const double t_small = 2.0 * d->M * d->N * d->K / 620e6;
+    if (p8 == 1 || t_p8 < 0.95 * t_small) {
+      const bool ok = !d->b_kmajor ? launch_p8<false, false>(g, s) : launch_p8<false, true>(g, s);
+      if (ok) return;
+    }
+  }
   if (ks == 1 && use256(d, force_bm)) {
     const bool ok = !d->a_kmajor ? (!d->b_kmajor ? launch_256<false, false>(g, s) : launch_256<false, true>(g, s)) : false;
     if (ok) return;
