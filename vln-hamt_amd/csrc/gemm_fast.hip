@@ -595,13 +595,15 @@ template <int N> __device__ __forceinline__ void p8_wait() {
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int EPI, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
+// COLSUM (weight-gradient form, A = dY stored [K][M]): wave column 0 of the tiles with n0 == 0 also reduces A over k --
+// one extra MFMA per A fragment against an operand that holds ones in row i only, so that the column sums of the wave's
+// 8 fragments land in the 8 rows of ONE accumulator (4 registers): the bias gradient, for free of any extra pass over dY.
+template <int EPI, bool A_KM, bool B_KM, bool COLSUM>
+__device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, float* db, int db_accum) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * P8_BUF];          // 128 KiB
-  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
-  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
+  const bool do_cs = COLSUM && db != nullptr && n0 == 0 && wc == 0;        // wave-uniform
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
   const int nk = g.K / BK;
   const unsigned lds0 = lds_base_of(lds);
 
@@ -676,6 +678,18 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j][s], af[i][s], acc[I0 + i][j], 0, 0, 0);
+    if constexpr (COLSUM) {
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t o2 = (lane & 15) == I0 + i ? 0x3F803F80u : 0u;       // bf16 ones in row I0 + i of the operand
+          union { uint4 u; bf16x8 v; } sel;
+          sel.u = make_uint4(o2, o2, o2, o2);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel.v, af[i][s], cs, 0, 0, 0);
+        }
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     P8_STAMP(P, 3)
@@ -703,6 +717,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
   }
 #endif
 
+  if constexpr (COLSUM) {
+    if (do_cs) {   // cs[e] of lane l = column sum of fragment 4 (l >> 4) + e at row l & 15: fragments 0..7 live in lanes 0..31
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int fi = 4 * (lane >> 4) + e;                                // fragment: a0 rows 0..3, a1 rows 4..7
+        const int row = m0 + 128 * wr + 64 * (fi >> 2) + 16 * (fi & 3) + (lane & 15);
+        if (lane < 32 && row < g.M) db[row] = db_accum ? db[row] + cs[e] : cs[e];
+      }
+    }
+  }
   // epilogue: two passes (a0 rows, a1 rows) through this wave's own 16 KiB of LDS: [64][64] fp32, float4 slot ^= row & 7
   float* ct = (float*)lds + w * 4096;
 #pragma unroll
@@ -724,6 +748,31 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
       epi_store<EPI, 8>(g, row, col, v8);
     }
   }
+}
+
+template <int EPI, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  p8_tile<EPI, A_KM, B_KM, false>(g, (bid / tiles_n) * 256, (bid % tiles_n) * 256, nullptr, 0);
+}
+
+// the grouped weight-gradient launch (see wgrad_grouped_kernel) on the two-phase tile
+__global__ __launch_bounds__(512) void wgrad_grouped_p8_kernel(const WgradProb* __restrict__ tab, WgradXcd xs) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  int lo = xs.start[xcd], hi = xs.start[xcd + 1] - 1;
+  if (hi < lo || idx >= tab[hi].tile_end) return;
+  const int first = lo;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (idx >= tab[mid].tile_end) lo = mid + 1; else hi = mid;
+  }
+  const WgradProb q = tab[lo];
+  const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
+  const int tiles_n = (q.N + 255) / 256;
+  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
+              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1};
+  p8_tile<-2, true, true, true>(g, (local / tiles_n) * 256, (local % tiles_n) * 256, q.db, q.flags & 2);
 }
 
 template <bool A_KM, bool B_KM>
@@ -892,7 +941,8 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   // Two launch classes: problems whose operand rows are >= 256 elements wide can use 256-square tiles; the rest 128 / 64
   // rows.  Within a class: longest reductions first, the short tail tiles fill in behind them.
   std::vector<int> cls[2];
-  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256) ? 0 : 1].push_back(i);
+  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && probs[i].K >= 128) ? 0 : 1].push_back(i);
+  static const int use_p8 = getenv("HAMT_WGRAD_P8") ? atoi(getenv("HAMT_WGRAD_P8")) : 1;   // 0: the one-phase 256-square tile
   const char* fenv = getenv("HAMT_WGRAD_TILE");   // test / tuning override: 256, 128 or 64 (read per call)
   const int force = fenv ? atoi(fenv) : 0;
   {
@@ -967,7 +1017,8 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
       hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, off + b0, cnt);
     }
     const dim3 grid(8 * max_tiles);
-    if (bm == 256) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, tab + off, xs);
+    if (bm == 256 && use_p8) hipLaunchKernelGGL(wgrad_grouped_p8_kernel, grid, dim3(512), 0, s, tab + off, xs);
+    else if (bm == 256) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, tab + off, xs);
     else if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, tab + off, xs);
     else hipLaunchKernelGGL((wgrad_grouped_kernel<64, 128, 2, 2>), grid, dim3(256), 0, s, tab + off, xs);
     HAMT_CHECK_LAUNCH("hamt_wgrad_grouped");
