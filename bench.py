@@ -59,76 +59,6 @@ def build_model(prec, device):
     return model, cfg
 
 
-# HBM bytes per launch of wgrad_grouped_kernel<128> from the PMC passes (profiles/r01_pmc_*.txt: FETCH_SIZE x 2 per
-# MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), keyed by per-GPU batch; None = not collected for that batch
-WGRAD_TRAFFIC_BYTES = {64: int((2 * 2386062.4 + 521465.0) * 1024)}   # ~5.4 GB per launch, mean over the task mix (operands ~2 GB + 0.5 GB of dW)
-
-
-def time_gemm_probe(batch, device, iters=30):
-    """Secondary probe: the bf16 MFMA GEMM at the text FFN-1 shape (M = B*80 rows, N = 3072, K = 768; forward + bias),
-    HIP-event timed on the launch stream.  Algorithmic FLOPs = 2*M*N*K per launch."""
-    from vln_hamt_amd import ops
-    M, N, K = batch * L_TXT, FFN, H
-    a = torch.randn(M, K, device=device).to(torch.bfloat16)      # operands as the step feeds them: bf16, K-contiguous
-    w = (torch.randn(N, K, device=device) * 0.05).to(torch.bfloat16)
-    bias = torch.randn(N, device=device)
-    out = torch.empty(M, N, device=device)
-    for _ in range(5):
-        ops.gemm(a, w, out, bias=bias, prec="bf16")
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
-    s.record()
-    for _ in range(iters):
-        ops.gemm(a, w, out, bias=bias, prec="bf16")
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
-    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return {"kernel": f"bf16 MFMA GEMM + bias, NT, M={M} N={N} K={K} (text FFN-1 forward shape; tile picked by the launcher)", "achieved": round(tf, 2),
-            "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2)}
-
-
-def time_gemm_family(model, cfg, batch, device, iters=5):
-    """The other big consumer (rocprofv3: gemm_fast_kernel<64|128, BIAS, NT>, the forward projections): every such call of
-    one SAP forward pass is recorded (operands, bias, output) and the list re-issued under HIP events; achieved =
-    sum(2*M*N*K) / time, avg_launch_us comparable with the rocprofv3 averages of those kernels."""
-    from vln_hamt_amd import _lib as Lb, ops
-    from vln_hamt_amd.synth import make_batch
-    b = make_batch("sap", batch, cfg, seed=4243, txt_len=L_TXT, hist_len=T_HIST, device=device)
-    calls, orig = [], ops.gemm
-
-    def rec(a, bb, out, **kw):
-        if kw.get("bias") is not None and not kw.get("a_kmajor") and not kw.get("b_kmajor") and kw.get("epilogue", 0) == 0 \
-                and a.dtype == torch.bfloat16 and bb.dtype == torch.bfloat16 and a.shape[1] % 64 == 0:
-            calls.append((a, bb, out, kw))
-        return orig(a, bb, out, **kw)
-
-    ops.gemm = rec
-    import vln_hamt_amd.blocks as blk
-    blk_gemm, blk.gemm = blk.gemm, rec
-    try:
-        with torch.no_grad():
-            model(b, "sap", True)
-    finally:
-        ops.gemm, blk.gemm = orig, blk_gemm
-    torch.cuda.synchronize()
-    flops = sum(2.0 * o.shape[0] * o.shape[1] * a.shape[1] for a, _, o, _ in calls)
-    run = lambda: [orig(a, bb, o, **kw) for a, bb, o, kw in calls]
-    run()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        run()
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
-    tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": f"gemm_fast_kernel<64|128, BIAS, NT>: the {len(calls)} forward projection GEMMs of one SAP pass, B={batch} (eager re-issue: "
-                      "includes host launch gaps for the small ones)", "achieved": round(tf, 2), "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / max(1, len(calls)), 2)}
-
-
 def time_xattn_probe(batch, device, reps=20):
     """The cross-modal attention kernels (vilmodel.py:327-348 inside the x-layers) at the step's own shapes: text queries over
     the 6 history + 37 observation tokens and the reverse, 12 heads of 64, bf16, dropout 0.1, key mask.  They are HBM /
@@ -182,68 +112,6 @@ def time_xattn_probe(batch, device, reps=20):
                                     "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "tflops": round(flops / us / 1e6, 1)}
     return {"kernel": f"attn_s128_fwd/bwd_kernel (x-layer cross attention, B={batch}, 12 heads x 64, bf16, dropout 0.1)", "bound": "hbm",
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "cases": res}
-
-
-def time_wgrad_roofline(model, cycle, batch, device, iters=3):
-    """Live HIP-event timing of the dominant kernel of the step (rocprofv3: wgrad_grouped_kernel<256,256,2,4>, profiles/):
-    for every step of one task-mix cycle (`cycle` = [(task, batch)] x 12, the very batches of the timed region) the
-    grouped weight-gradient launch of that backward pass is re-issued from the problem list the pass queued (same
-    operands, scratch outputs; the problems of the 256-square-tile class = ONE launch of the kernel per step), so the mean
-    launch duration is over the same population of launches as the rocprofv3 kernel-trace average.
-    Algorithmic FLOPs = sum over problems of 2*M*N*K."""
-    from vln_hamt_amd import _lib as Lb, ops, wgrad
-    lib = Lb.load()
-    lists, keep = {}, []
-    for task, b in cycle:
-        if task in lists:
-            continue
-        items = []
-        prev = wgrad.get_handler()
-        wgrad.set_handler(items.extend)
-        try:
-            model(b, task, True).mean().backward()
-        finally:
-            wgrad.set_handler(prev)
-        for p_ in model.parameters():
-            p_.grad = None
-        items = [it for it in items if it[2].stride(0) >= 256 and it[3].stride(0) >= 256]   # the 256-square-tile launch class
-        n = len(items)
-        descs = (Lb.WgradDesc * n)()
-        flops = 0.0
-        for i, (w, bb, dy16, x16) in enumerate(items):
-            dw = torch.empty(w.shape, dtype=torch.float32, device=device)
-            db = torch.empty(w.shape[0], dtype=torch.float32, device=device)
-            keep += [dw, db, dy16, x16]
-            d = descs[i]
-            d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), (db.data_ptr() if bb is not None else None)
-            d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
-            flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
-        tab = torch.empty(wgrad.table_entries(descs, n) * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
-        lists[task] = (n, descs, tab, flops)
-
-    def run(task):
-        n, descs, tab, _ = lists[task]
-        Lb.check(lib.hamt_wgrad_grouped(n, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
-    for task, _ in cycle:
-        run(task)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
-    s.record()
-    for _ in range(iters):
-        for task, _ in cycle:
-            run(task)
-    e.record()
-    torch.cuda.synchronize()
-    launches = iters * len(cycle)
-    ms = s.elapsed_time(e) / launches
-    flops = sum(lists[t][3] for t, _ in cycle) / len(cycle)        # mean per launch over the mix
-    tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": f"wgrad_grouped_kernel<256,256,2,4> (bf16 MFMA; the weight-gradient problems of each backward pass of one "
-                      f"{len(cycle)}-step task-mix cycle, {min(v[0] for v in lists.values())}-{max(v[0] for v in lists.values())} problems per launch, B={batch})",
-            "flops_per_call": flops, "launches_per_call": 1, "avg_launch_us": round(ms * 1e3, 2),
-            "per_task_gflop": {t: round(v[3] / 1e9, 1) for t, v in lists.items()}}
 
 
 def cpu_baseline(budget_s=20.0, batch=16):
@@ -301,6 +169,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-probes", action="store_true", help="only the timed steps (for rocprofv3 runs: no probe launches in the kernel statistics)")
+    ap.add_argument("--also-batch", type=int, default=-1, help="second per-GPU batch reported in `batch_sweep` (default: 16, the reference's "
+                    "per-GPU batch, when --batch is left at 64 on one GPU; 0 = none)")
     args = ap.parse_args()
 
     from vln_hamt_amd import ops
@@ -338,11 +209,12 @@ def main():
     n_distinct = 12
     batches = {}
 
-    def get_batch(step):
+    def get_batch(step, bsz=None):
+        bsz = bsz or args.batch
         task = sched.task_at(step) if sched else args.task
-        key = (task, step % n_distinct)
+        key = (task, step % n_distinct, bsz)
         if key not in batches:                          # synthetic inputs resident in HBM before the timed region
-            b = make_batch(task, args.batch, cfg, seed=1234 + rank + 7919 * (step % n_distinct), txt_len=L_TXT,
+            b = make_batch(task, bsz, cfg, seed=1234 + rank + 7919 * (step % n_distinct), txt_len=L_TXT,
                            hist_len=T_HIST, mlm_exact=12 if task == "mlm" else None, device=device)
             if task == "itm":
                 r = make_itm_rng(b, seed=step)
@@ -361,14 +233,15 @@ def main():
         from vln_hamt_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(model, opt, max_grad_norm=5.0, grad_sync=grad_sync)
 
-    def train_step(step):
-        task, b = get_batch(step)
+    def train_step(step, bsz=None):
+        bsz = bsz or args.batch
+        task, b = get_batch(step, bsz)
         if graphed is not None:
             gstep[0] += 1
             lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
             for g in opt.param_groups:
                 g["lr"] = lr
-            key = (task, step % n_distinct)
+            key = (task, step % n_distinct, bsz)
             graphed.step(key, b, task)
             # the bench's inputs are resident in HBM: keep working on the captured step's own static input tensors (a
             # loader would write each new batch into them; GraphedTrainStep.step copies any other batch in)
@@ -391,26 +264,29 @@ def main():
     if graphed is not None and args.warmup < n_distinct:
         log(f"note: warmup raised to {n_distinct} so that every (task, batch) graph is captured before the timed region")
         args.warmup = n_distinct
-    for s in range(args.warmup):
-        t_ = time.perf_counter()
-        tk, _ = train_step(s)
-        if s < 3:
-            torch.cuda.synchronize()
-            log(f"warmup step {s} ({tk}): {time.perf_counter() - t_:.3f} s")
-    torch.cuda.synchronize()
-    log("warmup done")
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    samples, flops = 0, 0.0
-    for s in range(args.warmup, args.warmup + args.steps):
-        task, n = train_step(s)
-        samples += n
-        flops += 3.0 * trunk_fwd_flops(task) * n
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = max_over_ranks(time.perf_counter() - t0, device)
+    def timed_region(bsz, warmup, steps, verbose=True):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; returns (seconds = max over ranks, samples, flops)"""
+        for s in range(warmup):
+            t_ = time.perf_counter()
+            tk, _ = train_step(s, bsz)
+            if s < 3 and verbose:
+                torch.cuda.synchronize()
+                log(f"warmup step {s} ({tk}): {time.perf_counter() - t_:.3f} s")
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        samples, flops = 0, 0.0
+        for s in range(warmup, warmup + steps):
+            task, n = train_step(s, bsz)
+            samples += n
+            flops += 3.0 * trunk_fwd_flops(task) * n
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return max_over_ranks(time.perf_counter() - t0, device), samples, flops
+
+    dt, samples, flops = timed_region(args.batch, args.warmup, args.steps)
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
     total_samples = sum_over_ranks(float(samples), device)
     total_flops = sum_over_ranks(flops, device)
@@ -432,17 +308,34 @@ def main():
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
         }
+        also = args.also_batch if args.also_batch >= 0 else (16 if (args.batch == 64 and world == 1 and args.task == "mix") else 0)
+        if also and world == 1 and not args.no_probes:
+            # the reference's own per-GPU batch (pretrain_r2r.json:9) next to the headline batch, same model / optimizer / steps
+            dt2, smp2, fl2 = timed_region(also, args.warmup, args.steps, verbose=False)
+            out["batch_sweep"] = [{"per_gpu_batch": also, "value": round(smp2 / dt2, 2), "unit": "panorama-steps/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                                   "model_tflops_per_gpu": round(fl2 / dt2 / 1e12, 2), "mfma_roofline_frac_end_to_end": round(fl2 / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4)}]
+            log(f"batch {also}: {dt2 / args.steps * 1e3:.3f} ms/step")
         if args.task == "mix":
             cycle = [get_batch(s_) for s_ in range(len(sched.cycle))]
         else:
             cycle = [get_batch(0)]
-        out["roofline"] = time_wgrad_roofline(model, cycle, args.batch, device)
-        out["roofline"]["traffic"] = WGRAD_TRAFFIC_BYTES.get(args.batch)
-        out["roofline_probe_ffn1"] = time_gemm_probe(args.batch, device)
-        out["roofline_probe_fwd_gemms"] = time_gemm_family(model, cfg, args.batch, device)
-        out["roofline_probe_xattn"] = time_xattn_probe(args.batch, device)
-        log("roofline probe done; timing the CPU oracle baseline")
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_probes:
+            from tools import roofline_probe as rp
+            table = rp.kernel_table(model, opt, cycle, device)
+            dom = dict(table[0])                            # the kernel with the largest share of a step
+            traffic, src = rp.traffic_of(dom["kernel"], args.batch)
+            out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                               "traffic": traffic, "traffic_source": src, "kernel": dom["kernel"], "per_step_ms": dom["per_step_ms"],
+                               "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                               "algorithmic_work_per_launch": dom["work_per_launch"],
+                               "how": "dominant kernel of the step = largest per-step total among the kernels of one task-mix cycle; its launches are "
+                                      "re-issued (same operands, same epilogues) as a captured hipGraph and timed with HIP events on the launch stream; "
+                                      "work = 2MNK per GEMM launch (34 B per parameter for the AdamW kernel)"}
+            out["kernel_table"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in table[:12]]
+            out["roofline_subblock_xattn"] = rp.subblock_xattn(model, args.batch, device)
+            out["roofline_probe_xattn"] = time_xattn_probe(args.batch, device)
+        log("roofline probes done; timing the CPU oracle baseline")
+        if world == 1 and not args.no_cpu_baseline and not args.no_probes:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         else:
             out["cpu_baseline"] = None

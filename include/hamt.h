@@ -41,6 +41,19 @@ typedef enum { HAMT_PREC_BF16 = 0, HAMT_PREC_F32 = 1 } hamt_prec;
 int hamt_version(void);
 /* copies the calling thread's last error text into buf (NUL terminated); returns its length */
 int hamt_last_error(char* buf, size_t n);
+/* name (as rocprofv3 prints it, template arguments included) of the kernel the calling thread's most recent hamt_gemm /
+ * hamt_gemm_ws call launched for its contraction -- lets a profiler attribute recorded calls to kernel-trace rows */
+int hamt_last_kernel(char* buf, size_t n);
+/* Caller-provided scratch sizes (the library never allocates).  shape[] by op:
+ *   HAMT_WS_GEMM_SPLITK  {M, N, K}  bytes hamt_gemm_ws can use for its deterministic split-K (0: it will not split)
+ *   HAMT_WS_COLSUM       {M, N}     hamt_colsum `ws`
+ *   HAMT_WS_SUMSQ        {}         hamt_sumsq `ws`
+ *   HAMT_WS_LN_BWD       {M, H}     hamt_ln_bwd / hamt_ln_bwd_add `ws`
+ *   HAMT_WS_WGRAD_TABLE  {M_0, M_1, ...}  (output rows of every problem) hamt_wgrad_grouped `table`
+ *   HAMT_WS_LNRED_TABLE  {n}        hamt_ln_bwd_reduce_grouped `table`
+ * returns the size in bytes, or 0 for an unknown op / malformed shape */
+enum { HAMT_WS_GEMM_SPLITK = 0, HAMT_WS_COLSUM = 1, HAMT_WS_SUMSQ = 2, HAMT_WS_LN_BWD = 3, HAMT_WS_WGRAD_TABLE = 4, HAMT_WS_LNRED_TABLE = 5 };
+size_t hamt_workspace_bytes(int op, const int* shape, int nshape);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = epilogue( A[M,K] * B[K,N] )            (all nn.Linear calls of A2-A5, A7, A10, A11,

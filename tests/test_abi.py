@@ -12,7 +12,7 @@ def _header_protos():
     src = open(os.path.join(ROOT, "include", "hamt.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(hamt_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t)\s+(hamt_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         protos[m.group(1)] = n
@@ -39,6 +39,17 @@ def test_library_exports_every_symbol():
     assert lib.hamt_version() == 1
     buf = ctypes.create_string_buffer(64)
     assert lib.hamt_last_error(buf, 64) >= 0
+    assert lib.hamt_last_kernel(buf, 64) >= 0
+    # scratch sizes the callers allocate (hamt_workspace_bytes): pure host arithmetic
+    assert _lib.workspace_bytes(_lib.WS_SUMSQ) == 4096
+    assert _lib.workspace_bytes(_lib.WS_COLSUM, 5120, 768) == 64 * 768 * 4
+    assert _lib.workspace_bytes(_lib.WS_LN_BWD, 5120, 768) == 3 * 256 * 768 * 4
+    assert _lib.workspace_bytes(_lib.WS_WGRAD_TABLE, 768, 2304, 30522) == (12 + 36 + 477) * _lib.WGRAD_TABLE_ENTRY
+    assert _lib.workspace_bytes(_lib.WS_LNRED_TABLE, 54) == 54 * _lib.LNRED_TABLE_ENTRY
+    assert _lib.workspace_bytes(_lib.WS_GEMM_SPLITK, 5120, 3072, 768) == 0          # a grid that fills the chip is not split
+    ks = _lib.workspace_bytes(_lib.WS_GEMM_SPLITK, 128, 768, 8192)
+    assert ks > 0 and ks % (128 * 768 * 4) == 0
+    assert _lib.workspace_bytes(99) == 0
 
 
 def test_struct_layouts_match_header():

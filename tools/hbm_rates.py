@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Achieved HBM rate per kernel = (2 x FETCH_SIZE + WRITE_SIZE) per launch (rocprofv3 --pmc passes summarised by
 pmc_summary.py; KB; x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md) / mean launch duration (kernel-trace
-summary of prof_summary.py).  usage: hbm_rates.py pmc_fetch.txt pmc_write.txt kernel_stats.txt"""
-import re, sys
+summary of prof_summary.py).  usage: hbm_rates.py pmc_fetch.txt pmc_write.txt kernel_stats.txt [--json out.json]
+--json also writes {kernel: {read_bytes, write_bytes, avg_us}} per launch (bench.py's `roofline.traffic` reads it)."""
+import json, re, sys
 from prof_summary import short
 
 def pmc(path, counter):
@@ -16,6 +17,7 @@ def pmc(path, counter):
 fetch, write = pmc(sys.argv[1], "FETCH_SIZE"), pmc(sys.argv[2], "WRITE_SIZE")
 print(f"# (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / mean duration; peak 8 000 GB/s (≈6 300 achievable, MI355X_MICROARCH.md)")
 print(f"{'kernel':72s} {'avg_us':>8s} {'read MB':>9s} {'write MB':>9s} {'GB/s':>8s} {'of 8 TB/s':>9s}")
+table = {}
 for l in open(sys.argv[3]):
     m = re.match(r"(.{90})\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", l)
     if not m:
@@ -27,3 +29,6 @@ for l in open(sys.argv[3]):
     rd, wr = 2 * fetch[key] / 1024, write.get(key, 0.0) / 1024
     gbs = (rd + wr) / 1024 / (us * 1e-6)
     print(f"{k[:72]:72s} {us:8.1f} {rd:9.1f} {wr:9.1f} {gbs:8.0f} {100*gbs/8000:8.1f}%")
+    table[k] = {"read_bytes": int(rd * 2 ** 20), "write_bytes": int(wr * 2 ** 20), "avg_us": us}
+if "--json" in sys.argv:
+    json.dump(table, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -56,6 +56,8 @@ class WgradDesc(C.Structure):
 SIGNATURES = {
     "hamt_version": [],
     "hamt_last_error": [C.c_char_p, sz],
+    "hamt_last_kernel": [C.c_char_p, sz],
+    "hamt_workspace_bytes": [i32, C.POINTER(i32), i32],
     "hamt_gemm": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp],
     "hamt_gemm_ksplit": [C.POINTER(GemmDesc)],
     "hamt_gemm_ws": [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, sz, vp],
@@ -123,7 +125,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = i32
+        fn.restype = sz if name == "hamt_workspace_bytes" else i32
     if lib.hamt_version() != 1:
         raise HamtError("libhamt_hip.so ABI version mismatch")
     _lib = lib
@@ -134,6 +136,21 @@ def last_error() -> str:
     buf = C.create_string_buffer(512)
     load().hamt_last_error(buf, 512)
     return buf.value.decode(errors="replace")
+
+
+def last_kernel() -> str:
+    """kernel the most recent hamt_gemm call of this thread launched (rocprofv3's name, template arguments included)"""
+    buf = C.create_string_buffer(160)
+    load().hamt_last_kernel(buf, 160)
+    return buf.value.decode(errors="replace")
+
+
+def workspace_bytes(op: int, *shape) -> int:
+    arr = (i32 * max(1, len(shape)))(*shape)
+    return int(load().hamt_workspace_bytes(op, arr, len(shape)))
+
+
+WS_GEMM_SPLITK, WS_COLSUM, WS_SUMSQ, WS_LN_BWD, WS_WGRAD_TABLE, WS_LNRED_TABLE = range(6)
 
 
 def check(rc: int, name: str):

@@ -9,6 +9,7 @@
 #define HAMT_WAVE 64
 
 void hamt_set_error(const char* fmt, ...);
+void hamt_set_last_kernel(const char* fmt, ...);
 
 #define HAMT_CHECK_ARG(cond, ...)                      \
   do {                                                 \

@@ -467,6 +467,7 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
     HAMT_CHECK_LAUNCH("hamt_gemm(fast)");
     return HAMT_OK;
   }
+  hamt_set_last_kernel(d->prec == HAMT_PREC_F32 ? "gemm_f32_kernel<%s, %s>" : "gemm_bf16_kernel<%s, %s, ...>", d->a_kmajor ? "true" : "false", d->b_kmajor ? "true" : "false");
   if (d->prec == HAMT_PREC_F32) {
     HAMT_CHECK_ARG(d->dtype_a == HAMT_F32 && d->dtype_b == HAMT_F32, "hamt_gemm: PREC_F32 needs fp32 operands");
     int tiles = ((d->M + F_BM - 1) / F_BM) * ((d->N + F_BN - 1) / F_BN);

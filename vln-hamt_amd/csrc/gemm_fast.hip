@@ -779,7 +779,8 @@ template <bool A_KM, bool B_KM>
 bool launch_p8(const GemmArgsF& g, hipStream_t s) {
   const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256));
   const int e = g.epi;
-#define HAMT_L(E) hipLaunchKernelGGL((gemm_p8_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g)
+#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_p8_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g); \
+                    hamt_set_last_kernel("gemm_p8_kernel<%d, %s, %s>", (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
@@ -794,7 +795,8 @@ template <bool A_KM, bool B_KM>
 bool launch_256(const GemmArgsF& g, hipStream_t s) {
   const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256));
   const int e = g.epi;
-#define HAMT_L(E) hipLaunchKernelGGL((gemm_fast256_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g)
+#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_fast256_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g); \
+                    hamt_set_last_kernel("gemm_fast256_kernel<%d, %s, %s>", (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
@@ -811,7 +813,8 @@ bool launch_256(const GemmArgsF& g, hipStream_t s) {
 template <int BM, bool A_KM, bool B_KM>
 void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   const int e = g.epi;
-#define HAMT_L(E) hipLaunchKernelGGL((gemm_fast_kernel<BM, E, A_KM, B_KM>), grid, dim3(256), 0, s, g)
+#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_fast_kernel<BM, E, A_KM, B_KM>), grid, dim3(256), 0, s, g); \
+                    hamt_set_last_kernel("gemm_fast_kernel<%d, %d, %s, %s>", BM, (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);

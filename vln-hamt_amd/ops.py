@@ -145,7 +145,7 @@ def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=Fal
     M, N = x2d.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x2d.device)
-    ws = torch.empty(64 * N, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(L.workspace_bytes(L.WS_COLSUM, M, N) // 4, dtype=torch.float32, device=x2d.device)
     L.check(L.load().hamt_colsum(M, N, _p(x2d), _ld(x2d), _dt(x2d), _p(out), int(accumulate), _p(ws), _stream()), "hamt_colsum")
     return out
 
@@ -553,7 +553,7 @@ def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_
     Mp = _rup(M) if want_dx16 else 0
     dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want_dx16 else None
     red = torch.empty(3, H, dtype=torch.float32, device=dev)      # stored (not accumulated) by the reduce kernel
-    ws = torch.empty(3 * 256 * H, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.workspace_bytes(L.WS_LN_BWD, M, H) // 4, dtype=torch.float32, device=dev)
     d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp)
     defer = _can_defer_ln(params, dev, H)
     L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dx16),

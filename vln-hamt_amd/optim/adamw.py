@@ -88,7 +88,7 @@ class AdamW(Optimizer):
         self._hyp_slot = 0
         self._hyp = torch.zeros(len(ps), 4, dtype=torch.float32, device=dev)
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._ws = torch.empty(L.workspace_bytes(L.WS_SUMSQ) // 4, dtype=torch.float32, device=dev)
         self._sync_shadow_views()
         self._publish_grad_slots()
         self._built = True

@@ -166,7 +166,7 @@ def defer_ln_reduce(ws, red, M, H, want_dxsum, pairs):
 
 def table_entries(descs, n: int) -> int:
     """upper bound on the launch-table entries of hamt_wgrad_grouped for these problems (include/hamt.h)"""
-    return sum((descs[i].M + 63) // 64 for i in range(n))
+    return L.workspace_bytes(L.WS_WGRAD_TABLE, *[descs[i].M for i in range(n)]) // L.WGRAD_TABLE_ENTRY
 
 
 def launch(descs, n: int, table: Optional[torch.Tensor] = None):
