@@ -88,6 +88,10 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned dst_uniform) 
   // destination) is declared clobbered rather than saved/restored: 3 instructions per piece instead of 5.
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst_uniform) : "memory", "m0");
 }
+// the same with the source as scalar base + 32-bit per-lane byte offset (one VGPR, no 64-bit address arithmetic per piece)
+__device__ __forceinline__ void glds16_off(const bf16_t* base_uniform, unsigned byte_off, unsigned dst_uniform) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base_uniform), "s"(dst_uniform) : "memory", "m0");
+}
 // LDS byte address of a __shared__ object as a plain integer (taken ONCE: every use of the pointer cast costs a null
 // check, s_cmp + s_cselect, per DMA piece otherwise); piece destinations are integer offsets from it.
 __device__ __forceinline__ unsigned lds_base_of(const bf16_t* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)p); }
@@ -103,37 +107,45 @@ template <int R> __device__ __forceinline__ int col_swz(int kk) {
 //   KM == false: operand stored [rows][K] (K contiguous): tile image [R][64], 8 rows per instruction, chunk ^= row & 7
 //   KM == true : operand stored [K][cols] (K strided):    tile image [64][R], 1 KiB = 1024/(2R) k-rows per instruction
 // Out-of-range rows are clamped (re-read a valid row); see the callers for why that is harmless.
-template <bool KM, int R, int NW = 4>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ P, int ld, int r0, int rmax, int k0, int kmax, unsigned lds_bytes,
-                                           int w, int lane) {   // lds_bytes: LDS byte address of the tile image (wave-uniform)
-  if constexpr (!KM) {
-    constexpr int PER_WAVE = R / NW;             // tile rows per wave
+// The per-lane source offsets are computed ONCE per output tile: the address arithmetic of a piece (row clamp,
+// swizzle, 64-bit multiply-add: ~20 VALU instructions, measured ~100 cycles per piece in a load segment) shrinks to one
+// v_add (K-contiguous) or add + min + mad (K-strided) per piece and k-tile.  Offsets are 32-bit: operands < 4 GiB.
+template <bool KM, int R, int NW> struct TileSrc {
+  static constexpr int CH = R / 8, RPI = KM ? 64 / CH : 8, PER_WAVE = KM ? BK / NW : R / NW, NP = PER_WAVE / RPI;
+  unsigned off[NP];
+  int kk0;
+  __device__ __forceinline__ void init(int ld, int r0, int rmax, int w, int lane) {
 #pragma unroll
-    for (int j = 0; j < PER_WAVE / 8; ++j) {
-      const int rbase = w * PER_WAVE + j * 8;    // wave-uniform
-      const int r = rbase + (lane >> 3);
-      const int chunk = (lane & 7) ^ (r & 7);    // source k-chunk that lands in LDS slot (lane & 7)
-      int gr = r0 + r;
-      gr = gr < rmax ? gr : rmax;
-      glds16(P + (size_t)gr * ld + k0 + chunk * 8, lds_bytes + (unsigned)(rbase * BK * 2));
+    for (int j = 0; j < NP; ++j) {
+      if constexpr (!KM) {
+        const int r = w * PER_WAVE + j * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (r & 7);
+        int gr = r0 + r;
+        gr = gr < rmax ? gr : rmax;
+        off[j] = ((unsigned)gr * (unsigned)ld + (unsigned)chunk * 8u) * 2u;
+      } else {
+        const int kk = w * PER_WAVE + j * RPI + lane / CH;
+        const int chunk = (lane % CH) ^ col_swz<R>(kk);
+        int c = r0 + chunk * 8;
+        c = c < ld - 8 ? c : ld - 8;
+        off[j] = (unsigned)c * 2u;
+      }
     }
-  } else {
-    constexpr int CH = R / 8;                    // 16-byte chunks per k-row (32, 16 or 8)
-    constexpr int ROWS_PER_INSTR = 64 / CH;      // 2, 4 or 8
-    constexpr int PER_WAVE = BK / NW;            // k-rows per wave
+    kk0 = KM ? w * PER_WAVE + lane / CH : 0;
+  }
+  __device__ __forceinline__ void issue(const bf16_t* __restrict__ P, int ld, int k0, int kmax, unsigned lds_bytes, int w) const {
 #pragma unroll
-    for (int j = 0; j < PER_WAVE / ROWS_PER_INSTR; ++j) {
-      const int kbase = w * PER_WAVE + j * ROWS_PER_INSTR;   // wave-uniform
-      const int kk = kbase + lane / CH;
-      const int chunk = (lane % CH) ^ col_swz<R>(kk);
-      int gk = k0 + kk;
-      gk = gk < kmax ? gk : kmax;
-      int c = r0 + chunk * 8;
-      c = c < ld - 8 ? c : ld - 8;               // stay inside the row's allocation; masked at the store
-      glds16(P + (size_t)gk * ld + c, lds_bytes + (unsigned)(kbase * R * 2));
+    for (int j = 0; j < NP; ++j) {
+      if constexpr (!KM) {
+        glds16_off(P, off[j] + (unsigned)k0 * 2u, lds_bytes + (unsigned)((w * PER_WAVE + j * 8) * BK * 2));
+      } else {
+        int gk = k0 + kk0 + j * RPI;
+        gk = gk < kmax ? gk : kmax;
+        glds16_off(P, (unsigned)gk * ((unsigned)ld * 2u) + off[j], lds_bytes + (unsigned)((w * PER_WAVE + j * RPI) * R * 2));
+      }
     }
   }
-}
+};
 
 // MFMA fragment (8 bf16 along k for one row/column) of the 16 rows/columns starting at r16, k-step s (32 k)
 template <bool KM, int R>
@@ -290,10 +302,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = lds_base_of(lds);
+  TileSrc<A_KM, BM, NW> src_a;
+  TileSrc<B_KM, BN, NW> src_b;
+  src_a.init(g.lda, m0, g.M - 1, w, lane);
+  src_b.init(g.ldb, n0, g.N - 1, w, lane);
   auto stage = [&](int kt, int slot) {
     const unsigned dst = lds0 + (unsigned)(slot * STAGE * 2);
-    stage_tile<A_KM, BM, NW>(g.A, g.lda, m0, g.M - 1, (kt0 + kt) * BK, g.ka_max, dst, w, lane);
-    stage_tile<B_KM, BN, NW>(g.B, g.ldb, n0, g.N - 1, (kt0 + kt) * BK, g.kb_max, dst + (unsigned)(A_ELEMS * 2), w, lane);
+    src_a.issue(g.A, g.lda, (kt0 + kt) * BK, g.ka_max, dst, w);
+    src_b.issue(g.B, g.ldb, (kt0 + kt) * BK, g.kb_max, dst + (unsigned)(A_ELEMS * 2), w);
   };
   if constexpr (NSTAGE > 1) {
 #pragma unroll
@@ -432,13 +448,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int EPI, bool A_KM, bool B_KM>
+// NST = depth of the operand ring: 2 when two or three workgroups share a CU (they hide each other's DMA latency), 3 - 4 for
+// grids of about one workgroup per CU (the narrow N = 768 outputs), where nothing else covers the ~1000-cycle L2 round trip.
+template <int BM, int EPI, bool A_KM, bool B_KM, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int nk_all = g.K / BK;   // K range of this slice
   const int kt0 = (int)((long)nk_all * blockIdx.y / g.ksplit), kt1 = (int)((long)nk_all * (blockIdx.y + 1) / g.ksplit);
-  gemm_tile<BM, EPI, A_KM, B_KM, 2, false>(g, (bid / tiles_n) * BM, (bid % tiles_n) * BN, kt0, kt1 - kt0, blockIdx.y, nullptr, 0);
+  gemm_tile<BM, EPI, A_KM, B_KM, NST, false>(g, (bid / tiles_n) * BM, (bid % tiles_n) * BN, kt0, kt1 - kt0, blockIdx.y, nullptr, 0);
 }
 
 // ---------------------------------------------------------------- grouped weight gradients
@@ -531,10 +549,6 @@ __global__ __launch_bounds__(512) void gemm_fast256_kernel(GemmArgsF g) {
 //     consecutive columns.
 constexpr int P8_UNIT = 128 * BK;                // elements per unit (16 KiB)
 constexpr int P8_BUF = 4 * P8_UNIT;              // elements per k-tile buffer (64 KiB): [X0, Y0, Y1, X1]
-
-__device__ __forceinline__ void glds16_off(const bf16_t* base_uniform, unsigned byte_off, unsigned dst_uniform) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base_uniform), "s"(dst_uniform) : "memory", "m0");
-}
 
 // unit-local row / column r (0..127) of the `half`-th unit of an operand -> tile-local index.  GS = log2 of the group
 // size: A units are two groups of 64 rows (one per wave row), B units four groups of 32 columns (one per wave column).
@@ -810,14 +824,15 @@ bool launch_256(const GemmArgsF& g, hipStream_t s) {
   return true;
 }
 
-template <int BM, bool A_KM, bool B_KM>
+template <int BM, bool A_KM, bool B_KM, int NST = 2>
 void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   const int e = g.epi;
-#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_fast_kernel<BM, E, A_KM, B_KM>), grid, dim3(256), 0, s, g); \
-                    hamt_set_last_kernel("gemm_fast_kernel<%d, %d, %s, %s>", BM, (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
+#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_fast_kernel<BM, E, A_KM, B_KM, NST>), grid, dim3(256), 0, s, g); \
+                    hamt_set_last_kernel(NST == 2 ? "gemm_fast_kernel<%d, %d, %s, %s>" : "gemm_fast_kernel<%d, %d, %s, %s, %d>", BM, (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false", NST); } while (0)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
+  else if constexpr (NST != 2) launch_bm<BM, A_KM, B_KM, 2>(g, grid, s);   // deep rings are compiled for the narrow-output epilogues only
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_RELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_RELU);
   else if (e == HAMT_EPI_MUL_DGELU) HAMT_L(HAMT_EPI_MUL_DGELU);
@@ -844,6 +859,10 @@ bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void*
   if ((!d->a_kmajor || !d->b_kmajor) && d->K % 64 != 0) return false;
   if (d->a_kmajor && d->K % 64 != 0) return false;   // TN: the caller pads the reduction rows of A with zeros
   if (d->lda % 8 || d->ldb % 8 || ((uintptr_t)A % 16) || ((uintptr_t)B % 16)) return false;
+  {   // the DMA pieces address their operand with 32-bit byte offsets from its base
+    const double a_bytes = 2.0 * (d->a_kmajor ? (double)d->K : (double)d->M) * d->lda, b_bytes = 2.0 * (d->b_kmajor ? (double)d->K : (double)d->N) * d->ldb;
+    if (a_bytes >= 4294967296.0 || b_bytes >= 4294967296.0) return false;
+  }
   if (d->a_kmajor && d->lda < 64) return false;
   if (d->b_kmajor && d->ldb < 128) return false;
   return true;
@@ -909,8 +928,14 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
     const bool ok = !d->a_kmajor ? (!d->b_kmajor ? launch_256<false, false>(g, s) : launch_256<false, true>(g, s)) : false;
     if (ok) return;
   }
-  if (!d->a_kmajor && !d->b_kmajor) { if (bm64) launch_bm<64, false, false>(g, g64, s); else launch_bm<128, false, false>(g, g128, s); }
-  else if (!d->a_kmajor) { if (bm64) launch_bm<64, false, true>(g, g64, s); else launch_bm<128, false, true>(g, g128, s); }
+  static const int force_st = getenv("HAMT_FAST_STAGES") ? atoi(getenv("HAMT_FAST_STAGES")) : 0;
+  const int nst = force_st ? force_st : 2;
+#define HAMT_BMST(AK, BK_) do { \
+    if (bm64) { if (nst == 4) launch_bm<64, AK, BK_, 4>(g, g64, s); else if (nst == 3) launch_bm<64, AK, BK_, 3>(g, g64, s); else launch_bm<64, AK, BK_>(g, g64, s); } \
+    else { if (nst == 4) launch_bm<128, AK, BK_, 4>(g, g128, s); else if (nst == 3) launch_bm<128, AK, BK_, 3>(g, g128, s); else launch_bm<128, AK, BK_>(g, g128, s); } } while (0)
+  if (!d->a_kmajor && !d->b_kmajor) HAMT_BMST(false, false);
+  else if (!d->a_kmajor) HAMT_BMST(false, true);
+#undef HAMT_BMST
   else { if (bm64 && d->lda >= 64) launch_bm<64, true, true>(g, g64, s); else launch_bm<128, true, true>(g, g128, s); }
   if (ks > 1) hamt_reduce_partials(ks, d->M * d->N, ws, (float*)C, (d->epilogue & HAMT_EPI_ACCUM) ? 1 : 0, s);
 }
@@ -935,6 +960,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     HAMT_CHECK_ARG(d.ldy % 8 == 0 && d.ldy >= 64 && d.ldy >= d.M && d.ldx % 8 == 0 && d.ldx >= 128 && d.ldx >= d.N && d.ldw >= d.N,
                    "hamt_wgrad_grouped: problem %d: bad leading dimension (ldy %d, ldx %d, ldw %d)", i, d.ldy, d.ldx, d.ldw);
     HAMT_CHECK_ARG((uintptr_t)d.dy % 16 == 0 && (uintptr_t)d.x % 16 == 0, "hamt_wgrad_grouped: problem %d: operands must be 16-byte aligned", i);
+    HAMT_CHECK_ARG(2.0 * d.K * d.ldy < 4294967296.0 && 2.0 * d.K * d.ldx < 4294967296.0, "hamt_wgrad_grouped: problem %d: operands must be smaller than 4 GiB (32-bit DMA offsets)", i);
     if (d.K > 0) order.push_back(i);
     else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
   }
