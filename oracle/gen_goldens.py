@@ -120,6 +120,28 @@ def grads_summary(named_params, prefix):
     return out
 
 
+def grad_probe(g, n=257):
+    """n evenly strided elements of a gradient (zero padded for tensors with fewer): what tests/ compare element-wise"""
+    f = g.detach().flatten()
+    pr = f[:: max(1, f.numel() // n)][:n]
+    out = np.zeros(n, dtype=np.float32)
+    out[:pr.numel()] = pr.numpy()
+    return out
+
+
+def grads_packed(named_params, prefix):
+    """the same information as grads_summary in three arrays (the canon model has 416 parameters x 6 tasks)"""
+    names, norms, probes = [], [], []
+    for k, p in named_params:
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(p.grad.detach().double().norm().item())
+        probes.append(grad_probe(p.grad))
+    return {f"{prefix}grad_names": np.array(names), f"{prefix}grad_norms": np.array(norms, dtype=np.float64),
+            f"{prefix}grad_probes": np.stack(probes)}
+
+
 def run_task(model, vil, oracle_sd, cfg, batch, task, tag, store, check):
     # ---- reference
     model.zero_grad(set_to_none=True)
@@ -234,10 +256,28 @@ def gen_canon():
             store[pre + "hist_embeds"] = h.numpy()
             if o is not None:
                 store[pre + "ob_probe"] = o[:, :, :16].numpy().copy()
-        with torch.no_grad():
-            orc = HamtOracle(sd, cfg, training=False)
-            ol = orc.forward(batch, task, True, itm_rng)
-        print(f"  [canon {task}] oracle-vs-reference loss max|d|={(ol - loss).abs().max().item():.3e}")
+        # ---- backward at the benchmarked model size (main_r2r.py:237-246: loss.mean().backward()): per-parameter gradient
+        # norms and 257-point probes of every gradient from the REFERENCE's autograd (dropout off: the model is in eval mode)
+        model.zero_grad(set_to_none=True)
+        if task == "itm":
+            np.random.seed(4321)
+            torch.manual_seed(4321)
+        model(batch, task, True).mean().backward()
+        store.update(grads_packed(model.named_parameters(), pre))
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
+        orc = HamtOracle(osd, cfg, training=False)
+        ol = orc.forward(batch, task, True, itm_rng)
+        ol.mean().backward()
+        gd, gmax = 0.0, 0.0
+        for k, p_ in model.named_parameters():
+            if p_.grad is not None:
+                assert osd[k].grad is not None, k
+                gd = max(gd, (osd[k].grad - p_.grad).abs().max().item())
+                gmax = max(gmax, p_.grad.abs().max().item())
+            else:
+                assert osd[k].grad is None or float(osd[k].grad.abs().max()) == 0.0, k
+        model.zero_grad(set_to_none=True)
+        print(f"  [canon {task}] oracle-vs-reference loss max|d|={(ol.detach() - loss).abs().max().item():.3e}  grad max|d|={gd:.3e} (max |g| {gmax:.3e})")
     np.savez_compressed(os.path.join(OUT, "canon_pretrain.npz"), **store)
     print("canon_pretrain.npz:", len(store), "arrays")
 

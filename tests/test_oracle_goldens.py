@@ -119,6 +119,43 @@ def test_canon_full_config_matches_reference():
         np.testing.assert_allclose(loss.numpy(), store[f"{task}/loss"], rtol=2e-5, atol=2e-5, err_msg=task)
 
 
+@pytest.mark.parametrize("task", ["mlm", "sap", "sar", "sprel", "mrc", "itm"])
+def test_canon_backward_matches_reference(task):
+    """Backward at the BENCHMARKED model size (main_r2r.py:237-246): every per-parameter gradient norm and a
+    257-point probe of every gradient, captured from the reference's own autograd on the R2R-canon model (B=2, L=80, T=5)."""
+    from _util import canon_batch, grad_probe
+    store = load_npz("canon_pretrain.npz")
+    cfg = OracleConfig()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=int(store["meta/sd_seed"]))
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
+    batch, itm = canon_batch(store, task, cfg)
+    HamtOracle(osd, cfg).forward(batch, task, True, itm).mean().backward()
+    names = [str(n) for n in store[f"{task}/grad_names"]]
+    norms, probes = store[f"{task}/grad_norms"], store[f"{task}/grad_probes"]
+    assert {k for k, v in osd.items() if v.grad is not None and float(v.grad.abs().max()) > 0} <= set(names)
+    gmax = float(norms.max())
+    for i, k in enumerate(names):
+        g = osd[k].grad
+        assert g is not None, k
+        assert abs(float(g.double().norm()) - norms[i]) <= 1e-4 * max(norms[i], 1e-3 * gmax), (k, float(g.double().norm()), norms[i])
+        np.testing.assert_allclose(grad_probe(g), probes[i], rtol=0, atol=2e-5 * max(1.0, float(np.abs(probes[i]).max())), err_msg=k)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_committed_tiny_goldens_match_their_generator(tmp_path, monkeypatch):
+    """Generator <-> fixture drift guard: re-running oracle/gen_goldens.py's tiny set against the real reference
+    must reproduce the committed file key for key and bit for bit."""
+    import importlib
+    gen = importlib.import_module("oracle.gen_goldens")
+    monkeypatch.setattr(gen, "OUT", str(tmp_path))
+    gen.gen_tiny()
+    new = dict(np.load(tmp_path / "tiny_pretrain.npz", allow_pickle=False))
+    old = load_npz("tiny_pretrain.npz")
+    assert set(new) == set(old), sorted(set(new) ^ set(old))[:10]
+    for k in new:
+        assert np.array_equal(new[k], old[k], equal_nan=new[k].dtype.kind == 'f'), k
+
+
 def test_optimizer_goldens():
     """3 steps of clip(5.0) + HF AdamW + warmup schedule with the name-based decay groups (A24)."""
     store = load_npz("optim_tiny.npz")
