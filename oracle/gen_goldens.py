@@ -337,7 +337,9 @@ def gen_finetune():
     ft = ref_shim.import_finetune()
     store = {}
     for tag, extra in (("ca", dict(no_lang_ca=False, act_pred_token="ob_txt")),
-                       ("nolangca", dict(no_lang_ca=True, act_pred_token="ob"))):
+                       ("nolangca", dict(no_lang_ca=True, act_pred_token="ob")),
+                       ("obhist", dict(no_lang_ca=False, act_pred_token="ob_hist")),            # vilmodel_cmt.py:722-723
+                       ("obtxthist", dict(no_lang_ca=False, act_pred_token="ob_txt_hist"))):    # vilmodel_cmt.py:724-725
         cfg = OracleConfig.tiny(hidden_size=128, num_attention_heads=2, intermediate_size=256, image_feat_size=64, **extra)
         sd = make_state_dict(navcmt_param_shapes(cfg), seed=9)
         rcfg = ref_shim.make_config(cfg, output_attentions=True)
@@ -375,8 +377,65 @@ def gen_finetune():
             store[pre + n] = t.numpy()
         d = max((a - c).abs()[torch.isfinite(a)].max().item() for a, c in zip(out, oout))
         print(f"  [finetune {tag}] oracle-vs-reference visual max|d|={d:.3e}")
+    gen_agent_models(store)
     np.savez_compressed(os.path.join(OUT, "tiny_finetune.npz"), **store)
     print("tiny_finetune.npz:", len(store), "arrays")
+
+
+def gen_agent_models(store):
+    """Row A23: the reference's own VLNBertCMT.forward (model_HAMT.py:20-65) and Critic (:258-269).  VLNBertCMT is built
+    around an already constructed reference NavCMT (its __init__ would fetch bert-base-uncased's config from the hub and go
+    through HF 4.12's from_pretrained, neither of which exists here), then driven exactly as the agent drives it
+    (agent_cmt.py:270-397): language once, history cls, one history step per time step with `ob_step`, visual with the LIST
+    of history embeddings, ragged `hist_lens` and return_states=True.  eval mode: drop_env is the identity."""
+    import types
+    ft, mh = ref_shim.import_finetune_agent_models()
+    for tag, no_lang_ca in (("agent_ca", False), ("agent_nolangca", True)):
+        cfg = OracleConfig.tiny(hidden_size=128, num_attention_heads=2, intermediate_size=256, image_feat_size=64,
+                                no_lang_ca=no_lang_ca, act_pred_token="ob" if no_lang_ca else "ob_txt")
+        sd = make_state_dict(navcmt_param_shapes(cfg), seed=9)
+        nav = ft.NavCMT(ref_shim.make_config(cfg, output_attentions=True))
+        nav.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        agent = mh.VLNBertCMT.__new__(mh.VLNBertCMT)
+        torch.nn.Module.__init__(agent)
+        agent.args = types.SimpleNamespace(no_lang_ca=no_lang_ca, feat_dropout=0.4)
+        agent.vln_bert = nav
+        agent.drop_env = torch.nn.Dropout(p=0.4)
+        agent.eval()
+        b = make_batch("sap", 4, cfg, seed=33, txt_len=24, hist_len=3, ragged=False)
+        hist_lens = [4, 2, 3, 1]                       # valid history tokens per sample (cls + steps taken), agent_cmt.py:312
+        with torch.no_grad(), ref_shim.cuda_is_identity():
+            lang = agent("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+            hs = [agent("history").expand(4, -1)]
+            for t in range(3):
+                hs.append(agent("history", hist_img_feats=b["hist_img_fts"][:, t], hist_ang_feats=b["hist_ang_fts"][:, t],
+                                hist_pano_img_feats=b["hist_pano_img_fts"][:, t], hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t], ob_step=t))
+            logits, states = agent("visual", txt_embeds=lang, txt_masks=b["txt_masks"], hist_embeds=hs, hist_lens=hist_lens,
+                                   ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"],
+                                   ob_masks=b["ob_masks"], return_states=True)
+            (logits_only,) = agent("visual", txt_embeds=lang, txt_masks=b["txt_masks"], hist_embeds=hs, hist_lens=hist_lens,
+                                   ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+            mask = mh.length2mask(hist_lens, size=4)
+        assert torch.equal(logits, logits_only)
+        pre = f"{tag}/"
+        store.update(to_np(b, pre + "in/"))
+        store[pre + "hist_lens"] = np.array(hist_lens)
+        store[pre + "length2mask"] = mask.numpy()
+        store[pre + "hist"] = torch.stack(hs, 1).numpy()
+        store[pre + "act_logits"] = logits.numpy()
+        store[pre + "states"] = states.numpy()
+        print(f"  [finetune {tag}] VLNBertCMT.forward: logits {tuple(logits.shape)}, states {tuple(states.shape)}")
+    critic = mh.Critic(types.SimpleNamespace(dropout=0.5))
+    csd = make_state_dict({"state2value.0.weight": (512, 768), "state2value.0.bias": (512,), "state2value.3.weight": (1, 512), "state2value.3.bias": (1,)}, seed=12)
+    critic.load_state_dict(csd, strict=True)
+    critic.eval()
+    g = torch.Generator().manual_seed(5)
+    st = torch.randn(8, 768, generator=g)
+    with torch.no_grad():
+        val = critic(st)
+    store["critic/state"] = st.numpy()
+    store["critic/value"] = val.numpy()
+    store["critic/sd_seed"] = np.array(12)
 
 
 def gen_vit():

@@ -91,6 +91,28 @@ def import_finetune():
     return _import_pkg("finetune_src", "models", ["vilmodel_cmt"])[0]
 
 
+def import_finetune_agent_models():
+    """-> (vilmodel_cmt, model_HAMT) of finetune_src/models.  model_HAMT.py imports `utils.misc` (pure torch) and
+    `models.vlnbert_init` (whose hub / HF-loader calls sit inside functions we never call: VLNBertCMT is built around an
+    already constructed NavCMT, see gen_goldens.gen_finetune)."""
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+    return _import_pkg("finetune_src", "models", ["vilmodel_cmt", "model_HAMT"])
+
+
+class cuda_is_identity:
+    """The agent-side wrappers call `.cuda()` on freshly built index tensors (model_HAMT.py:40, utils/misc.py:15-16); in this
+    GPU-less container that call is made the identity for the duration of a forward (arithmetic untouched)."""
+
+    def __enter__(self):
+        self._orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.cuda = self._orig
+
+
 def make_config(ocfg, **extra):
     """A PretrainedConfig-like namespace carrying r2r_model_config.json's keys."""
     d = dict(vars(ocfg))

@@ -319,7 +319,9 @@ def test_state_dict_roundtrip_and_from_pretrained(tiny):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("tag,extra", [("ca", dict(no_lang_ca=False, act_pred_token="ob_txt")),
-                                       ("nolangca", dict(no_lang_ca=True, act_pred_token="ob"))])
+                                       ("nolangca", dict(no_lang_ca=True, act_pred_token="ob")),
+                                       ("obhist", dict(no_lang_ca=False, act_pred_token="ob_hist")),
+                                       ("obtxthist", dict(no_lang_ca=False, act_pred_token="ob_txt_hist"))])
 def test_finetune_navcmt_modes_vs_reference_goldens(tag, extra, prec):
     """finetune twin (vilmodel_cmt.py:624-728): language / history / visual modes against the reference's outputs."""
     from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
@@ -353,6 +355,121 @@ def test_finetune_navcmt_modes_vs_reference_goldens(tag, extra, prec):
     for n, t in zip(("act_logits", "txt", "hist_out", "ob_out"), out):
         errs[n] = rel_err(t, store[f"{tag}/{n}"])
     print(f"[finetune {tag} {prec}] " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) <= TOL[prec], errs
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag,no_lang_ca", [("agent_ca", False), ("agent_nolangca", True)])
+def test_vlnbert_cmt_forward_vs_reference_goldens(tag, no_lang_ca, prec):
+    """Row A23: VLNBertCMT.forward (model_HAMT.py:20-65) driven like the agent (agent_cmt.py:270-397) -- language, history cls,
+    one history step per time step with `ob_step`, visual over the LIST of history embeddings with ragged `hist_lens` and
+    return_states -- against the outputs of the reference's own class (tiny_finetune.npz).  Built around a tiny NavCMT the way
+    the golden generator builds the reference's (get_vlnbert_models always makes the 768-wide model)."""
+    import types
+    from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
+    from vln_hamt_amd.modeling import HamtConfig
+    from vln_hamt_amd.models.model_HAMT import VLNBertCMT, length2mask
+    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+    store = load_npz("tiny_finetune.npz")
+    ocfg = tiny_cfg(no_lang_ca=no_lang_ca, act_pred_token="ob" if no_lang_ca else "ob_txt")
+    sd = make_state_dict(navcmt_param_shapes(ocfg), seed=9)
+    kw = dict(vars(ocfg))
+    kw.pop("pretrain_tasks")
+    agent = VLNBertCMT.__new__(VLNBertCMT)
+    torch.nn.Module.__init__(agent)
+    agent.args = types.SimpleNamespace(no_lang_ca=no_lang_ca, feat_dropout=0.4)
+    agent.vln_bert = NavCMT(HamtConfig(hamt_precision=prec, **kw))
+    agent.vln_bert.load_state_dict(sd, strict=True)
+    agent.drop_env = torch.nn.Dropout(p=0.4)
+    agent = agent.to(DEV).eval()
+    b = to_dev({k: torch.from_numpy(v) for k, v in sub(store, f"{tag}/in/").items()})
+    lens = store[f"{tag}/hist_lens"].tolist()
+    assert np.array_equal(length2mask(lens, size=4).numpy(), store[f"{tag}/length2mask"])          # bit exact index work
+    with torch.no_grad():
+        lang = agent("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+        hs = [agent("history").expand(4, -1)]
+        for t in range(3):
+            hs.append(agent("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
+                            hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(), hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous(), ob_step=t))
+        logits, states = agent("visual", txt_embeds=lang, txt_masks=b["txt_masks"], hist_embeds=hs, hist_lens=lens, ob_img_feats=b["ob_img_fts"],
+                               ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"], return_states=True)
+        (logits_only,) = agent("visual", txt_embeds=lang, txt_masks=b["txt_masks"], hist_embeds=hs, hist_lens=lens, ob_img_feats=b["ob_img_fts"],
+                               ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+    errs = {"hist": rel_err(torch.stack(hs, 1), store[f"{tag}/hist"]), "act_logits": rel_err(logits, store[f"{tag}/act_logits"]),
+            "states": rel_err(states, store[f"{tag}/states"]), "logits_only": rel_err(logits_only, store[f"{tag}/act_logits"])}
+    print(f"[agent {tag} {prec}] " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) <= TOL[prec], errs
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_critic_vs_reference_goldens(prec):
+    """Critic (model_HAMT.py:258-269) against the reference class's output."""
+    import types
+    from oracle.hamt_oracle import make_state_dict
+    from vln_hamt_amd.models.model_HAMT import Critic
+    store = load_npz("tiny_finetune.npz")
+    sd = make_state_dict({"state2value.0.weight": (512, 768), "state2value.0.bias": (512,), "state2value.3.weight": (1, 512),
+                          "state2value.3.bias": (1,)}, seed=int(store["critic/sd_seed"]))
+    critic = Critic(types.SimpleNamespace(dropout=0.5, hamt_precision=prec))
+    critic.load_state_dict(sd, strict=True)
+    critic = critic.to(DEV).eval()
+    with torch.no_grad():
+        val = critic(torch.from_numpy(store["critic/state"]).to(DEV))
+    e = rel_err(val, store["critic/value"])
+    print(f"[critic {prec}] err {e:.1e}")
+    assert val.shape == (8,) and e <= TOL[prec], e
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_rxr_shape_rollout_vs_oracle(prec):
+    """BASELINE config 5's shape through the real model size (never under pytest before): XLM-R vocabulary 250 002,
+    514 positions, LayerNorm eps 1e-5, 160-token instructions, image features 512-d, 20 history steps (21 history tokens),
+    `no_lang_ca` (run_rxr.sh:3, 16, 32-36; vlnbert_init.py:33-41) -- language once, 20 x history, visual over the full
+    history -- against the pinned oracle on the same weights."""
+    from oracle.hamt_oracle import HamtOracle, OracleConfig, make_state_dict, navcmt_param_shapes
+    from vln_hamt_amd.modeling import HamtConfig
+    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+    ocfg = OracleConfig(vocab_size=250002, max_position_embeddings=514, layer_norm_eps=1e-5, image_feat_size=512, no_lang_ca=True,
+                        act_pred_token="ob_txt")
+    sd = make_state_dict(navcmt_param_shapes(ocfg), seed=41)
+    kw = dict(vars(ocfg))
+    kw.pop("pretrain_tasks")
+    model = NavCMT(HamtConfig(hamt_precision=prec, **kw))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    B, L, T, V, D = 2, 160, 20, 36, 512
+    g = torch.Generator().manual_seed(3)
+    txt_ids = torch.randint(5, 250002, (B, L), generator=g)
+    txt_masks = torch.arange(L)[None] < torch.tensor([[L], [L - 37]])
+    pano, pang = torch.randn(T, B, V, D, generator=g), torch.randn(T, B, V, 4, generator=g)
+    img, ang = torch.randn(T, B, D, generator=g), torch.randn(T, B, 4, generator=g)
+    ob_img, ob_ang = torch.randn(B, V + 1, D, generator=g), torch.randn(B, V + 1, 4, generator=g)
+    nav = torch.zeros(B, V + 1, dtype=torch.long)
+    nav[:, :5] = 1
+    nav[:, V] = 2
+    ob_masks = torch.ones(B, V + 1, dtype=torch.bool)
+    hist_masks = torch.arange(T + 1)[None] < torch.tensor([[T + 1], [T - 6]])
+
+    def run(m, dev):
+        d = lambda t: t.to(dev)
+        lang = m("language", txt_ids=d(txt_ids), txt_masks=d(txt_masks))
+        hs = [m("history").expand(B, -1)]
+        for t in range(T):
+            hs.append(m("history", hist_img_feats=d(img[t]), hist_ang_feats=d(ang[t]), ob_step_ids=d(torch.tensor([t])),
+                        hist_pano_img_feats=d(pano[t]), hist_pano_ang_feats=d(pang[t])))
+        hist = torch.stack(hs, 1)
+        out = m("visual", txt_embeds=lang, hist_embeds=hist, txt_masks=d(txt_masks), hist_masks=d(hist_masks), ob_img_feats=d(ob_img),
+                ob_ang_feats=d(ob_ang), ob_nav_types=d(nav), ob_masks=d(ob_masks))
+        return hist, out
+    with torch.no_grad():
+        hist, out = run(model, DEV)
+        orc = HamtOracle(sd, ocfg)
+        rhist, rout = run(lambda mode, **k: orc.ft_forward(mode, **k), "cpu")
+    errs = {"hist": rel_err(hist, rhist)}
+    for n, a, r in zip(("act_logits", "txt", "hist_out", "ob_out"), out, rout):
+        errs[n] = rel_err(a, r)
+    print(f"[rxr shape {prec}] " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert hist.shape == (B, T + 1, 768) and out[0].shape == (B, V + 1)
     assert max(errs.values()) <= TOL[prec], errs
 
 
