@@ -289,6 +289,15 @@ int hamt_mse_bwd(size_t n, const float* x, const float* t, const float* g, float
 int hamt_kl_fwd(int R, int C, const float* x, int ldx, const float* t, int ldt, float* loss, float* lse, void* stream);
 int hamt_kl_bwd(int R, int C, const float* x, int ldx, const float* t, int ldt, const float* lse,
                 const float* g, float* dx, int lddx, void* stream);
+/* A2C rollout loss of the finetune agent (finetune_src/r2r/agent_cmt.py:476-518), all [T, B] steps x episodes at once
+ * (row-major [T][B] fp32 arrays): ret[t,b] = discounted return R_t = gamma R_{t+1} + reward_t seeded with last_value[b]
+ * (NULL = 0: the caller passes the critic's value of the last state for episodes that have not ended, 0 for the others);
+ * out[b] = {sum_t -logp (R - V) mask, sum_t 1/2 (R - V)^2 mask, sum_t -ent_w ent mask} (ent may be NULL).  bwd: gradients
+ * of g[0] * sum(out) w.r.t. logp, value (critic term only: the advantage in the policy term is detached, :493) and ent. */
+int hamt_a2c_fwd(int T, int B, const float* reward, const float* mask, const float* value, const float* logp, const float* ent,
+                 const float* last_value, float gamma, float ent_w, float* ret, float* out, void* stream);
+int hamt_a2c_bwd(int T, int B, const float* ret, const float* mask, const float* value, float ent_w, const float* g,
+                 float* dlogp, float* dvalue, float* dent, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * optimiser side (A24): global L2 norm over a flat gradient arena, then the reference's HF AdamW

@@ -666,3 +666,41 @@ def vit_forward_features(sd: Dict[str, Tensor], c: VitConfig, images: Tensor) ->
         x = x + y                                                                                               # :197
     x = F.layer_norm(x, (D,), sd["norm.weight"], sd["norm.bias"], 1e-6)                                         # :344
     return x[:, 0]                                                                                              # :346
+
+
+def a2c_loss_ref(policy_log_probs, hidden_values, rewards, masks, last_value, ended, entropys=None, gamma=0.9,
+                 entropy_loss_weight=0.01, normalize_loss="total"):
+    """The agent's A2C loss, statement by statement (finetune_src/r2r/agent_cmt.py:476-518).  Per-step lists as the rollout
+    collects them: policy_log_probs[t] (B,), hidden_values[t] = critic(hidden_states[t]) (B,) -- the reference calls the critic
+    inside the loop (:491) --, rewards[t] / masks[t] numpy (B,), last_value (B,) the critic's value of the last state
+    (detached, :478), ended (B,) bool, entropys[t] (B,) when feedback == 'sample' (:497-498).  Returns (rl_loss, logs)."""
+    import numpy as np
+    batch_size = len(ended)
+    discount_reward = np.zeros(batch_size, np.float32)                  # :479
+    for i in range(batch_size):
+        if not ended[i]:                                                 # :481-482
+            discount_reward[i] = float(last_value[i])
+    rl_loss = 0.0
+    total = 0
+    logs = {"critic_loss": [], "policy_loss": []}
+    for t in range(len(rewards) - 1, -1, -1):                           # :486
+        discount_reward = discount_reward * gamma + rewards[t]           # :487
+        mask_ = torch.from_numpy(masks[t])
+        r_ = torch.from_numpy(discount_reward.copy())
+        v_ = hidden_values[t]
+        a_ = (r_ - v_).detach()                                          # :493
+        t_policy_loss = (-policy_log_probs[t] * a_ * mask_).sum()        # :495
+        t_critic_loss = (((r_ - v_) ** 2) * mask_).sum() * 0.5           # :496
+        rl_loss = rl_loss + t_policy_loss + t_critic_loss
+        if entropys is not None:
+            rl_loss = rl_loss + (-entropy_loss_weight * entropys[t] * mask_).sum()    # :498
+        logs["critic_loss"].append(float(t_critic_loss))
+        logs["policy_loss"].append(float(t_policy_loss))
+        total = total + np.sum(masks[t])                                 # :503
+    if normalize_loss == "total":                                        # :507-513
+        rl_loss = rl_loss / float(total)
+    elif normalize_loss == "batch":
+        rl_loss = rl_loss / batch_size
+    else:
+        assert normalize_loss == "none"
+    return rl_loss, logs

@@ -769,6 +769,130 @@ def test_graphed_inference_rollout_matches_eager():
         assert len(gv.graphs) == 3
 
 
+def _tiny_navcmt(no_lang_ca=True, train=False, p_drop=None):
+    from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
+    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+    from vln_hamt_amd.modeling import HamtConfig
+    ocfg = tiny_cfg(no_lang_ca=no_lang_ca, act_pred_token="ob" if no_lang_ca else "ob_txt")
+    if p_drop is not None:
+        for k in ("hidden_dropout_prob", "attention_probs_dropout_prob", "pred_head_dropout_prob"):
+            setattr(ocfg, k, p_drop)
+    kw = dict(vars(ocfg))
+    kw.pop("pretrain_tasks")
+    model = NavCMT(HamtConfig(hamt_precision="bf16", **kw))
+    model.load_state_dict(make_state_dict(navcmt_param_shapes(ocfg), seed=9), strict=True)
+    return model.to(DEV).train(train)
+
+
+def test_rollout_caches_match_the_plain_rollout():
+    """Row N2: the step-invariant text side of a `no_lang_ca` rollout is projected to keys / values once (in `language` mode,
+    riding on the returned tensors) and the history lives in a device-resident buffer (models.model_HAMT.HistoryCache) -- both
+    must give exactly the logits of the plain path (re-projecting every step, re-stacking a Python list: the reference's
+    agent_cmt.py:305-397 / vilmodel_cmt.py:701-709).  Also: refreshing a kept language result in place for the next episode
+    (copy_language_), which is what a hipGraph-captured `visual` step needs."""
+    import types
+    from vln_hamt_amd.graph import GraphedInference
+    from vln_hamt_amd.models.model_HAMT import HistoryCache, VLNBertCMT
+    from vln_hamt_amd.models.vilmodel_cmt import copy_language_
+    store = load_npz("tiny_finetune.npz")
+    model = _tiny_navcmt()
+    agent = VLNBertCMT.__new__(VLNBertCMT)
+    torch.nn.Module.__init__(agent)
+    agent.args, agent.vln_bert, agent.drop_env = types.SimpleNamespace(no_lang_ca=True, feat_dropout=0.0), model, torch.nn.Dropout(0.0)
+    agent.eval()
+    b = to_dev({k: torch.from_numpy(v) for k, v in sub(store, "nolangca/in/").items()})
+    B, H = b["txt_ids"].shape[0], 128
+    hist_step = lambda t: agent("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
+                                hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(), hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous(), ob_step=t)
+    vkw = dict(txt_masks=b["txt_masks"], ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+    with torch.no_grad():
+        lang = agent("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+        assert all(hasattr(t, "_hamt_xkv") for t in lang[:-1])
+        plain = [t.clone() for t in lang]                       # same values, no cached projections
+        cache = HistoryCache(B, 8, H, DEV).reset(agent("history"))
+        hs = [agent("history").expand(B, -1)]
+        for t in range(3):
+            lens = [t + 1] * B
+            (want,) = agent("visual", txt_embeds=plain, hist_embeds=hs, hist_lens=lens, **vkw)
+            (got,) = agent("visual", txt_embeds=lang, hist_embeds=cache, hist_lens=lens, **vkw)
+            fin = torch.isfinite(want)
+            assert torch.equal(torch.isfinite(got), fin) and float((want[fin] - got[fin]).abs().max()) == 0.0, t
+            h = hist_step(t)
+            hs.append(h)
+            cache.append(h)
+        assert len(cache) == 4 and torch.equal(cache.view(), torch.stack(hs, 1))
+        # next episode: other instructions into the SAME tensors; a captured visual step must follow
+        gv = GraphedInference(lambda hist: agent.vln_bert("visual", txt_embeds=lang, hist_embeds=hist, hist_masks=torch.ones(B, 4, dtype=torch.bool, device=DEV), **vkw))
+        first = [t.clone() for t in gv("v4", cache.view().contiguous())]
+        ids2 = b["txt_ids"].flip(0).contiguous()
+        lang2 = agent("language", txt_ids=ids2, txt_masks=b["txt_masks"].flip(0).contiguous())
+        vkw2 = dict(vkw, txt_masks=b["txt_masks"].flip(0).contiguous())
+        want2 = agent.vln_bert("visual", txt_embeds=[t.clone() for t in lang2], hist_embeds=cache.view().contiguous(), hist_masks=torch.ones(B, 4, dtype=torch.bool, device=DEV), **vkw2)
+        copy_language_(lang, lang2)
+        vkw["txt_masks"].copy_(vkw2["txt_masks"])
+        got2 = gv("v4", cache.view().contiguous())
+        fin = torch.isfinite(want2[0])
+        assert float((want2[0][fin] - got2[0][fin]).abs().max()) == 0.0
+        assert float((first[0][fin] - got2[0][fin]).abs().max()) > 0.0          # the episodes do differ
+
+
+def test_graphed_rollout_training_step_matches_eager():
+    """Row N2, training direction: a whole imitation-learning rollout (language once, visual + history per step with the growing
+    history, a cross-entropy per step -- agent_cmt.py:248-529 order) and its ONE backward, clip and AdamW captured as a single
+    hipGraph (GraphedTrainStep with a loss_fn) == the same steps launched eagerly, on fresh batches under one key."""
+    from vln_hamt_amd import ops
+    from vln_hamt_amd.graph import GraphedTrainStep
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.synth import make_batch
+    T = 3
+
+    def rollout_loss(model, b, _task):
+        B = b["txt_ids"].shape[0]
+        lang = model("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+        hs = [model("history").expand(B, -1)]
+        loss = 0.0
+        for t in range(T):
+            out = model("visual", txt_embeds=lang, hist_embeds=torch.stack(hs, 1), txt_masks=b["txt_masks"], hist_masks=b["hist_masks"][:, :t + 1].contiguous(),
+                        ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+            loss = loss + ops.cross_entropy(out[0], b["ob_action_viewindex"]).mean()
+            hs.append(model("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
+                            ob_step_ids=b["step_ids"][t:t + 1], hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
+                            hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
+        return loss
+
+    cfg = tiny_cfg(no_lang_ca=True, act_pred_token="ob")
+    bs = []
+    for i in range(4):
+        b = make_batch("sap", 4, cfg, seed=70 + i, txt_len=24, hist_len=T, device=DEV)
+        b["step_ids"] = torch.arange(T, device=DEV)
+        bs.append(b)
+    models = []
+    for graphed in (False, True):
+        m = _tiny_navcmt(train=True, p_drop=0.0)
+        o = AdamW([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=1e-3, betas=(0.9, 0.98), eps=1.0)
+        losses = []
+        if graphed:
+            gs = GraphedTrainStep(m, o, 5.0, loss_fn=rollout_loss)
+            for b in bs:
+                losses.append(float(gs.step("rollout", b, "rollout")))
+            assert len(gs.graphs) == 1
+        else:
+            for b in bs:
+                loss = rollout_loss(m, b, None)
+                loss.backward()
+                clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+                o.step()
+                o.zero_grad()
+                losses.append(float(loss))
+        models.append((m, losses))
+    torch.cuda.synchronize()
+    (m1, l1), (m2, l2) = models
+    assert max(abs(a - c) for a, c in zip(l1, l2)) < 1e-4, (l1, l2)
+    worst = max(float((a - c).abs().max()) for (_, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()))
+    print(f"[graphed rollout step] losses {l2}; worst parameter difference vs eager {worst:.2e}")
+    assert worst < 2e-5, worst
+
+
 # ------------------------------------------------------------------------------------------- two ranks on one GPU
 def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
     """One data-parallel rank (gloo carries the collectives of CUDA tensors, so two ranks can share the box's single

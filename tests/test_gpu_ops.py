@@ -608,3 +608,40 @@ def test_wire_pack_unpack_bf16(off, n):
     L.check(lib.hamt_wire_unpack_bf16(n, ops._p(y), ops._p(x), ops._stream()), "unpack")
     assert torch.equal(x, y.float())
     assert torch.equal(base[:off], keep[:off]) and torch.equal(base[off + n:], keep[off + n:])
+
+
+@pytest.mark.parametrize("normalize,with_ent", [("total", True), ("batch", False), ("none", True)])
+def test_a2c_loss_vs_reference_restatement(normalize, with_ent):
+    """ops.a2c_loss (one scan kernel over [T, B]) against the statement-by-statement restatement of the agent's loop
+    (oracle.hamt_oracle.a2c_loss_ref <- finetune_src/r2r/agent_cmt.py:476-518): loss, logged sums and the gradients w.r.t. the
+    policy log-probabilities, the critic values and the entropies.  (The reference loop itself needs the simulator: unpinned.)"""
+    import numpy as np
+    from oracle.hamt_oracle import a2c_loss_ref
+    from vln_hamt_amd import ops
+    T, B = 7, 8
+    g = torch.Generator().manual_seed(3)
+    logp = (-torch.rand(T, B, generator=g) * 3).requires_grad_(True)
+    value = torch.randn(T, B, generator=g).requires_grad_(True)
+    ent = torch.rand(T, B, generator=g).requires_grad_(True)
+    rewards = (torch.randn(T, B, generator=g) * 2).numpy()
+    ended_at = torch.randint(2, T + 2, (B,), generator=g).numpy()            # some episodes run past the rollout (not ended)
+    masks = (np.arange(T)[:, None] < ended_at[None]).astype(np.float32)
+    rewards = rewards * masks
+    ended = ended_at <= T
+    last_value = torch.randn(B, generator=g)
+    ref, logs = a2c_loss_ref([logp[t] for t in range(T)], [value[t] for t in range(T)], [rewards[t] for t in range(T)],
+                             [masks[t] for t in range(T)], last_value, ended, [ent[t] for t in range(T)] if with_ent else None,
+                             gamma=0.9, entropy_loss_weight=0.01, normalize_loss=normalize)
+    ref.backward()
+    d = lambda t: t.detach().to("cuda").requires_grad_(True)
+    lp, va, en = d(logp), d(value), d(ent)
+    lv = torch.where(torch.from_numpy(ended), torch.zeros(B), last_value).to("cuda")
+    loss, parts = ops.a2c_loss(lp, va, torch.from_numpy(rewards).to("cuda"), torch.from_numpy(masks).to("cuda"), last_value=lv,
+                               entropy=en if with_ent else None, gamma=0.9, entropy_weight=0.01, normalize=normalize)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    assert abs(float(parts["policy"]) - sum(logs["policy_loss"])) <= 1e-4 * max(1.0, abs(sum(logs["policy_loss"])))
+    assert abs(float(parts["critic"]) - sum(logs["critic_loss"])) <= 1e-4 * max(1.0, abs(sum(logs["critic_loss"])))
+    for a, r, n in ((lp, logp, "logp"), (va, value, "value")) + (((en, ent, "ent"),) if with_ent else ()):
+        err = float((a.grad.cpu() - r.grad).abs().max())
+        assert err <= 1e-5 * max(1.0, float(r.grad.abs().max())), (n, err)

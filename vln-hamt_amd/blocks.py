@@ -197,25 +197,51 @@ class SelfAttnBlockFn(torch.autograd.Function):
 
 
 # ================================================================================================= cross attention block
+class KvProjFn(torch.autograd.Function):
+    """kv16 [Mkp, 2H] bf16 = c [W_k; W_v]^T + [b_k; b_v] -- the context side of a cross attention as its own node, so that a
+    context that does not change between calls (the step-invariant text stream of the `no_lang_ca` rollout, vilmodel_cmt.py:
+    645-652 / 701-709) is projected ONCE and shared by every step's attention: autograd sums the steps' dkv16 and this node
+    runs one dgrad + one queued wgrad for the whole rollout."""
+
+    @staticmethod
+    def forward(ctx, c, wk, bk, wv, bv):
+        B, Sk, H = c.shape
+        Mk = B * Sk
+        c2 = c.reshape(Mk, H)
+        if not c2.is_contiguous():
+            c2 = c2.contiguous()
+        c16 = _x16_of(c, c2)
+        kv16 = torch.empty(c16.shape[0], 2 * H, dtype=torch.bfloat16, device=c.device)
+        _proj(c16, Mk, (wk, wv), (bk, bv), kv16)
+        ctx.save_for_backward(c16, wk, bk, wv, bv)
+        ctx.meta = (B, Sk, H)
+        return kv16
+
+    @staticmethod
+    def backward(ctx, dkv16):
+        if dkv16 is None:
+            return (None,) * 5
+        c16, wk, bk, wv, bv = ctx.saved_tensors
+        B, Sk, H = ctx.meta
+        if not dkv16.is_contiguous():
+            dkv16 = dkv16.contiguous()
+        dc, dwkv, dbkv = _proj_bwd(dkv16, B * Sk, c16, (wk, wv), (bk, bv), need_dx=ctx.needs_input_grad[0])
+        return (dc.view(B, Sk, H) if dc is not None else None, dwkv[0], dbkv[0], dwkv[1], dbkv[1])
+
+
 class CrossAttnBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta):
+    def forward(ctx, x, kv16, Sk, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wo, bo, gamma, beta):
         B, Sq, H = x.shape
-        Sk = c.shape[1]
         Mq, Mk = B * Sq, B * Sk
         dev = x.device
         x2 = x.reshape(Mq, H)
-        c2 = c.reshape(Mk, H)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        if not c2.is_contiguous():
-            c2 = c2.contiguous()
-        x16, c16 = _x16_of(x, x2), _x16_of(c, c2)
-        Mqp, Mkp = x16.shape[0], c16.shape[0]
+        x16 = _x16_of(x, x2)
+        Mqp = x16.shape[0]
         q16 = torch.empty(Mqp, H, dtype=torch.bfloat16, device=dev)
         gemm(x16[:Mq], weight_operand(wq, "bf16"), q16[:Mq], bias=bq.detach())
-        kv16 = torch.empty(Mkp, 2 * H, dtype=torch.bfloat16, device=dev)
-        _proj(c16, Mk, (wk, wv), (bk, bv), kv16)
         mask2 = add_mask.reshape(B, Sk).to(torch.float32).contiguous() if add_mask is not None else None
         ctx16 = _zeros_or_empty(Mqp, Mq, H, dev)
         lse = torch.empty(B * heads * Sq, dtype=torch.float32, device=dev)
@@ -226,7 +252,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         o = torch.empty(Mq, H, dtype=torch.float32, device=dev)
         gemm(ctx16[:Mq], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
-        ctx.save_for_backward(x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
+        ctx.save_for_backward(x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma)
         ctx.ln_params = (gamma, beta, bo)
         ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
         ctx.mark_non_differentiable(y16)
@@ -236,11 +262,11 @@ class CrossAttnBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _unused=None):
         if dy is None:
-            return (None,) * 17
-        x16, c16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma = ctx.saved_tensors
+            return (None,) * 14
+        x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma = ctx.saved_tensors
         B, Sq, Sk, H, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
         Mq, Mk = B * Sq, B * Sk
-        Mqp, Mkp = x16.shape[0], c16.shape[0]
+        Mqp, Mkp = x16.shape[0], kv16.shape[0]
         dev = dy.device
         dz, _, dx16, dgamma, dbeta, dbo = _ln_bwd(dy.reshape(Mq, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
                                                   cid_ln, False, True, True, params=ctx.ln_params)
@@ -254,9 +280,23 @@ class CrossAttnBlockFn(torch.autograd.Function):
                                              _p(lse), None, _p(dq16), _p(dkv16[:, :H]), _p(dkv16[:, H:]), _p(rng_state(dev)), _stream()),
                 "hamt_attn_small_bwd")
         dx, dwqs, dbqs = _proj_bwd(dq16, Mq, x16, (wq,), (bq,), dx_accum_into=dz)
-        dc, dwkv, dbkv = _proj_bwd(dkv16, Mk, c16, (wk, wv), (bk, bv), need_dx=ctx.needs_input_grad[1])
-        return (dx.view(B, Sq, H), dc.view(B, Sk, H) if dc is not None else None, None, None, None, None, None,
-                dwqs[0], dbqs[0], dwkv[0], dbkv[0], dwkv[1], dbkv[1], dwo, dbo, dgamma, dbeta)
+        return (dx.view(B, Sq, H), dkv16 if ctx.needs_input_grad[1] else None, None, None, None, None, None, None,
+                dwqs[0], dbqs[0], dwo, dbo, dgamma, dbeta)
+
+
+def _kv_key(c, att):
+    a = getattr(att.key.weight, "_hamt_arena16", None)
+    return (id(att), c._version, att.key.weight._version, att.value.weight._version, a[2] if a is not None else -1, ops._cache_epoch[0],
+            torch.is_grad_enabled())
+
+
+def precompute_cross_kv(c, att):
+    """Project the context `c` [B, Sk, H] with cross-attention module `att`'s key / value weights now and remember the result on
+    the tensor (`c._hamt_xkv`): later cross_attn_block calls with this very context (and unchanged weights) skip the projection.
+    Used by NavCMT's `language` mode for the step-invariant text stream of a `no_lang_ca` rollout."""
+    kv16 = KvProjFn.apply(c, att.key.weight, att.key.bias, att.value.weight, att.value.bias)
+    c._hamt_xkv = (_kv_key(c, att), kv16)
+    return kv16
 
 
 # ================================================================================================= feed-forward block
@@ -327,9 +367,14 @@ def self_attn_block(x, add_mask, att_self, att_out, training):
 def cross_attn_block(x, c, add_mask, att, att_out, training):
     pa = float(att.dropout.p) if training else 0.0
     ph = float(att_out.dropout.p) if training else 0.0
-    y, y16 = CrossAttnBlockFn.apply(x, c, add_mask, att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
-                                    att.query.weight, att.query.bias, att.key.weight, att.key.bias, att.value.weight, att.value.bias,
-                                    att_out.dense.weight, att_out.dense.bias, att_out.LayerNorm.weight, att_out.LayerNorm.bias)
+    cached = getattr(c, "_hamt_xkv", None)
+    if cached is not None and cached[0] == _kv_key(c, att):
+        kv16 = cached[1]
+    else:
+        kv16 = KvProjFn.apply(c, att.key.weight, att.key.bias, att.value.weight, att.value.bias)
+    y, y16 = CrossAttnBlockFn.apply(x, kv16, c.shape[1], add_mask, att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
+                                    att.query.weight, att.query.bias, att_out.dense.weight, att_out.dense.bias,
+                                    att_out.LayerNorm.weight, att_out.LayerNorm.bias)
     return _tag(y, y16)
 
 

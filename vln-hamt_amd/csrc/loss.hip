@@ -92,6 +92,42 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(int C, const float* __restr
 }
 inline int nb(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
 
+// A2C rollout loss of the finetune agent (finetune_src/r2r/agent_cmt.py:476-518), all T steps and B episodes in one launch:
+// one thread per episode runs the reverse discounted-return scan R_t = gamma R_{t+1} + r_t (seeded with the critic's value of
+// the last state for episodes that have not ended, :480-484) and sums, per step, the policy term -log pi(a_t) (R_t - V_t),
+// the critic term 1/2 (R_t - V_t)^2 and (feedback == 'sample') the entropy term -w H_t, each times mask_t (:489-500).  The
+// advantage inside the policy term is a constant (`.detach()`, :493).  out[b] = {policy, critic, entropy} sums of episode b.
+__global__ void a2c_fwd_kernel(int T, int B, const float* __restrict__ reward, const float* __restrict__ mask, const float* __restrict__ value,
+                               const float* __restrict__ logp, const float* __restrict__ ent, const float* __restrict__ last_value,
+                               float gamma, float ent_w, float* __restrict__ ret, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float R = last_value ? last_value[b] : 0.f, pol = 0.f, crit = 0.f, en = 0.f;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * B + b;
+    R = R * gamma + reward[i];
+    ret[i] = R;
+    const float a = R - value[i], m = mask[i];
+    pol += -logp[i] * a * m;
+    crit += 0.5f * a * a * m;
+    if (ent) en += -ent_w * ent[i] * m;
+  }
+  out[3 * b] = pol; out[3 * b + 1] = crit; out[3 * b + 2] = en;
+}
+// gradients for an upstream scale g (d loss / d out summed: the caller's normalisation): dlogp = -(R - V) m g,
+// dV = -(R - V) m g (critic term only), dent = -w m g
+__global__ void a2c_bwd_kernel(size_t n, const float* __restrict__ ret, const float* __restrict__ mask, const float* __restrict__ value,
+                               float ent_w, const float* __restrict__ g, float* __restrict__ dlogp, float* __restrict__ dvalue,
+                               float* __restrict__ dent) {
+  const float gs = *g;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float a = ret[i] - value[i], m = mask[i];
+    dlogp[i] = -a * m * gs;
+    dvalue[i] = -a * m * gs;
+    if (dent) dent[i] = -ent_w * m * gs;
+  }
+}
+
 }  // namespace
 
 extern "C" int hamt_ce_fwd(int R, int C, const float* x, int ldx, const int64_t* label, float* loss, float* lse, void* stream) {
@@ -136,5 +172,23 @@ extern "C" int hamt_kl_bwd(int R, int C, const float* x, int ldx, const float* t
   if (R == 0) return HAMT_OK;
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(R), dim3(256), 0, as_stream(stream), C, x, ldx, t, ldt, lse, g, dx, lddx);
   HAMT_CHECK_LAUNCH("hamt_kl_bwd");
+  return HAMT_OK;
+}
+
+extern "C" int hamt_a2c_fwd(int T, int B, const float* reward, const float* mask, const float* value, const float* logp, const float* ent,
+                            const float* last_value, float gamma, float ent_w, float* ret, float* out, void* stream) {
+  HAMT_CHECK_ARG(T >= 0 && B >= 0 && reward && mask && value && logp && ret && out, "hamt_a2c_fwd: bad argument");
+  if (B == 0) return HAMT_OK;
+  hipLaunchKernelGGL(a2c_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), T, B, reward, mask, value, logp, ent, last_value, gamma, ent_w, ret, out);
+  HAMT_CHECK_LAUNCH("hamt_a2c_fwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_a2c_bwd(int T, int B, const float* ret, const float* mask, const float* value, float ent_w, const float* g,
+                            float* dlogp, float* dvalue, float* dent, void* stream) {
+  HAMT_CHECK_ARG(T >= 0 && B >= 0 && ret && mask && value && g && dlogp && dvalue, "hamt_a2c_bwd: bad argument");
+  const size_t n = (size_t)T * B;
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(a2c_bwd_kernel, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, as_stream(stream), n, ret, mask, value, ent_w, g, dlogp, dvalue, dent);
+  HAMT_CHECK_LAUNCH("hamt_a2c_bwd");
   return HAMT_OK;
 }

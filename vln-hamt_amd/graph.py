@@ -22,9 +22,14 @@ class GraphedTrainStep:
     norm + AdamW graph -- with the collective launched eagerly between the two replays on the same stream, so RCCL
     never has to be captured."""
 
-    def __init__(self, model, optimizer, max_grad_norm: float = 5.0, grad_sync=None):
+    def __init__(self, model, optimizer, max_grad_norm: float = 5.0, grad_sync=None, loss_fn=None):
+        """`loss_fn(model, batch, task) -> scalar loss` replaces the default `model(batch, task, True).mean()`: e.g. a whole
+        finetune rollout (language once, history / visual per step, a loss per step -- agent_cmt.py:248-529) whose ONE
+        backward then sits in the same captured graph (`task` is only a label for such a function)."""
         self.model, self.opt, self.max_norm = model, optimizer, float(max_grad_norm)
         self.grad_sync = grad_sync
+        self.loss_fn = loss_fn or (lambda m, b, t: m(b, t, True).mean())
+        self._custom_loss = loss_fn is not None
         # with a process group alive, RCCL's watchdog thread polls its events while we capture: only this thread's
         # calls may be policed by the capture ("global" mode aborts the watchdog with hipErrorCapturedEvent)
         self.capture_mode = "thread_local" if grad_sync is not None else "global"
@@ -42,7 +47,7 @@ class GraphedTrainStep:
         self.opt.materialize()
 
     def _eager(self, batch, task):
-        loss = self.model(batch, task, True).mean()
+        loss = self.loss_fn(self.model, batch, task)
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync(self.opt)
@@ -80,7 +85,8 @@ class GraphedTrainStep:
                                       "synchronisation and a data-dependent shape that cannot be captured")
 
     def _capture(self, key, batch, task):
-        self._check_capturable(batch, task)
+        if not self._custom_loss:
+            self._check_capturable(batch, task)
         src = batch
         batch = copy.copy(src)                 # the graph's static inputs: replays read THESE tensors (step() refills them)
         for k, v in src.items():
@@ -109,7 +115,7 @@ class GraphedTrainStep:
         if overl:
             self.grad_sync.mode = "plan"       # the end-of-backward flush only builds the plan during the capture
         with torch.cuda.graph(g, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
-            loss_c = self.model(batch, task, True).mean()
+            loss_c = self.loss_fn(self.model, batch, task)
             loss_c.backward()
             if self.grad_sync is None:
                 self._update(dev)

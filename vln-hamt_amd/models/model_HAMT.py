@@ -15,6 +15,38 @@ def length2mask(length, size=None, device=None):
     return ar > (torch.as_tensor(length, dtype=torch.int64, device=device) - 1)[:, None]
 
 
+class HistoryCache:
+    """Device-resident history of a no-grad rollout.  The reference agent keeps a Python list of per-step
+    embeddings and re-stacks ALL of them at every step (agent_cmt.py:305-307, model_HAMT.py:48); here each new embedding is
+    written once into its row of a [B, max_len, H] buffer and `visual` reads the first n rows in place -- the buffer's address
+    never changes, so hipGraph-captured `visual` steps (one per history length) read it directly and the captured `history` step
+    can write into it.  Pass it as `hist_embeds`; training rollouts (autograd) keep using the list."""
+
+    def __init__(self, batch_size: int, max_len: int, hidden: int, device):
+        self.buf = torch.zeros(batch_size, max_len, hidden, dtype=torch.float32, device=device)
+        self.n = 0
+
+    def reset(self, cls_embed=None):
+        self.n = 0
+        if cls_embed is not None:
+            self.append(cls_embed.expand(self.buf.shape[0], -1))
+        return self
+
+    def append(self, h):
+        """h: [B, H] (the `history` mode's output of this step)"""
+        B, T, H = self.buf.shape
+        assert self.n < T, "HistoryCache is full"
+        ops.copy_rows_into(self.buf.view(B, T * H), self.n * H, h.detach().reshape(B, H).contiguous())
+        self.n += 1
+        return self
+
+    def view(self):
+        return self.buf[:, :self.n]
+
+    def __len__(self):
+        return self.n
+
+
 class VLNBertCMT(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -40,7 +72,7 @@ class VLNBertCMT(nn.Module):
             return self.vln_bert(mode, hist_img_feats=hist_img_feats, hist_ang_feats=hist_ang_feats, ob_step_ids=ob_step_ids,
                                  hist_pano_img_feats=hist_pano_img_feats, hist_pano_ang_feats=hist_pano_ang_feats)
         if mode == 'visual':
-            hist_embeds = torch.stack(hist_embeds, 1)
+            hist_embeds = hist_embeds.view() if isinstance(hist_embeds, HistoryCache) else torch.stack(hist_embeds, 1)
             hist_masks = length2mask(hist_lens, size=hist_embeds.size(1), device=hist_embeds.device).logical_not()
             ob_img_feats = self._drop(ob_img_feats)
             act_logits, txt_embeds, hist_embeds, ob_embeds = self.vln_bert(

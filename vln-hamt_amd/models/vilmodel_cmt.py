@@ -185,6 +185,12 @@ class NavCMT(BertPreTrainedModel):
                 for layer in self.encoder.x_layers:
                     att = layer.lang_self_att(txt, txt_m)[0]
                     outs.append(V._ffn(layer.lang_inter, layer.lang_output, att, self.training))
+                # ... and, beyond the reference, what every later `visual` call would re-derive from them: the key / value
+                # projections of x-layer l's cross attention over outs[l].  They ride on the tensors
+                # (`_hamt_xkv`); a `visual` call given other tensors simply projects again.
+                if blocks.usable(precision_of(cfg), txt):
+                    for l, layer in enumerate(self.encoder.x_layers):
+                        blocks.precompute_cross_kv(outs[l], layer.visual_attention.att)
                 return outs
             return txt
 
@@ -231,3 +237,20 @@ class NavCMT(BertPreTrainedModel):
             act_logits = ops.fill_where_zero(self.next_action(fuse).squeeze(-1), ob_nav_types, -float('inf'))
             return act_logits, txt_embeds, hist_out, ob_out
         raise ValueError(mode)
+
+
+def copy_language_(dst, src):
+    """In-place refresh of a kept `language` result (tensor or the `no_lang_ca` list) with a new episode's, INCLUDING the cached
+    cross-attention key / value projections riding on the tensors: what a hipGraph-captured `visual` step keeps reading
+    (graph.GraphedInference bakes the addresses of `dst` in)."""
+    if torch.is_tensor(dst):
+        dst, src = [dst], [src]
+    for d, s_ in zip(dst, src):
+        kd, ks = getattr(d, "_hamt_xkv", None), getattr(s_, "_hamt_xkv", None)
+        d.copy_(s_)
+        if kd is not None and ks is not None:
+            kd[1].copy_(ks[1])
+            d._hamt_xkv = (ks[0][:1] + (d._version,) + ks[0][2:], kd[1])      # same weights, `d`'s new version
+        elif kd is not None:
+            del d._hamt_xkv
+    return dst

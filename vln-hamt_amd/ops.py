@@ -675,6 +675,16 @@ def gather_rows(table, idx, base=None):
     return GatherRowsFn.apply(table, idx, base)
 
 
+@torch.no_grad()
+def copy_rows_into(dst2d: torch.Tensor, col0: int, src2d: torch.Tensor):
+    """dst2d[:, col0:col0 + W] = src2d  (fp32, rows of either side may be strided): one hamt_gather_rows launch with the
+    identity index -- the in-place `cat` / `stack` of the no-grad paths (history cache, vision buffer)."""
+    R, W = src2d.shape
+    assert dst2d.shape[0] == R and dst2d.stride(1) == 1 and src2d.stride(1) == 1 and col0 + W <= dst2d.shape[1]
+    L.check(L.load().hamt_gather_rows(R, W, _p(src2d), _ld(src2d), None, None, W, _p(dst2d), _ld(dst2d), col0, _stream()), "hamt_gather_rows")
+    return dst2d
+
+
 class Add3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, c):
@@ -892,6 +902,52 @@ def cross_entropy(x, label):
 
 def mse_loss(x, t):
     return MseFn.apply(x, t)
+
+
+class A2cFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, value, ent, reward, mask, last_value, gamma, ent_w):
+        T, B = logp.shape
+        dev = logp.device
+        f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        logp_, value_, ent_, reward_, mask_, last_ = f(logp), f(value), f(ent), f(reward), f(mask), f(last_value)
+        ret = torch.empty(T, B, dtype=torch.float32, device=dev)
+        out = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        L.check(L.load().hamt_a2c_fwd(T, B, _p(reward_), _p(mask_), _p(value_), _p(logp_), _p(ent_), _p(last_), float(gamma), float(ent_w),
+                                      _p(ret), _p(out), _stream()), "hamt_a2c_fwd")
+        ctx.save_for_backward(ret, mask_, value_)
+        ctx.meta = (T, B, float(ent_w), ent is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ret, mask_, value_ = ctx.saved_tensors
+        T, B, ent_w, has_ent = ctx.meta
+        dev = ret.device
+        # the caller reduces `out` with ONE scalar weight per rollout (sum, / total, / batch: agent_cmt.py:508-514)
+        g = dout.reshape(-1)[:1].to(torch.float32).contiguous()
+        dlogp = torch.empty(T, B, dtype=torch.float32, device=dev)
+        dvalue = torch.empty(T, B, dtype=torch.float32, device=dev)
+        dent = torch.empty(T, B, dtype=torch.float32, device=dev) if has_ent else None
+        L.check(L.load().hamt_a2c_bwd(T, B, _p(ret), _p(mask_), _p(value_), ent_w, _p(g), _p(dlogp), _p(dvalue), _p(dent), _stream()), "hamt_a2c_bwd")
+        return dlogp, dvalue, dent, None, None, None, None, None
+
+
+def a2c_loss(logp, value, reward, mask, last_value=None, entropy=None, gamma=0.9, entropy_weight=0.01, normalize="total"):
+    """The agent's RL loss over a whole rollout in two launches (finetune_src/r2r/agent_cmt.py:476-518): `logp`, `value`,
+    `reward`, `mask` (and `entropy` for feedback == 'sample') are [T, B]; `last_value` [B] is the critic's value of the last
+    state for episodes that have not ended and 0 for the others (:480-484).  normalize: 'total' (/ mask.sum()), 'batch'
+    (/ B) or 'none' (:508-514).  Returns (loss, {policy, critic, entropy sums}) -- the sums are what the reference logs."""
+    out = A2cFn.apply(logp, value, entropy, reward, mask, last_value, gamma, entropy_weight)
+    parts = out.sum(0)
+    loss = parts.sum()
+    if normalize == "total":
+        loss = loss / mask.to(torch.float32).sum()
+    elif normalize == "batch":
+        loss = loss / logp.shape[1]
+    else:
+        assert normalize == "none", normalize
+    return loss, {"policy": parts[0].detach(), "critic": parts[1].detach(), "entropy": parts[2].detach()}
 
 
 def kl_div_logsoftmax(x, t):
