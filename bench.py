@@ -177,8 +177,8 @@ def main():
     from vln_hamt_amd import ops
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
-    from vln_hamt_amd.parallel import (OverlappedGradSync, TaskSchedule, allreduce_grads, barrier, broadcast_params, default_wire, init_distributed,
-                                       max_over_ranks, sum_over_ranks)
+    from vln_hamt_amd.parallel import (OverlappedGradSync, ShardedGradSync, TaskSchedule, allreduce_grads, barrier, broadcast_params, default_wire,
+                                       init_distributed, max_over_ranks, sum_over_ranks)
     from vln_hamt_amd.synth import make_batch, make_itm_rng
 
     rank, local_rank, world = init_distributed()
@@ -202,7 +202,13 @@ def main():
     grad_sync = None
     if dist_on:
         wire = default_wire(args.prec)                  # bf16 mode: bf16 on the wire (DDP bf16_compress_hook arithmetic)
-        grad_sync = (lambda o: allreduce_grads(o, wire)) if os.environ.get("HAMT_NO_OVERLAP") else OverlappedGradSync(opt, n_groups=int(os.environ.get("HAMT_SYNC_GROUPS", 4)), wire=wire)
+        ng = int(os.environ.get("HAMT_SYNC_GROUPS", 4))
+        if os.environ.get("HAMT_NO_OVERLAP"):
+            grad_sync = lambda o: allreduce_grads(o, wire)
+        elif os.environ.get("HAMT_SHARDED", "1") != "0" and args.prec == "bf16":
+            grad_sync = ShardedGradSync(opt, n_groups=ng, wire=wire)    # reduce-scatter -> owned-slice AdamW -> all-gather (default)
+        else:
+            grad_sync = OverlappedGradSync(opt, n_groups=ng, wire=wire)  # all-reduce, full AdamW on every rank
     net = model
 
     sched = TaskSchedule(cyclic=True) if args.task == "mix" else None
@@ -255,8 +261,12 @@ def main():
         lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
         for g in opt.param_groups:
             g["lr"] = lr
-        clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)
-        opt.step()
+        if getattr(grad_sync, "sharded", False):
+            opt.prepare_step()
+            grad_sync.update(5.0)
+        else:
+            clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)
+            opt.step()
         opt.zero_grad()
         ops.advance_rng_epoch(device)
         return task, b["txt_ids"].shape[0]
@@ -288,6 +298,16 @@ def main():
 
     dt, samples, flops = timed_region(args.batch, args.warmup, args.steps)
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
+    exposed_comm_ms = None
+    if dist_on and not args.no_probes:
+        # the same steps with the collectives themselves skipped (every rank keeps its own values: timing only, after the measurement):
+        # the difference is the part of the exchange that compute does not hide
+        from vln_hamt_amd import parallel as par
+        par.DRY[0] = True
+        dt_dry, _, _ = timed_region(args.batch, 2, args.steps, verbose=False)
+        par.DRY[0] = False
+        exposed_comm_ms = round((dt - dt_dry) / args.steps * 1e3, 3)
+        log(f"without the collectives: {dt_dry / args.steps * 1e3:.3f} ms/step -> exposed communication {exposed_comm_ms} ms/step")
     total_samples = sum_over_ranks(float(samples), device)
     total_flops = sum_over_ranks(flops, device)
 
@@ -301,12 +321,13 @@ def main():
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
-                       "parallelism": f"dp{world}" + (f" (flat-arena {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} all-reduce, {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
+                       "parallelism": f"dp{world}" + (f" (flat-arena {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} " + ("reduce-scatter + owned-slice AdamW + all-gather" if getattr(grad_sync, "sharded", False) else "all-reduce") + f", {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
                        "launch": "hipGraph replay" if graphed is not None else "eager"},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+            "exposed_comm_ms_per_step": exposed_comm_ms,
         }
         also = args.also_batch if args.also_batch >= 0 else (16 if (args.batch == 64 and world == 1 and args.task == "mix") else 0)
         if also and world == 1 and not args.no_probes:

@@ -319,6 +319,11 @@ int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v, void* p16,
 int hamt_adamw_table(size_t n, float* p, float* g, float* m, float* v, void* p16, const int* ends,
                      const float* hyp, int nparams, const float* gnorm_sq, float max_norm, float beta1,
                      float beta2, float eps, int zero_grad, void* stream);
+/* the same over the arena elements [first, first + n) only (p, g, m, v, p16 point at element `first`; `ends` / `hyp` still
+ * describe the whole arena): a rank of a sharded optimizer updates just the segments it owns (parallel.ShardedGradSync) */
+int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g, float* m, float* v, void* p16,
+                           const int* ends, const float* hyp, int nparams, const float* gnorm_sq,
+                           float max_norm, float beta1, float beta2, float eps, int zero_grad, void* stream);
 /* g *= min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  -- standalone clip for torch-optimiser users */
 int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream);
 

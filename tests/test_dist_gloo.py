@@ -174,3 +174,24 @@ def test_wgrad_plan_invariants_cpu():
             assert g_prev in plan.deps[g_next]
     first = [min(o for o, ws in writes.items() if any(g == gg for g, _ in ws)) for gg in range(len(plan.groups))]
     assert len(plan.groups) >= 4 and first[:4] == sorted(first[:4])                     # (4)
+
+
+def test_shard_cuts_invariants():
+    """parallel.shard_cuts: ranges tile the arena, end on 8 * world granules, never move a cut towards an EARLIER-final range,
+    and the bf16- / fp32-gathered region boundary is always a cut."""
+    from vln_hamt_amd.parallel import shard_cuts
+    import random
+    rnd = random.Random(0)
+    for world in (1, 2, 4, 8):
+        q = 8 * world
+        for _ in range(50):
+            n = q * rnd.randint(4, 400)
+            n_a = q * rnd.randint(0, n // q)
+            bounds = sorted(rnd.sample(range(8, n, 8), min(5, n // 8 - 1)))
+            cuts = shard_cuts(n, n_a, world, bounds)
+            assert cuts[0] == 0 and cuts[-1] == n and n_a in cuts and cuts == sorted(set(cuts))
+            assert all(c % q == 0 for c in cuts)
+            for b in bounds:                                  # the cut that stands for b is the granule boundary at or below it
+                assert (b // q * q) in cuts
+            owned = sum((hi - lo) // world for lo, hi in zip(cuts[:-1], cuts[1:]))
+            assert owned * world == n                          # every element has exactly one owner

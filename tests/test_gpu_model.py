@@ -894,7 +894,7 @@ def test_graphed_rollout_training_step_matches_eager():
 
 
 # ------------------------------------------------------------------------------------------- two ranks on one GPU
-def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
+def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False):
     """One data-parallel rank (gloo carries the collectives of CUDA tensors, so two ranks can share the box's single
     GPU): the product's multi-GPU step on this rank's own batches."""
     import torch.distributed as dist
@@ -903,7 +903,7 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
     from vln_hamt_amd.graph import GraphedTrainStep
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
-    from vln_hamt_amd.parallel import OverlappedGradSync, broadcast_params
+    from vln_hamt_amd.parallel import OverlappedGradSync, ShardedGradSync, broadcast_params
     from vln_hamt_amd.synth import make_batch
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -918,7 +918,7 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
                {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], lr=1e-3, betas=(0.9, 0.98), eps=1.0)
     o.materialize()
     broadcast_params(o)
-    sync = OverlappedGradSync(o, n_groups=3, wire=wire)
+    sync = (ShardedGradSync if sharded else OverlappedGradSync)(o, n_groups=3, wire=wire)
     seq = ["sap", "mlm", "sap", "mrc", "mlm", "sap"]
     batches = {t: make_batch(t, 4, cfg, seed=100 * rank + sum(map(ord, t)), txt_len=20, hist_len=4, ragged=True, device=DEV) for t in set(seq)}
     try:
@@ -930,9 +930,18 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
             for t in seq:
                 m(batches[t], t, True).mean().backward()
                 sync(o)
-                clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
-                o.step()
+                if sharded:
+                    o.prepare_step()
+                    sync.update(5.0)
+                else:
+                    clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+                    o.step()
                 o.zero_grad()
+        torch.cuda.synchronize()
+        if sharded:
+            torch.save(o._flat_p16.detach().cpu(), os.path.join(out_dir, f"shadow{rank}.pt"))     # what the next forward would read
+            torch.save(o._flat_p[o._n_shadow_only:].detach().cpu(), os.path.join(out_dir, f"fp32read{rank}.pt"))
+            sync.gather_masters()
         torch.cuda.synchronize()
         torch.save(o._flat_p.detach().cpu(), os.path.join(out_dir, f"params{rank}.pt"))
     finally:
@@ -940,11 +949,14 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire,use_graph", [("fp32", False), ("fp32", True), ("bf16", False)])
-def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph):
+@pytest.mark.parametrize("wire,use_graph,sharded", [("fp32", False, False), ("fp32", True, False), ("bf16", False, False),
+                                                    ("fp32", False, True), ("fp32", True, True), ("bf16", True, True)])
+def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph, sharded):
     """world_size = 2 for real: two processes, different batches, the product's overlapped exchange (gloo moves the
     CUDA tensors) -- against one process that computes both ranks' gradients on the same weights, averages them,
-    clips and steps.  Both ranks must also end with identical parameters."""
+    clips and steps.  Both ranks must also end with identical parameters.  sharded: parallel.ShardedGradSync (reduce-scatter,
+    AdamW over the owned slices, all-gather of the bf16 shadow / the fp32-read region) -- what each rank's next forward would
+    read (shadow arena, fp32-read region) must be identical on both ranks BEFORE the masters are gathered."""
     import socket
     import torch.multiprocessing as mp
     from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
@@ -955,9 +967,13 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     if not wgrad.ENABLED:
         pytest.skip("HAMT_NO_DEFER_WGRAD")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph, sharded), nprocs=2, join=True)
     p0, p1 = torch.load(os.path.join(str(tmp_path), "params0.pt")), torch.load(os.path.join(str(tmp_path), "params1.pt"))
     assert torch.equal(p0, p1), "ranks diverged"
+    if sharded:
+        for name in ("shadow", "fp32read"):
+            a, b_ = torch.load(os.path.join(str(tmp_path), f"{name}0.pt")), torch.load(os.path.join(str(tmp_path), f"{name}1.pt"))
+            assert torch.equal(a, b_), f"{name}: the ranks would run their next forward on different weights"
     # ---- reference: one process, both ranks' gradients per step
     cfg = tiny_cfg()
     sd = make_state_dict(pretrain_param_shapes(cfg), seed=5)

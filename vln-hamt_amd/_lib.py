@@ -104,6 +104,7 @@ SIGNATURES = {
     "hamt_sumsq": [sz, vp, vp, i32, vp, vp],
     "hamt_adamw_flat": [sz, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table": [sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
+    "hamt_adamw_table_range": [sz, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
     "hamt_clip_scale": [sz, vp, vp, f32, vp],
     "hamt_rng_advance": [vp, vp],
 }

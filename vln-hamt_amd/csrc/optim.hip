@@ -75,7 +75,9 @@ template <int U, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, bf16_t* __restrict__ p16, const int* __restrict__ ends,
                                                           const float4* __restrict__ hyp, int nparams, const float* __restrict__ gnorm_sq,
-                                                          float max_norm, float b1, float b2, float eps, int zero_grad) {
+                                                          float max_norm, float b1, float b2, float eps, int zero_grad, size_t first4) {
+  // (first4: float4 index of the pointers' element 0 inside the arena that `ends` describes -- a rank of a sharded optimizer
+  // updates only its own segments)
   // A block owns one contiguous range of the arena and walks it parameter by parameter (a range of ~85 k elements touches
   // one or two parameters), so that the inner loop is pure streaming with the hyper-parameters in registers: U float4 of
   // each of p, g, m, v in flight per thread (16 independent 16-byte loads), stores non-temporal (nothing re-reads p, m, v
@@ -87,13 +89,13 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __res
   int pi = 0;
   {   // binary search: first parameter whose end is beyond this block's first element
     int a = 0, b = nparams - 1;
-    const long e0 = (long)lo * 4;
+    const long e0 = (long)(lo + first4) * 4;
     while (a < b) { const int mid = (a + b) >> 1; if ((long)ends[mid] > e0) b = mid; else a = mid + 1; }
     pi = a;
   }
   typedef float f4 __attribute__((ext_vector_type(4)));
   for (size_t seg = lo; seg < hi; ++pi) {
-    const size_t pend = pi < nparams - 1 ? min(hi, (size_t)ends[pi] >> 2) : hi;   // offsets are multiples of 8 elements
+    const size_t pend = pi < nparams - 1 ? min(hi, ((size_t)ends[pi] >> 2) - first4) : hi;   // offsets are multiples of 8 elements
     const float4 h = hyp[pi];
     if (h.w != 0.f) {
       for (size_t i = seg + threadIdx.x; i < pend; i += 256 * U) {
@@ -159,10 +161,18 @@ extern "C" int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v,
   HAMT_CHECK_LAUNCH("hamt_adamw_flat");
   return HAMT_OK;
 }
+extern "C" int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g, float* m, float* v, void* p16, const int* ends, const float* hyp,
+                                      int nparams, const float* gnorm_sq, float max_norm, float beta1, float beta2, float eps,
+                                      int zero_grad, void* stream);
 extern "C" int hamt_adamw_table(size_t n, float* p, float* g, float* m, float* v, void* p16, const int* ends, const float* hyp,
                                 int nparams, const float* gnorm_sq, float max_norm, float beta1, float beta2, float eps,
                                 int zero_grad, void* stream) {
-  HAMT_CHECK_ARG(p && g && m && v && ends && hyp && nparams > 0 && n % 4 == 0, "hamt_adamw_table: bad argument");
+  return hamt_adamw_table_range(0, n, p, g, m, v, p16, ends, hyp, nparams, gnorm_sq, max_norm, beta1, beta2, eps, zero_grad, stream);
+}
+extern "C" int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g, float* m, float* v, void* p16, const int* ends, const float* hyp,
+                                      int nparams, const float* gnorm_sq, float max_norm, float beta1, float beta2, float eps,
+                                      int zero_grad, void* stream) {
+  HAMT_CHECK_ARG(p && g && m && v && ends && hyp && nparams > 0 && n % 4 == 0 && first % 4 == 0, "hamt_adamw_table: bad argument");
   HAMT_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
                  ((uintptr_t)p16 % 8) == 0 && ((uintptr_t)hyp % 16) == 0, "hamt_adamw_table: arenas must be 16-byte aligned");
   if (n == 0) return HAMT_OK;
@@ -171,7 +181,7 @@ extern "C" int hamt_adamw_table(size_t n, float* p, float* g, float* m, float* v
   size_t b = (n / 4 + 2047) / 2048;
   int nb = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
   hipLaunchKernelGGL((adamw_table_kernel<4, true, false>), dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v, (bf16_t*)p16, ends,
-                     (const float4*)hyp, nparams, gnorm_sq, max_norm, beta1, beta2, eps, zero_grad);
+                     (const float4*)hyp, nparams, gnorm_sq, max_norm, beta1, beta2, eps, zero_grad, first / 4);
   HAMT_CHECK_LAUNCH("hamt_adamw_table");
   return HAMT_OK;
 }

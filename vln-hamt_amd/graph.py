@@ -51,9 +51,13 @@ class GraphedTrainStep:
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync(self.opt)
-        from .optim import clip_grad_norm_
-        clip_grad_norm_(self.model.parameters(), self.max_norm, optimizer=self.opt)
-        self.opt.step()
+        if getattr(self.grad_sync, "sharded", False):      # reduce-scattered gradients: norm, AdamW over the owned slices, all-gather
+            self.opt.prepare_step()
+            self.grad_sync.update(self.max_norm)
+        else:
+            from .optim import clip_grad_norm_
+            clip_grad_norm_(self.model.parameters(), self.max_norm, optimizer=self.opt)
+            self.opt.step()
         self.opt.zero_grad()
         ops.advance_rng_epoch(loss.device)
         return loss
@@ -126,7 +130,7 @@ class GraphedTrainStep:
         if overl:
             self.grad_sync.mode = "eager"
             plan = self.grad_sync.take_plan()  # the pass's weight-gradient GEMMs: launched between the two graphs
-        if self.grad_sync is not None:
+        if self.grad_sync is not None and not getattr(self.grad_sync, "sharded", False):
             if self.update_graph is None:      # norm + AdamW over the arena: the same launches for every key
                 self.update_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.update_graph, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
@@ -182,7 +186,11 @@ class GraphedTrainStep:
                 self.opt._packed = True        # the replay packed the gradients; only the collective is left
                 self.grad_sync(self.opt)
                 self.opt._packed = False
-            self.update_graph.replay()
+            if getattr(self.grad_sync, "sharded", False):
+                self.grad_sync.update(self.max_norm)     # eager: owned-slice norm + 4-byte all-reduce + AdamW + all-gathers
+                ops.advance_rng_epoch(loss_c.device)
+            else:
+                self.update_graph.replay()
         return loss_c
 
 

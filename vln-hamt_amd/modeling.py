@@ -56,6 +56,7 @@ class HamtPreTrainedModel(nn.Module):
             if module.bias is not None:
                 module.bias.data.zero_()
         elif isinstance(module, nn.Embedding):
+            module.weight._hamt_fp32_read = True      # looked up in fp32 (optim.adamw.shadow_only: not a bf16-only GEMM weight)
             module.weight.data.normal_(mean=0.0, std=std)
             if module.padding_idx is not None:
                 module.weight.data[module.padding_idx].zero_()

@@ -30,6 +30,14 @@ from .. import _lib as L
 from ..ops import _p, _stream
 
 ALIGN = 8   # elements: keeps every tensor 32-byte aligned in the fp32 arenas and 16-byte aligned in the bf16 shadow
+REGION_ALIGN = 512   # elements: region / arena ends (8-element granules x up to 64 ranks)
+
+
+def shadow_only(p) -> bool:
+    """Is `p` read by the model ONLY through the optimizer's bf16 shadow (a GEMM weight of the bf16 path)?  Everything else --
+    vectors, embedding tables (gathered in fp32; `_hamt_fp32_read`, set by modeling.HamtPreTrainedModel), skinny or odd-width
+    matrices that go through the exact-fp32 GEMM -- is read from the fp32 master."""
+    return p.dim() == 2 and p.shape[1] % 64 == 0 and p.shape[0] % 8 == 0 and p.shape[0] >= 64 and not getattr(p, "_hamt_fp32_read", False)
 
 
 class AdamW(Optimizer):
@@ -64,10 +72,22 @@ class AdamW(Optimizer):
             if (g["betas"], g["eps"]) != b0:
                 raise ValueError("AdamW: betas/eps must be the same in every group (they are in the reference)")
         dev = ps[0].device
-        offs, n = [], 0
+        # Arena order: first the parameters the forward / backward only ever READ THROUGH THE bf16 SHADOW (the GEMM weights),
+        # then everything that is read in fp32 (biases, LayerNorm, embedding tables, skinny / odd-width weights).  A sharded
+        # data-parallel optimizer (parallel.ShardedGradSync) all-gathers the first region as bf16 and the second as fp32;
+        # both regions end on a multiple of REGION_ALIGN elements so that they split evenly over up to 64 ranks.  Relative
+        # order inside a region is the registration order (query / key / value weights stay adjacent: blocks._packed).
+        order = sorted(range(len(ps)), key=lambda i: 0 if shadow_only(ps[i]) else 1)
+        ps, gidx = [ps[i] for i in order], [gidx[i] for i in order]
+        offs, n, n_a = [], 0, None
         for p in ps:
+            if n_a is None and not shadow_only(p):
+                n = (n + REGION_ALIGN - 1) // REGION_ALIGN * REGION_ALIGN
+                n_a = n
             offs.append(n)
             n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        n = (n + REGION_ALIGN - 1) // REGION_ALIGN * REGION_ALIGN
+        self._n_shadow_only = n if n_a is None else n_a
         self._params, self._gidx, self._offs, self._n = ps, gidx, offs, n
         self._flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, o in zip(ps, offs):
@@ -80,7 +100,7 @@ class AdamW(Optimizer):
         L.check(L.load().hamt_cast_f32_bf16(n, _p(self._flat_p), _p(self._flat_p16), _stream()), "hamt_cast_f32_bf16")
         self._steps = np.zeros(len(ps), dtype=np.int64)
         self._gidx_np = np.asarray(gidx, dtype=np.int64)
-        ends = [o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN for p, o in zip(ps, offs)]
+        ends = offs[1:] + [n]          # (alignment gaps count as the tail of the parameter in front of them: zeros that stay zeros)
         self._ends = torch.tensor(ends, dtype=torch.int32, device=dev)
         # ring of pinned staging buffers: the async H2D copy of step k must have run before its slot is rewritten
         self._hyp_ring = [torch.zeros(len(ps), 4, dtype=torch.float32).pin_memory() for _ in range(4)]

@@ -90,6 +90,7 @@ def wrap_ddp(model, local_rank: int):
 # `default_wire(prec)` picks bf16 for the bf16 compute mode (whose weight gradients are products of bf16 images anyway)
 # unless HAMT_GRAD_WIRE says otherwise.
 _staging: dict = {}
+DRY = [False]      # measurement switch (bench.py): skip the collectives themselves (every rank keeps its own values) to time a step without them
 
 
 def default_wire(prec: str = "bf16") -> str:
@@ -114,7 +115,7 @@ def _stage_for(flat: torch.Tensor) -> torch.Tensor:
 def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20, wire: str = "fp32") -> torch.Tensor:
     """In-place average of a flat fp32 tensor over all ranks, in `chunk_elems`-element all-reduces (128 MiB fp32 / 64 MiB
     bf16 messages)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()) or DRY[0]:
         return flat
     world = dist.get_world_size()
     if wire == "bf16":
@@ -259,6 +260,201 @@ class OverlappedGradSync:
             self.done = False
             return
         allreduce_grads(optimizer, self.wire)
+
+
+def shard_cuts(n: int, n_a: int, world: int, bounds):
+    """Range boundaries for the sharded exchange: the plan's arena cut points `bounds` (ascending, inside (0, n)) rounded DOWN to
+    multiples of 8 * world (a cut may only move towards the range that becomes final LATER), plus the region boundary `n_a`
+    (bf16-gathered | fp32-gathered).  Returns sorted unique cut points including 0 and n; every range then splits into `world`
+    equal chunks of whole 8-element granules."""
+    q = 8 * world
+    assert n % q == 0 and n_a % q == 0, (n, n_a, world)
+    cuts = {0, n, n_a}
+    for b in bounds:
+        cuts.add(b // q * q)
+    return sorted(c for c in cuts if 0 <= c <= n)
+
+
+class ShardedGradSync(OverlappedGradSync):
+    """ZeRO-1 style step for the flat arenas: instead of all-reducing the gradient arena and running the
+    34-byte-per-parameter AdamW pass over all 174.8 M parameters on EVERY rank,
+
+        grouped wgrad g  ||  reduce-scatter(arena range g-1)        (as before, range by range behind the weight-gradient GEMMs)
+        -> each rank: sum of squares of the slices it owns -> ONE 8-byte all-reduce = the global norm
+        -> clip + AdamW over the owned slices only (1/world of the update traffic)
+        -> all-gather: the bf16 shadow for the GEMM-weight region (what forward / backward read), fp32 for the rest
+
+    Rank r owns chunk r of every range (ranges end on multiples of 8 * world elements, optim.adamw.REGION_ALIGN).  Bytes per GPU on
+    the wire with the bf16 format: (world-1)/world x (2 B/param reduce-scatter + 2 B/param all-gather of the weights + 4 B/param
+    of the ~14 % fp32-read parameters) -- about the bf16 all-reduce's -- while the update's HBM traffic drops by `world`.
+    Gradient slots of parameters without a gradient hold zeros on every rank (DDP find_unused_parameters=True semantics,
+    utils/misc.py:57-58): a range is zeroed right after its reduce-scatter and only the owned, reduced chunk is written back.
+    fp32 masters of GEMM weights this rank does not own are NOT kept current (nobody reads them: `gather_masters()` before saving)."""
+
+    sharded = True
+
+    def __init__(self, optimizer, n_groups: int = 4, wire: str = "fp32"):
+        super().__init__(optimizer, n_groups, wire)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.gloo = dist.is_initialized() and dist.get_backend() != "nccl"
+        o = optimizer.materialize()
+        assert o._n % (8 * self.world) == 0 and o._n_shadow_only % (8 * self.world) == 0
+        self._stage = torch.empty(o._n, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
+        self._own16 = torch.empty(o._n // self.world + 8, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
+        self._own32 = torch.empty(o._n // self.world + 8, dtype=torch.float32, device=o._flat_g.device)
+        self._gsq = torch.zeros(1, dtype=torch.float32, device=o._flat_g.device)
+        self._ranges = None                # [(lo, hi)] of the last exchange
+
+    # ---- collectives (gloo has neither reduce_scatter nor all_gather_into_tensor: same arithmetic through all_reduce / all_gather)
+    def _reduce_scatter(self, out, inp):
+        if not dist.is_initialized() or DRY[0]:
+            c = inp.numel() // self.world
+            out.copy_(inp[self.rank * c:(self.rank + 1) * c])
+        elif self.gloo:
+            dist.all_reduce(inp, op=dist.ReduceOp.SUM)
+            c = inp.numel() // self.world
+            out.copy_(inp[self.rank * c:(self.rank + 1) * c])
+        else:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+
+    def _all_gather_inplace(self, buf):
+        """buf [world * c]: chunk `rank` is current; fill in the others"""
+        if not dist.is_initialized() or DRY[0]:
+            return
+        c = buf.numel() // self.world
+        if self.gloo:
+            parts = [torch.empty_like(buf[:c]) for _ in range(self.world)]
+            dist.all_gather(parts, buf[self.rank * c:(self.rank + 1) * c].contiguous())
+            for r, t in enumerate(parts):
+                if r != self.rank:
+                    buf[r * c:(r + 1) * c].copy_(t)
+        else:
+            dist.all_gather_into_tensor(buf, buf[self.rank * c:(self.rank + 1) * c])
+
+    def _exchange_range(self, lo, hi):
+        """flat_g[lo:hi] -> mean over ranks of chunk `rank`, written back in place; the rest of the range zeroed"""
+        from . import _lib as L
+        from .ops import _p, _stream
+        g = self.opt._flat_g[lo:hi]
+        c = (hi - lo) // self.world
+        if self.wire == "bf16":
+            st, own = self._stage[lo:hi], self._own16[:c]
+            L.check(L.load().hamt_wire_pack_bf16(hi - lo, _p(g), _p(st), 1.0 / self.world, _stream()), "hamt_wire_pack_bf16")
+            self._reduce_scatter(own, st)
+            g.zero_()
+            L.check(L.load().hamt_wire_unpack_bf16(c, _p(own), _p(g[self.rank * c:(self.rank + 1) * c]), _stream()), "hamt_wire_unpack_bf16")
+        else:
+            own = self._own32[:c]
+            self._reduce_scatter(own, g)
+            g.zero_()
+            torch.mul(own, 1.0 / self.world, out=g[self.rank * c:(self.rank + 1) * c])
+
+    def run(self, plan):
+        """The plan's groups with the reduce-scatters on the communication stream (same overlap structure as the parent)."""
+        from . import wgrad
+        o = self.opt
+        main = torch.cuda.current_stream()
+        cuts = shard_cuts(o._n, o._n_shadow_only, self.world, [r[0] for r in plan.ranges if r[0] > 0])
+        # a (cut) range is final once every plan range that overlaps it is
+        rng = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            touched, after = set(), -1
+            for (plo, phi, paf, pt) in plan.ranges:
+                if plo < hi and phi > lo:
+                    touched |= set(pt)
+                    after = max(after, paf)
+            rng.append((lo, hi, after, touched))
+        self._ranges = [(lo, hi) for lo, hi, _, _ in rng]
+        pending = sorted(rng, key=lambda r: r[2])
+        k, done = 0, []
+
+        def reduce_ready(after):
+            nonlocal k
+            while k < len(pending) and pending[k][2] <= after:
+                lo, hi, _, touched = pending[k]
+                if touched:
+                    for g in touched:
+                        self.comm.wait_event(done[g])
+                else:
+                    self.comm.wait_stream(main)
+                with torch.cuda.stream(self.comm):
+                    self._exchange_range(lo, hi)
+                k += 1
+
+        reduce_ready(-1)
+        lanes = self.lanes if self.alternate else [main]
+        for ln in lanes:
+            if ln is not main:
+                ln.wait_stream(main)
+        for g in range(len(plan.groups)):
+            ln = lanes[g % len(lanes)]
+            for d in plan.deps[g]:
+                ln.wait_event(done[d])
+            with torch.cuda.stream(ln):
+                wgrad.launch_group(plan, g)
+            done.append(ln.record_event())
+            reduce_ready(g)
+        for ln in lanes:
+            if ln is not main:
+                main.wait_stream(ln)
+        main.wait_stream(self.comm)
+
+    def __call__(self, optimizer):
+        if self.done:
+            self.done = False
+            return
+        # no queued GEMM gradients in this pass (fp32 mode / nothing deferred): exchange the whole arena as one range per region
+        if not optimizer._packed:
+            optimizer._pack_grads()
+        o = self.opt
+        self._ranges = [(lo, hi) for lo, hi in zip(*(lambda c: (c[:-1], c[1:]))(shard_cuts(o._n, o._n_shadow_only, self.world, [])))]
+        for lo, hi in self._ranges:
+            self._exchange_range(lo, hi)
+
+    def owned(self):
+        """[(first, count)] arena segments this rank updates"""
+        out = []
+        for lo, hi in self._ranges:
+            c = (hi - lo) // self.world
+            if c:
+                out.append((lo + self.rank * c, c))
+        return out
+
+    @torch.no_grad()
+    def update(self, max_norm: float):
+        """Global-norm clip + AdamW over the owned segments, then the all-gathers.  The host part (optimizer.prepare_step) must
+        have run; replaces clip_grad_norm_ + optimizer.step() + zero_grad() of the unsharded loop."""
+        from . import _lib as L
+        from .ops import _p, _stream
+        o, lib = self.opt, L.load()
+        segs = self.owned()
+        for i, (f, c) in enumerate(segs):
+            L.check(lib.hamt_sumsq(c, _p(o._flat_g[f:f + c]), _p(self._gsq), int(i > 0), _p(o._ws), _stream()), "hamt_sumsq")
+        if dist.is_initialized() and not DRY[0]:
+            dist.all_reduce(self._gsq, op=dist.ReduceOp.SUM)          # 4 bytes: the global squared norm
+        b1, b2 = o.param_groups[0]["betas"]
+        for f, c in segs:
+            L.check(lib.hamt_adamw_table_range(f, c, _p(o._flat_p[f:f + c]), _p(o._flat_g[f:f + c]), _p(o._flat_m[f:f + c]), _p(o._flat_v[f:f + c]),
+                                               _p(o._flat_p16[f:f + c]), _p(o._ends), _p(o._hyp), len(o._params), _p(self._gsq), float(max_norm),
+                                               b1, b2, o.param_groups[0]["eps"], 1, _stream()), "hamt_adamw_table_range")
+        n_a = o._n_shadow_only
+        for lo, hi in self._ranges:
+            if hi <= n_a:
+                self._all_gather_inplace(o._flat_p16[lo:hi])         # GEMM weights: only their bf16 image is ever read
+            else:
+                self._all_gather_inplace(o._flat_p[lo:hi])
+        if o._n > n_a:                                                # bf16 images of the >= 2-D fp32-read parameters (tied MLM decoder ...)
+            L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
+        o.mark_updated()
+
+    @torch.no_grad()
+    def gather_masters(self):
+        """Make every rank's fp32 masters of the GEMM-weight region current (before state_dict() / checkpointing)."""
+        o = self.opt
+        for lo, hi in (self._ranges or []):
+            if hi <= o._n_shadow_only:
+                self._all_gather_inplace(o._flat_p[lo:hi])
 
 
 def broadcast_params(optimizer, src: int = 0) -> None:
