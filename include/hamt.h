@@ -212,6 +212,8 @@ typedef struct {
   float* dbeta;
   float* dxsum;
   int M, H;
+  int atomic; /* bit 0 / 1 / 2: dgamma / dbeta / dxsum is atomically ADDED to instead of stored (several LayerNorm calls sharing
+               * one parameter's zero-initialised gradient slot: no separate accumulation pass) */
 } hamt_ln_reduce_desc;
 #define HAMT_LNRED_TABLE_ENTRY 48
 int hamt_ln_bwd_reduce_grouped(int n, const hamt_ln_reduce_desc* descs, void* table, size_t table_bytes, void* stream);
@@ -270,6 +272,8 @@ int hamt_wire_unpack_bf16(size_t n, const void* y, float* x, void* stream);
 /* x[i] = value where flag[i] == 0  (A16 in-place masked_fill_(nav_types == 0, -inf), pretrain_cmt.py:177;
  * its backward zeroes the gradient at the same positions) */
 int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, void* stream);
+/* out[i] = (1 - mask[i]) * -10000: the additive attention mask of a bool (1 byte / element) keep-mask (vilmodel.py:597-599) */
+int hamt_extend_mask(size_t n, const void* mask_u8, float* out, void* stream);
 /* dx = dy * act'(h): mode 1 erf-GELU (vilmodel.py:23-29), mode 2 ReLU (h may be the ReLU output) */
 int hamt_act_bwd(size_t n, const float* dy, const float* h, int mode, float* dx, void* stream);
 

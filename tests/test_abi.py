@@ -60,7 +60,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.LnDesc) == 7 * 4
     assert ctypes.sizeof(_lib.WgradDesc) == 4 * 8 + 8 * 4          # 4 pointers + 8 ints, no padding
     assert _lib.WgradDesc.M.offset == 32 and _lib.WgradDesc.accum_db.offset == 60
-    assert ctypes.sizeof(_lib.LnReduceDesc) == 4 * 8 + 2 * 4 and _lib.LnReduceDesc.M.offset == 32      # hamt_ln_reduce_desc
+    assert ctypes.sizeof(_lib.LnReduceDesc) == 4 * 8 + 4 * 4 and _lib.LnReduceDesc.M.offset == 32 and _lib.LnReduceDesc.atomic.offset == 40      # hamt_ln_reduce_desc (3 ints + tail padding)
 
 
 def test_product_never_imports_oracle():

@@ -141,12 +141,14 @@ def test_optimizer_state_dict_roundtrip(tiny, tmp_path):
         _eager_step(m2, o2, b, t)
     torch.cuda.synchronize()
     w = _worst(m1, m2)
-    assert w < 1e-6, w                                               # same kernels, same inputs (dropout off)
     m3, o3 = _model_opt(cfg, sd, eps=1e-6)                           # a resume WITHOUT the optimizer state diverges measurably
     m3.load_state_dict(ck["model"])
     for b, t in zip(bs[3:], tasks[3:]):
         _eager_step(m3, o3, b, t)
-    assert _worst(m1, m3) > 1e-4
+    w3 = _worst(m1, m3)
+    # same kernels, same inputs, dropout off: what is left is the order of the atomic adds in the embedding gradients, which
+    # Adam with eps = 1e-6 turns into a few % of lr = 1e-3 on parameters whose gradient is rounding noise
+    assert w < 5e-5 and w3 > 1e-4 and w3 > 10 * w, (w, w3)
 
 
 def test_wgrad_queue_recovers_after_a_failed_backward(tiny):

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
 
 
 class LnReduceDesc(C.Structure):
-    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dxsum", C.c_void_p), ("M", i32), ("H", i32)]
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dxsum", C.c_void_p), ("M", i32), ("H", i32), ("atomic", i32)]
 
 
 LNRED_TABLE_ENTRY = 48
@@ -99,6 +99,7 @@ SIGNATURES = {
     "hamt_mse_bwd": [sz, vp, vp, vp, vp, vp],
     "hamt_kl_fwd": [i32, i32, vp, i32, vp, i32, vp, vp, vp],
     "hamt_kl_bwd": [i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp],
+    "hamt_extend_mask": [sz, vp, vp, vp],
     "hamt_a2c_fwd": [i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp],
     "hamt_a2c_bwd": [i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "hamt_sumsq": [sz, vp, vp, i32, vp, vp],

@@ -455,3 +455,18 @@ extern "C" int hamt_rng_advance(uint64_t* rng, void* stream) {
   HAMT_CHECK_LAUNCH("hamt_rng_advance");
   return HAMT_OK;
 }
+
+// additive attention mask of a boolean (1 byte per element) keep-mask: out = (1 - m) * -10000 (vilmodel.py:597-599, 604-606, 626-628)
+namespace {
+__global__ void extend_mask_kernel(size_t n, const unsigned char* __restrict__ m, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (1.0f - (m[i] ? 1.0f : 0.0f)) * -10000.0f;
+}
+}  // namespace
+extern "C" int hamt_extend_mask(size_t n, const void* mask_u8, float* out, void* stream) {
+  HAMT_CHECK_ARG(mask_u8 && out, "hamt_extend_mask: null pointer");
+  if (n == 0) return HAMT_OK;
+  hipLaunchKernelGGL(extend_mask_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, as_stream(stream), n, (const unsigned char*)mask_u8, out);
+  HAMT_CHECK_LAUNCH("hamt_extend_mask");
+  return HAMT_OK;
+}

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce4_kernel(int nb, int H, cons
 // Grouped form of the reduction: entry e owns blocks [e * bpe, (e + 1) * bpe) (bpe = 3 * Hmax / 64; blocks beyond an entry's
 // own 3 * H / 64 exit).  The entry table is written into device memory by tiny kernels from kernarg chunks, like the
 // grouped weight-gradient launch, so the call is capturable and `descs` need not outlive it.
-struct LnRedEntry { const float* ws; float* dgamma; float* dbeta; float* dxsum; int nb, H, pad0, pad1; };
+struct LnRedEntry { const float* ws; float* dgamma; float* dbeta; float* dxsum; int nb, H, atomic, pad1; };   // atomic: bit i = output i is ADDED (atomically)
 constexpr int LNRED_CHUNK = 64;                  // entries per kernarg chunk (64 x 48 B)
 struct LnRedChunk { LnRedEntry e[LNRED_CHUNK]; };
 __global__ void ln_red_table_write_kernel(LnRedChunk c, LnRedEntry* tab, int off, int cnt) {
@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_grouped_kernel(const LnRedE
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < 16; ++i) { const float4 r = red[i][l16]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
-      *(float4*)(o + col) = t;
+      if ((q.atomic >> which) & 1) {     // the output is a gradient-arena slot shared with other uses of the parameter (zero at the start of a step)
+        atomicAdd(o + col, t.x); atomicAdd(o + col + 1, t.y); atomicAdd(o + col + 2, t.z); atomicAdd(o + col + 3, t.w);
+      } else *(float4*)(o + col) = t;
     }
   }
 }
@@ -393,7 +395,7 @@ extern "C" int hamt_ln_bwd_reduce_grouped(int n, const hamt_ln_reduce_desc* desc
       const hamt_ln_reduce_desc& d = descs[b0 + i];
       int nwv, nb;
       ln_bwd_geometry(d.M, &nwv, &nb);
-      ch.e[i] = LnRedEntry{d.ws, d.dgamma, d.dbeta, d.dxsum, nb, d.H, 0, 0};
+      ch.e[i] = LnRedEntry{d.ws, d.dgamma, d.dbeta, d.dxsum, nb, d.H, d.atomic, 0};
     }
     hipLaunchKernelGGL(ln_red_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, b0, cnt);
   }

@@ -528,7 +528,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
     @staticmethod
     def _extend(mask):
         """(B,S) bool -> additive (B,1,1,S) = (1 - m) * -10000 (vilmodel.py:597-599)."""
-        return (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+        return ops.extend_mask(mask)
 
     def forward(self, txt_ids, txt_masks, hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
                 hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks):

@@ -167,7 +167,7 @@ class NavCMT(BertPreTrainedModel):
 
     @staticmethod
     def _extend(mask):
-        return (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+        return ops.extend_mask(mask)
 
     def forward(self, mode, txt_ids=None, txt_embeds=None, txt_masks=None, hist_img_feats=None, hist_ang_feats=None,
                 hist_pano_img_feats=None, hist_pano_ang_feats=None, hist_embeds=None, ob_step_ids=None, hist_masks=None,

@@ -657,6 +657,7 @@ class GatherRowsFn(torch.autograd.Function):
                 "hamt_gather_rows")
         ctx.save_for_backward(idx)
         ctx.tshape, ctx.has_base, ctx.bshape = table.shape, base is not None, (base.shape if base is not None else None)
+        ctx.table_param = table if (table.is_leaf and table.requires_grad and getattr(table, "_hamt_grad_slot", None) is not None) else None
         return out
 
     @staticmethod
@@ -666,13 +667,35 @@ class GatherRowsFn(torch.autograd.Function):
         R, W = dout.shape
         dtab = None
         if ctx.needs_input_grad[0]:
-            dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
-            L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(dtab), W, _stream()), "hamt_scatter_add_rows")
+            p = ctx.table_param
+            slot = getattr(p, "_hamt_grad_slot", None) if p is not None else None
+            from . import wgrad
+            if (slot is not None and wgrad.ENABLED and slot.shape == p.shape and slot.is_contiguous()
+                    and (p.grad is None or p.grad.data_ptr() == slot.data_ptr()) and torch._C._current_graph_task_id() >= 0):
+                # an embedding table that owns a slot in the optimizer's gradient arena (zero at the start of a step): add the rows
+                # there -- no 94 MB zero fill for the 30 522 x 768 word table, no copy into the arena afterwards; published as
+                # `.grad` at the end of the pass (the tied MLM decoder's queued weight gradient then accumulates on top)
+                L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(slot), W, _stream()), "hamt_scatter_add_rows")
+                wgrad.publish_slot_grad(p, slot)
+            else:
+                dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
+                L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(dtab), W, _stream()), "hamt_scatter_add_rows")
         return dtab, None, (dout.view(ctx.bshape) if ctx.has_base else None)
 
 
 def gather_rows(table, idx, base=None):
     return GatherRowsFn.apply(table, idx, base)
+
+
+@torch.no_grad()
+def extend_mask(mask: torch.Tensor) -> torch.Tensor:
+    """(B, S) bool keep-mask -> additive (B, 1, 1, S) fp32 = (1 - m) * -10000 (vilmodel.py:597-599) in one launch"""
+    if mask.dtype != torch.bool or not mask.is_cuda:
+        return (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+    m = mask.contiguous()
+    out = torch.empty(m.shape[0], 1, 1, m.shape[1], dtype=torch.float32, device=m.device)
+    L.check(L.load().hamt_extend_mask(m.numel(), _p(m), _p(out), _stream()), "hamt_extend_mask")
+    return out
 
 
 @torch.no_grad()

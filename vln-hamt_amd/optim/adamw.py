@@ -189,6 +189,8 @@ class AdamW(Optimizer):
         """Device side of a step (static launch sequence; capturable)."""
         b1, b2 = self.param_groups[0]["betas"]
         gn, max_norm = self._pending_clip if self._pending_clip is not None else (None, 0.0)
+        if zero_grad_arena:
+            self._flat_g._hamt_dirty = False
         L.check(L.load().hamt_adamw_table(self._n, _p(self._flat_p), _p(self._flat_g), _p(self._flat_m), _p(self._flat_v),
                                           _p(self._flat_p16), _p(self._ends), _p(self._hyp), len(self._params), _p(gn),
                                           float(max_norm), b1, b2, self.param_groups[0]["eps"], int(zero_grad_arena), _stream()),
@@ -217,6 +219,10 @@ class AdamW(Optimizer):
         super().zero_grad(set_to_none=set_to_none)
         self._packed = False
         from .. import wgrad
+        if self._built and getattr(self._flat_g, "_hamt_dirty", False):
+            # something accumulated into arena slots it assumed zero and no update (which zeroes the arena) has run since
+            self._flat_g.zero_()
+            self._flat_g._hamt_dirty = False
         dev = self.param_groups[0]["params"][0].device
         if dev.type == "cuda" and torch._C._current_graph_task_id() < 0 and wgrad.pending(dev):
             wgrad.reset(dev)                     # leftovers of a backward pass that raised: never carry them into the next step

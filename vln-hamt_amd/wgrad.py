@@ -158,10 +158,21 @@ def defer_ln_reduce(ws, red, M, H, want_dxsum, pairs):
     column sums of dx) in the grouped launch at the end of the pass, then publish `pairs` = [(parameter, row of red)] as
     `.grad` (added to an existing one).  The Function's backward returns None for these parameters."""
     ps = queue(ws.device).current()
-    ps.lnred.append((ws, red, M, H, want_dxsum))
-    for p, t in pairs:
-        if p is not None and t is not None and p.requires_grad:
-            ps.vecs.append((p, t))
+    ps.lnred.append((ws, red, M, H, want_dxsum, [(p if (p is not None and t is not None and p.requires_grad) else None) for p, t in pairs]))
+
+
+def mark_arena_dirty(slot: torch.Tensor):
+    """A producer relied on `slot` (a view of the optimizer's flat gradient arena) being zero before it added into it: the arena
+    must be re-zeroed before the next pass even if no optimizer step runs in between (optim.AdamW.zero_grad checks the mark;
+    the update kernel zeroes the arena itself)."""
+    base = slot._base if slot._base is not None else slot
+    base._hamt_dirty = True
+
+
+def publish_slot_grad(p: torch.Tensor, slot: torch.Tensor):
+    """`slot` (p's gradient-arena slot) was accumulated into in place during this pass: make it `p.grad` at the end of the pass."""
+    mark_arena_dirty(slot)
+    queue(slot.device).current().vecs.append((p, slot))
 
 
 def table_entries(descs, n: int) -> int:
@@ -216,7 +227,7 @@ def _target(p: torch.Tensor, targets: dict, fresh: list):
 def _flush_pass(ps: _Pass, handler):
     from .ops import _stream
     items, vecs, lnred = ps.items, ps.vecs, ps.lnred
-    if not items and not lnred:
+    if not items and not lnred and not vecs:
         return
     from . import streams
     streams.join_all()                # operands queued by backward nodes that ran on the second compute stream
@@ -224,15 +235,44 @@ def _flush_pass(ps: _Pass, handler):
         n = len(lnred)
         descs = (L.LnReduceDesc * n)()
         cur = torch.cuda.current_stream()
-        for i, (ws, red, M, H, want_dxsum) in enumerate(lnred):
+        late = []
+        uses: dict = {}
+        for (_ws, _red, _M, _H, want_dxsum, params) in lnred:
+            for j, p in enumerate(params):
+                if p is not None and not (j == 2 and not want_dxsum):
+                    uses[id(p)] = uses.get(id(p), 0) + 1
+        for i, (ws, red, M, H, want_dxsum, params) in enumerate(lnred):
             ws.record_stream(cur)         # (allocated under whichever compute stream ran that LayerNorm backward)
             red.record_stream(cur)
             d = descs[i]
-            d.ws, d.dgamma, d.dbeta, d.dxsum, d.M, d.H = ws.data_ptr(), red[0].data_ptr(), red[1].data_ptr(), (red[2].data_ptr() if want_dxsum else None), M, H
+            d.ws, d.M, d.H, d.atomic = ws.data_ptr(), M, H, 0
+            ptrs = [None, None, None]
+            for j, p in enumerate(params):
+                if p is None or (j == 2 and not want_dxsum):
+                    continue
+                slot = getattr(p, "_hamt_grad_slot", None)
+                # (at most two contributions per slot: a two-term fp32 sum does not depend on the order the atomics land in;
+                # a parameter used more often -- every step of a finetune rollout -- keeps the ordered sum below)
+                if slot is not None and slot.numel() == H and uses[id(p)] <= 2 and (p.grad is None or p.grad.data_ptr() == slot.data_ptr()):
+                    # straight into the parameter's (zero-initialised) gradient-arena slot: a parameter shared by several LayerNorm
+                    # calls (the cross-attention block runs twice per x-layer) needs no separate accumulation, and nothing to pack
+                    ptrs[j] = slot.data_ptr()
+                    d.atomic |= 1 << j
+                    p.grad = slot
+                    mark_arena_dirty(slot)
+                else:
+                    ptrs[j] = red[j].data_ptr()
+                    late.append((p, red[j]))
+            d.dgamma, d.dbeta, d.dxsum = ptrs
         table = torch.empty(n * L.LNRED_TABLE_ENTRY, dtype=torch.uint8, device=lnred[0][0].device)
         L.check(L.load().hamt_ln_bwd_reduce_grouped(n, descs, table.data_ptr(), table.numel(), _stream()), "hamt_ln_bwd_reduce_grouped")
-        for p, t in vecs:
+        for p, t in late:
             p.grad = t if p.grad is None else p.grad + t
+    for p, t in vecs:                    # gradients produced in place in their arena slots during the pass (embedding tables)
+        if p.grad is None:
+            p.grad = t
+        elif p.grad.data_ptr() != t.data_ptr():
+            p.grad = p.grad + t
     if not items:
         return
     if handler is not None:
