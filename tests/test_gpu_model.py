@@ -769,6 +769,39 @@ def test_graphed_inference_rollout_matches_eager():
         assert len(gv.graphs) == 3
 
 
+def test_bidirectional_cross_attention_node_matches_two_blocks(tiny):
+    """blocks.XBidirBlockFn (HAMT_XBIDIR=1: LXRTXLayer.cross_att, vilmodel.py:379-383, as one node with each stream projected once
+    by the packed QKV weights and one output projection over both streams' rows) == the two separate cross-attention blocks:
+    SAP loss and every parameter gradient, dropout off, same weights and batch; incl. MLM, whose last x-layer leaves the
+    vision stream's output unread (its gradient arrives as None)."""
+    from vln_hamt_amd.model import vilmodel
+    store, cfg, sd = tiny
+    prev = vilmodel.XBIDIR
+    try:
+        for tag in ("sap", "mlm", "sprel"):
+            task = tag
+            batch = to_dev(_batch_with_itm(store, tag))
+            res = []
+            for flag in (False, True):
+                vilmodel.XBIDIR = flag
+                m = build(cfg, sd, "bf16", train=False)
+                loss = m(batch, task, True)
+                loss.mean().backward()
+                torch.cuda.synchronize()
+                res.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+            (l0, g0), (l1, g1) = res
+            assert set(g0) == set(g1), set(g0) ^ set(g1)
+            assert float((l0 - l1).abs().max()) <= 2e-3 * max(1.0, float(l0.abs().max())), (tag, l0, l1)
+            dot = sum(float((g0[k].double() * g1[k].double()).sum()) for k in g0)
+            n0 = sum(float((g0[k].double() ** 2).sum()) for k in g0) ** 0.5
+            n1 = sum(float((g1[k].double() ** 2).sum()) for k in g0) ** 0.5
+            print(f"[xbidir {tag}] loss diff {float((l0 - l1).abs().max()):.1e}, gradient cosine {dot / (n0 * n1):.6f}, norm ratio {n1 / n0:.4f}")
+            # (the separate blocks sum the two directions' bf16 key/value gradients in fp32 GEMM epilogues, the node in one bf16 image)
+            assert dot / (n0 * n1) >= 0.9995 and abs(n1 / n0 - 1) < 5e-3
+    finally:
+        vilmodel.XBIDIR = prev
+
+
 def _tiny_navcmt(no_lang_ca=True, train=False, p_drop=None):
     from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
     from vln_hamt_amd.models.vilmodel_cmt import NavCMT

@@ -541,7 +541,7 @@ def _can_defer_ln(params, dev, H=64):
     return all(p is None or (isinstance(p, torch.Tensor) and p.is_leaf) for p in params)
 
 
-def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_dx16, want_dxsum, params=None):
+def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_dx16, want_dxsum, params=None, dx16_out=None):
     """-> (dz, dx32 | None, dx16 | None, dgamma, dbeta, dxsum | None).  `params` = (gamma, beta, bias) PARAMETERS (bias:
     of the dense layer whose output fed the LayerNorm, or None): the per-block partials of their gradients are then
     summed by ONE grouped launch at the end of the pass (54 tiny reductions leave the critical path of a step), published
@@ -551,7 +551,11 @@ def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_
     dz = torch.empty(M, H, dtype=torch.float32, device=dev)
     dx = torch.empty(M, H, dtype=torch.float32, device=dev) if (want_dx32 and p_pre > 0) else None
     Mp = _rup(M) if want_dx16 else 0
-    dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want_dx16 else None
+    if dx16_out is not None:      # caller-provided rows of a larger bf16 image (blocks.XBidirBlockFn's joint buffer)
+        assert want_dx16 and dx16_out.shape == (Mp, H) and dx16_out.is_contiguous()
+        dx16 = dx16_out
+    else:
+        dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want_dx16 else None
     red = torch.empty(3, H, dtype=torch.float32, device=dev)      # stored (not accumulated) by the reduce kernel
     ws = torch.empty(L.workspace_bytes(L.WS_LN_BWD, M, H) // 4, dtype=torch.float32, device=dev)
     d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp)
