@@ -832,7 +832,7 @@ void launch_bm(const GemmArgsF& g, dim3 grid, hipStream_t s) {
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
-  else if constexpr (NST != 2) launch_bm<BM, A_KM, B_KM, 2>(g, grid, s);   // deep rings are compiled for the narrow-output epilogues only
+  else if constexpr (BM == 32) launch_bm<64, A_KM, B_KM, NST>(g, dim3(((g.M + 63) / 64) * ((g.N + BN - 1) / BN), grid.y), s);   // 32-row tiles: narrow-output epilogues only
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_SAVE_PRE);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_RELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_RELU);
   else if (e == HAMT_EPI_MUL_DGELU) HAMT_L(HAMT_EPI_MUL_DGELU);
@@ -928,11 +928,14 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
     const bool ok = !d->a_kmajor ? (!d->b_kmajor ? launch_256<false, false>(g, s) : launch_256<false, true>(g, s)) : false;
     if (ok) return;
   }
-  static const int force_st = getenv("HAMT_FAST_STAGES") ? atoi(getenv("HAMT_FAST_STAGES")) : 0;
-  const int nst = force_st ? force_st : 2;
+  // 32-row tiles: for grids so small (the B = 16 shapes: 1280 x 768 outputs are 120 tiles of 64 rows) that 64-row tiles leave every
+  // SIMD with at most one wave, which then issues its DMA pieces, reads its fragments and multiplies strictly in turn
+  const long t32 = (long)((d->M + 31) / 32) * ((d->N + 127) / 128);
+  const bool bm32 = force_bm ? force_bm == 32 : (bm64 && ks == 1 && t64 <= 160 && d->K <= 1024);
+  const dim3 g32(((d->M + 31) / 32) * ((d->N + BN - 1) / BN), ks);
+  (void)t32;
 #define HAMT_BMST(AK, BK_) do { \
-    if (bm64) { if (nst == 4) launch_bm<64, AK, BK_, 4>(g, g64, s); else if (nst == 3) launch_bm<64, AK, BK_, 3>(g, g64, s); else launch_bm<64, AK, BK_>(g, g64, s); } \
-    else { if (nst == 4) launch_bm<128, AK, BK_, 4>(g, g128, s); else if (nst == 3) launch_bm<128, AK, BK_, 3>(g, g128, s); else launch_bm<128, AK, BK_>(g, g128, s); } } while (0)
+    if (bm32) launch_bm<32, AK, BK_>(g, g32, s); else if (bm64) launch_bm<64, AK, BK_>(g, g64, s); else launch_bm<128, AK, BK_>(g, g128, s); } while (0)
   if (!d->a_kmajor && !d->b_kmajor) HAMT_BMST(false, false);
   else if (!d->a_kmajor) HAMT_BMST(false, true);
 #undef HAMT_BMST
