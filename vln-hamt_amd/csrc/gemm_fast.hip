@@ -800,7 +800,14 @@ bool launch_p8(const GemmArgsF& g, hipStream_t s) {
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
   else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
-  else return false;
+  else if constexpr (!B_KM) {      // forward-only epilogues (the pre-LN ViT blocks: residual add / dropout in the epilogue)
+    if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX);
+    else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT);
+    else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT);
+    else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU);
+    else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_DROPOUT);
+    else return false;
+  } else return false;
 #undef HAMT_L
   return true;
 }
