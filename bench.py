@@ -161,7 +161,7 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU minibatch (ITM uses batch/2 originals, loader.py:130)")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
@@ -170,8 +170,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-probes", action="store_true", help="only the timed steps (for rocprofv3 runs: no probe launches in the kernel statistics)")
-    ap.add_argument("--also-batch", type=int, default=-1, help="second per-GPU batch reported in `batch_sweep` (default: 16, the reference's "
-                    "per-GPU batch, when --batch is left at 64 on one GPU; 0 = none)")
+    ap.add_argument("--also-batch", type=int, default=-1, help="another per-GPU batch reported in `batch_sweep` (default: 16 -- the reference's "
+                    "per-GPU batch -- and 256 when --batch is left at 64 on one GPU; 0 = none)")
     args = ap.parse_args()
 
     from vln_hamt_amd import ops
@@ -329,13 +329,20 @@ def main():
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
             "exposed_comm_ms_per_step": exposed_comm_ms,
         }
-        also = args.also_batch if args.also_batch >= 0 else (16 if (args.batch == 64 and world == 1 and args.task == "mix") else 0)
+        # the other two per-GPU batches SURVEY 8d names next to the headline one -- 16 is the reference's own (pretrain_r2r.json:9) -- on
+        # the same model / optimizer / number of steps
+        also = [args.also_batch] if args.also_batch > 0 else ([16, 256] if (args.also_batch < 0 and args.batch == 64 and world == 1 and args.task == "mix") else [])
         if also and world == 1 and not args.no_probes:
-            # the reference's own per-GPU batch (pretrain_r2r.json:9) next to the headline batch, same model / optimizer / steps
-            dt2, smp2, fl2 = timed_region(also, args.warmup, args.steps, verbose=False)
-            out["batch_sweep"] = [{"per_gpu_batch": also, "value": round(smp2 / dt2, 2), "unit": "panorama-steps/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                                   "model_tflops_per_gpu": round(fl2 / dt2 / 1e12, 2), "mfma_roofline_frac_end_to_end": round(fl2 / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4)}]
-            log(f"batch {also}: {dt2 / args.steps * 1e3:.3f} ms/step")
+            out["batch_sweep"] = []
+            for bsz in also:
+                dt2, smp2, fl2 = timed_region(bsz, args.warmup, args.steps if bsz <= 64 else max(12, args.steps // 2), verbose=False)
+                n2 = args.steps if bsz <= 64 else max(12, args.steps // 2)
+                out["batch_sweep"].append({"per_gpu_batch": bsz, "value": round(smp2 / dt2, 2), "unit": "panorama-steps/s", "steps": n2,
+                                           "ms_per_step": round(dt2 / n2 * 1e3, 3), "model_tflops_per_gpu": round(fl2 / dt2 / 1e12, 2),
+                                           "mfma_roofline_frac_end_to_end": round(fl2 / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4)})
+                log(f"batch {bsz}: {dt2 / n2 * 1e3:.3f} ms/step")
+                for k in [k for k in batches if k[2] == bsz]:
+                    del batches[k]
         if args.task == "mix":
             cycle = [get_batch(s_) for s_ in range(len(sched.cycle))]
         else:

@@ -101,18 +101,21 @@ def default_wire(prec: str = "bf16") -> str:
     return "bf16" if prec == "bf16" else "fp32"
 
 
-def _stage_for(flat: torch.Tensor) -> torch.Tensor:
-    """bf16 mirror of the storage `flat` views (same element offsets), allocated once per arena"""
+def _stage_for(flat: torch.Tensor, cache: dict | None = None) -> torch.Tensor:
+    """bf16 mirror of the storage `flat` views (same element offsets), allocated once per arena.  `cache`: where the mirror is
+    kept -- the gradient-sync object's own dict (OverlappedGradSync passes one); the module-level dict only serves the plain
+    allreduce_grads() helper."""
+    cache = _staging if cache is None else cache
     st = flat.untyped_storage()
     key = (st.data_ptr(), st.nbytes(), str(flat.device))
-    buf = _staging.get(key)
+    buf = cache.get(key)
     if buf is None:
-        buf = _staging[key] = torch.empty(st.nbytes() // 4, dtype=torch.bfloat16, device=flat.device)
+        buf = cache[key] = torch.empty(st.nbytes() // 4, dtype=torch.bfloat16, device=flat.device)
     o = flat.storage_offset()
     return buf[o:o + flat.numel()]
 
 
-def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20, wire: str = "fp32") -> torch.Tensor:
+def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20, wire: str = "fp32", stage_cache: dict | None = None) -> torch.Tensor:
     """In-place average of a flat fp32 tensor over all ranks, in `chunk_elems`-element all-reduces (128 MiB fp32 / 64 MiB
     bf16 messages)."""
     if not (dist.is_available() and dist.is_initialized()) or DRY[0]:
@@ -120,7 +123,7 @@ def allreduce_mean_(flat: torch.Tensor, chunk_elems: int = 32 << 20, wire: str =
     world = dist.get_world_size()
     if wire == "bf16":
         assert flat.dtype == torch.float32 and flat.is_contiguous()
-        stage = _stage_for(flat)
+        stage = _stage_for(flat, stage_cache)
         if flat.is_cuda:
             import ctypes as C
             from . import _lib as L
@@ -181,6 +184,7 @@ class OverlappedGradSync:
         self.comm = torch.cuda.Stream()
         self.lanes = [torch.cuda.Stream() for _ in range(int(os.environ.get("HAMT_SYNC_LANES", 2)))]
         self.alternate = os.environ.get("HAMT_SYNC_ONE_LANE") is None
+        self._stage_cache: dict = {}        # this object's bf16 wire mirrors (no module-level state)
         self.mode = "eager"                # "eager": run at flush; "plan": only build the plan (graph capture)
         self.plan = None
         self.done = False
@@ -232,7 +236,7 @@ class OverlappedGradSync:
                 else:
                     self.comm.wait_stream(main)
                 with torch.cuda.stream(self.comm):
-                    allreduce_mean_(flat[lo:hi], wire=self.wire)
+                    allreduce_mean_(flat[lo:hi], wire=self.wire, stage_cache=self._stage_cache)
                 k += 1
 
         reduce_ready(-1)
