@@ -137,6 +137,53 @@ def test_gemm_epilogues(prec):
     close(o16.float(), lin, 1e-2, "bf16 C")
 
 
+@pytest.mark.parametrize("layout,shape,variant", [
+    ("nt", (1280, 768, 3072), "gemm_kg_kernel<32, 2, 4"), ("nn", (1280, 768, 2304), "gemm_kg_kernel<32, 2, 4"),
+    ("nt", (1968, 768, 3072), "gemm_kg_kernel<64, 3, 2"), ("nn", (1968, 768, 2304), "gemm_kg_kernel<64, 3, 2"),
+    ("nt", (688, 768, 768), "gemm_kg_kernel<32, 2, 4"), ("nt", (100, 130, 1536), "gemm_kg_kernel<32, 2, 4"),
+    ("nn", (1301, 700, 1600), "gemm_kg_kernel<32, 2, 4"), ("nn", (2500, 520, 1664), "gemm_kg_kernel<64, 3, 2")])
+def test_gemm_k_groups(layout, shape, variant):
+    """Small grids with a long reduction run as K groups inside one workgroup (gemm_kg_kernel): every k-tile residue class,
+    ragged edges, the run-time epilogue (bias, accumulate, bf16 output with an aux multiply, dropout + residual)."""
+    ops = _ops()
+    from vln_hamt_amd import _lib as L
+    M, N, K = shape
+    A, B, a_st, b_st, a_km, b_km = _mk(layout, M, N, K, 21)
+    a16, b16 = a_st.to(DEV).to(torch.bfloat16), b_st.to(DEV).to(torch.bfloat16)
+    ref = bf16_round(A).double() @ bf16_round(B).double()
+    tol = 2e-5 * math.sqrt(K) / 4
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(a16, b16, out, b_kmajor=b_km, prec="bf16")
+    assert L.last_kernel().startswith(variant), L.last_kernel()
+    close(out, ref, tol, f"kg plain {layout} {shape}")
+    bias = rnd(N, seed=5)
+    base = rnd(M, N, seed=6)
+    out = base.to(DEV).clone()
+    ops.gemm(a16, b16, out, b_kmajor=b_km, bias=bias.to(DEV), epilogue=L.EPI_ACCUM, prec="bf16", alpha=0.5)
+    assert L.last_kernel().startswith(variant), L.last_kernel()
+    close(out, base.double() + 0.5 * ref + bias.double(), tol, "kg bias + accum + alpha")
+    h = bf16_round(rnd(M, N, seed=7))
+    o16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(a16, b16, o16, b_kmajor=b_km, epilogue=L.EPI_MUL_AUX, aux=h.to(DEV).to(torch.bfloat16), prec="bf16")
+    assert L.last_kernel().startswith(variant), L.last_kernel()
+    close(o16.float(), ref * h.double(), 1e-2, "kg mul_aux bf16")
+    # dropout + residual: same mask stream as the plain-tile kernels (HAMT_KG=1 would run those) -> compare with the mask replayed
+    res = rnd(M, N, seed=8).to(DEV)
+    ops.gemm(a16, b16, out, b_kmajor=b_km, bias=bias.to(DEV), epilogue=L.EPI_ADD_AUX, aux=res, prec="bf16", drop=(0.25, 77))
+    y = (out - res).cpu().double()
+    lin = ref + bias.double()
+    kept = y != 0
+    frac = float(kept.double().mean())
+    assert abs(frac - 0.75) < 0.02, frac
+    close(torch.where(kept, y, torch.zeros_like(y)), torch.where(kept, lin / 0.75, torch.zeros_like(lin)), 3 * tol, "kg dropout + residual")
+    if layout == "nn":      # ragged reduction: B stores K - 5 rows, A is zero there
+        Az = A.clone()
+        Az[:, K - 5:] = 0
+        ops.gemm(Az.to(DEV).to(torch.bfloat16), b_st[:K - 5].contiguous().to(DEV).to(torch.bfloat16), out, b_kmajor=True, prec="bf16", k_red=K)
+        assert L.last_kernel().startswith(variant), L.last_kernel()
+        close(out, bf16_round(Az).double() @ bf16_round(B).double(), tol, "kg nn ragged K")
+
+
 def test_gemm_tr_read_matches_scalar_fallback():
     """ds_read_b64_tr_b16 fragment path == scalar LDS gather path (HAMT_NO_TR=1), bit for bit."""
     code = r"""

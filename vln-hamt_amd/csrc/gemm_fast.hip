@@ -459,6 +459,106 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgsF g) {
   gemm_tile<BM, EPI, A_KM, B_KM, NST, false>(g, (bid / tiles_n) * BM, (bid % tiles_n) * BN, kt0, kt1 - kt0, blockIdx.y, nullptr, 0);
 }
 
+// ---------------------------------------------------------------- K groups inside a workgroup (small grids, long reductions)
+// A BM x 128 output tile computed by G groups of four waves: group q multiplies the k-tiles q, q + G, q + 2G, ... from its own
+// two-deep operand ring, and the G accumulator tiles are summed through LDS (group order 0, 1, 2: deterministic) in front of
+// the usual epilogue.  For outputs with fewer tiles than CUs (the B = 16 text stream: 1280 x 768 = 120 tiles of 64 rows) a
+// plain tile leaves each SIMD one wave that issues its DMA pieces, reads its fragments and multiplies strictly in turn
+// (~1000 cycles per k-tile for 256 cycles of MFMA); split-K over the grid pays for its partial tiles in HBM traffic
+// (measured: 6 slices of 1280 x 768 fp32 = 29 us, as slow as no split at all).  Here the G waves of a SIMD overlap each
+// other's phases and the partial sums never leave the CU.  The epilogue flags are read at run time (one or two row pieces
+// per thread: nothing to unroll).
+template <int N> __device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+template <int BM, int G, int D, bool B_KM>
+__global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
+  constexpr int NW = 4, TM = BM / 2, TN = 64, FM = TM / 16, FN = 4;
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS, RING = D * STAGE;
+  constexpr int NLD = (BM + BN) / (8 * NW);      // DMA pieces per wave per stage
+  static_assert(BM * BN * 4 <= RING * 2, "a group's accumulator tile must fit its operand ring");
+  __shared__ __attribute__((aligned(16))) bf16_t lds[G * RING];
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, ((g.M + BM - 1) / BM) * tiles_n);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, w = wave & 3, wm = w >> 1, wn = w & 1;
+  const int nk = g.K / BK, iters = (nk + G - 1) / G, mine = (nk - grp + G - 1) / G;   // k-tiles grp + i G, i < mine
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16_t* ring = lds + grp * RING;
+  const unsigned ring0 = lds_base_of(lds) + (unsigned)(grp * RING * 2);
+  TileSrc<false, BM, NW> src_a;
+  TileSrc<B_KM, BN, NW> src_b;
+  src_a.init(g.lda, m0, g.M - 1, w, lane);
+  src_b.init(g.ldb, n0, g.N - 1, w, lane);
+  auto stage = [&](int i, int slot) {
+    const unsigned dst = ring0 + (unsigned)(slot * STAGE * 2);
+    const int k0 = (grp + i * G) * BK;
+    src_a.issue(g.A, g.lda, k0, g.ka_max, dst, w);
+    src_b.issue(g.B, g.ldb, k0, g.kb_max, dst + (unsigned)(A_ELEMS * 2), w);
+  };
+#pragma unroll
+  for (int p = 0; p < D - 1; ++p)
+    if (p < mine) stage(p, p);
+  for (int i = 0; i < iters; ++i) {
+    {   // tile i has landed when at most the pieces of the (up to D - 2) younger tiles are outstanding
+      const int younger = min(D - 2, mine - 1 - i);
+      if (D >= 6 && younger >= 4) wait_vmcnt_n<4 * NLD>();
+      else if (D >= 5 && younger == 3) wait_vmcnt_n<3 * NLD>();
+      else if (D >= 4 && younger == 2) wait_vmcnt_n<2 * NLD>();
+      else if (D >= 3 && younger == 1) wait_vmcnt_n<NLD>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();               // tile i of every group is in LDS; everyone is done with tile i - 1
+    if (i + D - 1 < mine) stage(i + D - 1, (i + D - 1) % D);
+    if (i < mine) {
+      const bf16_t* As = ring + (i % D) * STAGE;
+      const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int a = 0; a < FM; ++a) af[a] = frag<false, BM>(As, wm * TM + a * 16, s, lane);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = frag<B_KM, BN>(Bs, wn * TN + j * 16, s, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[a], acc[a][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  // accumulator tiles -> LDS (each group into its own ring), summed in group order, epilogue: 16 threads per row, 8 columns each
+  float* ct = (float*)ring;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int rl = wm * TM + a * 16 + (lane & 15), c4 = wn * (TN / 4) + j * 4 + (lane >> 4);
+      *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[a][j];
+    }
+  __syncthreads();
+  for (int piece = t; piece < BM * 16; piece += 256 * G) {
+    const int rl = piece >> 4, c8 = piece & 15;
+    float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const float* cq = (const float*)(lds + q * RING);
+      const f32x4 lo = *(const f32x4*)(cq + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
+      const f32x4 hi = *(const f32x4*)(cq + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+      v8[0] += lo[0]; v8[1] += lo[1]; v8[2] += lo[2]; v8[3] += lo[3]; v8[4] += hi[0]; v8[5] += hi[1]; v8[6] += hi[2]; v8[7] += hi[3];
+    }
+    epi_store<-1, 8>(g, m0 + rl, n0 + c8 * 8, v8);
+  }
+}
+
 // ---------------------------------------------------------------- grouped weight gradients
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
@@ -875,16 +975,39 @@ bool hamt_gemm_fast_eligible(const hamt_gemm_desc* d, const void* A, const void*
   return true;
 }
 
+// K groups inside the workgroup (gemm_kg_kernel) instead of plain tiles / split-K: when the whole output is at most one round
+// of workgroups of that kernel and the reduction is long enough to amortise the extra LDS pass.  Returns 100 * tile rows +
+// 10 * groups + ring depth, or 0.  Measured (tools/ksplit_sweep.py, B = 16 shapes, us): 1280x768x3072 29.4 -> 16.7,
+// x2304 17.6 -> 14.5, 1968x768x3072 29.9 -> 22.2, x2304 22.9 -> 17.8; no gain once the plain tiles fill the chip (B = 64).
+static int kg_variant(const hamt_gemm_desc* d) {
+  static const int force = getenv("HAMT_KG") ? atoi(getenv("HAMT_KG")) : 0;   // 1 = never, > 1 = always this variant
+  if (d->a_kmajor || force == 1) return 0;
+  if (force) return force;
+  const int nk = d->K / BK;
+  if (nk < 12 || d->N > 1024) return 0;
+  const long tn = (d->N + 127) / 128, t32 = (long)((d->M + 31) / 32) * tn, t64 = (long)((d->M + 63) / 64) * tn;
+  if (t32 <= 256) return 3224;
+  if (t64 <= 256 && nk >= 24) return 6432;
+  return 0;
+}
+
 // K slices to use for this problem given `ws_bytes` of workspace (1 = no split).
 int hamt_gemm_fast_ksplit(const hamt_gemm_desc* d, size_t ws_bytes) {
   if (d->epilogue & ~HAMT_EPI_ACCUM) return 1;
   if (d->dtype_c != HAMT_F32 || d->ldc != d->N) return 1;
+  static const int force_bm = getenv("HAMT_FAST_BM") ? atoi(getenv("HAMT_FAST_BM")) : 0;
+  static const int force = getenv("HAMT_KS") ? atoi(getenv("HAMT_KS")) : 0;
+  if (!force_bm && !force && kg_variant(d)) return 1;
   const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
   const int nk = d->K / BK;
-  if (tiles >= 192 || nk < 16) return 1;
-  int s = (int)(384 / tiles);
-  if (s > nk / 8) s = nk / 8;
-  if (s > 16) s = 16;
+  int s;
+  if (force) s = force > nk ? nk : force;
+  else {
+    if (tiles >= 192 || nk < 16) return 1;
+    s = (int)(384 / tiles);
+    if (s > nk / 8) s = nk / 8;
+    if (s > 16) s = 16;
+  }
   while (s > 1 && (size_t)s * d->M * d->N * 4 > ws_bytes) --s;
   return s < 2 ? 1 : s;
 }
@@ -929,6 +1052,20 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
     if (p8 == 1 || t_p8 < 0.95 * t_small) {
       const bool ok = !d->b_kmajor ? launch_p8<false, false>(g, s) : launch_p8<false, true>(g, s);
       if (ok) return;
+    }
+  }
+  if (ks == 1 && !force_bm) {
+    const int kg = kg_variant(d);
+    if (kg) {
+      const int bm = kg / 100, G = (kg / 10) % 10, D = kg % 10;
+      const dim3 grid(((d->M + bm - 1) / bm) * ((d->N + BN - 1) / BN));
+#define HAMT_KGL(BM_, G_, D_) do { if (d->b_kmajor) hipLaunchKernelGGL((gemm_kg_kernel<BM_, G_, D_, true>), grid, dim3(256 * G_), 0, s, g); \
+                               else hipLaunchKernelGGL((gemm_kg_kernel<BM_, G_, D_, false>), grid, dim3(256 * G_), 0, s, g); \
+                               hamt_set_last_kernel("gemm_kg_kernel<%d, %d, %d, %s>", BM_, G_, D_, d->b_kmajor ? "true" : "false"); } while (0)
+      if (bm == 32 && G == 2 && D == 3) HAMT_KGL(32, 2, 3); else if (bm == 32 && G == 3) HAMT_KGL(32, 3, 2);
+      else if (bm == 32) HAMT_KGL(32, 2, 4); else if (G == 2) HAMT_KGL(64, 2, 3); else HAMT_KGL(64, 3, 2);
+#undef HAMT_KGL
+      return;
     }
   }
   if (ks == 1 && use256(d, force_bm)) {
