@@ -291,6 +291,8 @@ def main():
             task, n = train_step(s, bsz)
             samples += n
             flops += 3.0 * trunk_fwd_flops(task) * n
+        if graphed is not None:
+            graphed.finish()                 # the last step's parameter update (overlap_update: a replay applies the previous step's)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()

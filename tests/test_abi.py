@@ -47,8 +47,9 @@ def test_library_exports_every_symbol():
     assert _lib.workspace_bytes(_lib.WS_WGRAD_TABLE, 768, 2304, 30522) == (12 + 36 + 477) * _lib.WGRAD_TABLE_ENTRY
     assert _lib.workspace_bytes(_lib.WS_LNRED_TABLE, 54) == 54 * _lib.LNRED_TABLE_ENTRY
     assert _lib.workspace_bytes(_lib.WS_GEMM_SPLITK, 5120, 3072, 768) == 0          # a grid that fills the chip is not split
-    ks = _lib.workspace_bytes(_lib.WS_GEMM_SPLITK, 128, 768, 8192)
-    assert ks > 0 and ks % (128 * 768 * 4) == 0
+    assert _lib.workspace_bytes(_lib.WS_GEMM_SPLITK, 128, 768, 8192) == 0           # narrow + small grid: K groups inside the workgroup
+    ks = _lib.workspace_bytes(_lib.WS_GEMM_SPLITK, 512, 2048, 8192)
+    assert ks > 0 and ks % (512 * 2048 * 4) == 0
     assert _lib.workspace_bytes(99) == 0
 
 

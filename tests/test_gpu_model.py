@@ -514,6 +514,7 @@ def test_graph_replay_matches_eager_steps(tiny):
     losses = []
     for t in seq:
         losses.append(float(gs.step(t, batches[t], t)))
+    gs.finish()                      # (the update of the last replayed step is applied by the next replay or by finish())
     torch.cuda.synchronize()
     assert len(gs.graphs) == 4
     worst = 0.0
@@ -869,6 +870,23 @@ def test_rollout_caches_match_the_plain_rollout():
         assert float((first[0][fin] - got2[0][fin]).abs().max()) > 0.0          # the episodes do differ
 
 
+def _rollout_loss(model, b, T):
+    """imitation-learning rollout of T steps: language once, visual + history per step with the growing history"""
+    from vln_hamt_amd import ops
+    B = b["txt_ids"].shape[0]
+    lang = model("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
+    hs = [model("history").expand(B, -1)]
+    loss = 0.0
+    for t in range(T):
+        out = model("visual", txt_embeds=lang, hist_embeds=torch.stack(hs, 1), txt_masks=b["txt_masks"], hist_masks=b["hist_masks"][:, :t + 1].contiguous(),
+                    ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
+        loss = loss + ops.cross_entropy(out[0], b["ob_action_viewindex"]).mean()
+        hs.append(model("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
+                        ob_step_ids=b["step_ids"][t:t + 1], hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
+                        hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
+    return loss
+
+
 def test_graphed_rollout_training_step_matches_eager():
     """Row N2, training direction: a whole imitation-learning rollout (language once, visual + history per step with the growing
     history, a cross-entropy per step -- agent_cmt.py:248-529 order) and its ONE backward, clip and AdamW captured as a single
@@ -880,18 +898,7 @@ def test_graphed_rollout_training_step_matches_eager():
     T = 3
 
     def rollout_loss(model, b, _task):
-        B = b["txt_ids"].shape[0]
-        lang = model("language", txt_ids=b["txt_ids"], txt_masks=b["txt_masks"])
-        hs = [model("history").expand(B, -1)]
-        loss = 0.0
-        for t in range(T):
-            out = model("visual", txt_embeds=lang, hist_embeds=torch.stack(hs, 1), txt_masks=b["txt_masks"], hist_masks=b["hist_masks"][:, :t + 1].contiguous(),
-                        ob_img_feats=b["ob_img_fts"], ob_ang_feats=b["ob_ang_fts"], ob_nav_types=b["ob_nav_types"], ob_masks=b["ob_masks"])
-            loss = loss + ops.cross_entropy(out[0], b["ob_action_viewindex"]).mean()
-            hs.append(model("history", hist_img_feats=b["hist_img_fts"][:, t].contiguous(), hist_ang_feats=b["hist_ang_fts"][:, t].contiguous(),
-                            ob_step_ids=b["step_ids"][t:t + 1], hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
-                            hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
-        return loss
+        return _rollout_loss(model, b, T)
 
     cfg = tiny_cfg(no_lang_ca=True, act_pred_token="ob")
     bs = []
@@ -908,6 +915,7 @@ def test_graphed_rollout_training_step_matches_eager():
             gs = GraphedTrainStep(m, o, 5.0, loss_fn=rollout_loss)
             for b in bs:
                 losses.append(float(gs.step("rollout", b, "rollout")))
+            gs.finish()
             assert len(gs.graphs) == 1
         else:
             for b in bs:
@@ -925,6 +933,89 @@ def test_graphed_rollout_training_step_matches_eager():
     assert max(abs(a - c) for a, c in zip(l1, l2)) < 5e-4, (l1, l2)
     worst = max(float((a - c).abs().max()) for (_, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()))
     print(f"[graphed rollout step] losses {l2}; worst parameter difference vs eager {worst:.2e}")
+    assert worst < 1e-4, worst
+
+
+class _GateChecker:
+    """Every read of an nn.Parameter through module attribute access while an overlapped optimizer update is in flight must
+    happen on a stream that already waits for the chunk holding it (optim.AdamW.attach: module pre-hooks, container
+    declarations, explicit streams.gate calls)."""
+
+    def __enter__(self):
+        from vln_hamt_amd import streams
+        self.bad = []
+        self.orig = orig = torch.nn.Module.__getattr__
+        bad = self.bad
+
+        def patched(mod, name):
+            v = orig(mod, name)
+            if isinstance(v, torch.nn.Parameter):
+                for o in streams.pending_updates:
+                    if not o._ov.check_read(v):
+                        bad.append(f"{type(mod).__name__}.{name}")
+            return v
+        torch.nn.Module.__getattr__ = patched
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.Module.__getattr__ = self.orig
+
+
+@pytest.mark.parametrize("which", ["pretrain", "rollout_no_lang_ca", "rollout_lang_ca"])
+def test_overlapped_update_gates_every_parameter_read(tiny, which):
+    """The container declarations / explicit gates of the model mirrors are complete: with the update of step t running on
+    its own stream, no forward pass of step t+1 reads a parameter before the stream it runs on waits for that parameter's
+    chunk -- and the overlapped run still reproduces the in-stream run."""
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+    store, cfg, sd = tiny
+
+    def run(attach):
+        if which == "pretrain":
+            m = build(cfg, sd, "bf16", train=True)
+            seq = ["sap", "mlm", "sar", "itm", "mrc", "sprel", "mlm"]
+            bs = []
+            for i, t in enumerate(seq):
+                b = make_batch(t, 4, cfg, seed=70 + i, txt_len=20, hist_len=4, ragged=True, device=DEV)
+                if t == "itm":
+                    r = make_itm_rng(b, seed=3)
+                    b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+                bs.append(b)
+            loss_of = lambda b, t: m(b, t, True).mean()
+        else:
+            T = 3
+            m = _tiny_navcmt(no_lang_ca=which == "rollout_no_lang_ca", train=True, p_drop=0.0)
+            seq = ["r"] * 4
+            bs = []
+            for i in range(4):
+                b = make_batch("sap", 4, tiny_cfg(no_lang_ca=True, act_pred_token="ob"), seed=70 + i, txt_len=24, hist_len=T, device=DEV)
+                b["step_ids"] = torch.arange(T, device=DEV)
+                bs.append(b)
+            loss_of = lambda b, t: _rollout_loss(m, b, T)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        o = AdamW([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=1e-3, betas=(0.9, 0.98), eps=1.0)
+        if attach:
+            o.attach(m, chunk_elems=1 << 12)
+        losses = []
+        for b, t in zip(bs, seq):
+            loss = loss_of(b, t)
+            loss.backward()
+            clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+            o.step()
+            o.zero_grad()
+            losses.append(float(loss))
+        o.wait_update()
+        torch.cuda.synchronize()
+        return m, losses
+
+    m1, l1 = run(False)
+    with _GateChecker() as chk:
+        m2, l2 = run(True)
+    assert not chk.bad, sorted(set(chk.bad))
+    assert max(abs(a - c) for a, c in zip(l1, l2)) < 5e-4, (l1, l2)
+    worst = max(float((a - c).abs().max()) for (_, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()))
     assert worst < 1e-4, worst
 
 

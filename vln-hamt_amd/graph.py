@@ -9,6 +9,7 @@ before each replay), lazily cached weight shadows are invalidated before capture
 from __future__ import annotations
 
 import copy
+import os
 import time
 
 import torch
@@ -22,12 +23,24 @@ class GraphedTrainStep:
     norm + AdamW graph -- with the collective launched eagerly between the two replays on the same stream, so RCCL
     never has to be captured."""
 
-    def __init__(self, model, optimizer, max_grad_norm: float = 5.0, grad_sync=None, loss_fn=None):
+    def __init__(self, model, optimizer, max_grad_norm: float = 5.0, grad_sync=None, loss_fn=None, overlap_update=None):
         """`loss_fn(model, batch, task) -> scalar loss` replaces the default `model(batch, task, True).mean()`: e.g. a whole
         finetune rollout (language once, history / visual per step, a loss per step -- agent_cmt.py:248-529) whose ONE
-        backward then sits in the same captured graph (`task` is only a label for such a function)."""
+        backward then sits in the same captured graph (`task` is only a label for such a function).
+
+        `overlap_update` (default off; HAMT_OVERLAP_UPDATE=1 turns it on for a single GPU): the parameter update of step t is
+        the FIRST thing the replay of step t+1 launches, on a stream of its own next to that step's forward pass
+        (optim.AdamW.attach), instead of the last thing of step t.  The parameters then lag the returned loss by one update
+        until `finish()` is called (before evaluating, saving or reading parameters; a capture of a new key does it itself).
+        Measured on MI355X (profiles/r02_timeline_b16_overlap.txt): no gain -- the update saturates HBM, and the small
+        latency-bound kernels of the forward pass running next to it take 3-8x as long (B = 16: 5.89 vs 5.71 ms per step,
+        B = 64: 10.87 vs 10.49), so it stays an option, not the default."""
         self.model, self.opt, self.max_norm = model, optimizer, float(max_grad_norm)
         self.grad_sync = grad_sync
+        if overlap_update is None:
+            overlap_update = grad_sync is None and os.environ.get("HAMT_OVERLAP_UPDATE", "0") == "1"
+        self.lag = bool(overlap_update) and grad_sync is None
+        self._pending_table = None            # host table of the update the next replay (or finish()) applies
         self.loss_fn = loss_fn or (lambda m, b, t: m(b, t, True).mean())
         self._custom_loss = loss_fn is not None
         # with a process group alive, RCCL's watchdog thread polls its events while we capture: only this thread's
@@ -45,6 +58,17 @@ class GraphedTrainStep:
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.opt.materialize()
+        if self.lag and self.opt._ov is None:
+            self.opt.attach(model)
+
+    def finish(self):
+        """Apply the update the last replayed step left pending (overlap_update): call before reading parameters."""
+        if self._pending_table is not None:
+            self.opt.upload_table(self._pending_table)
+            self._pending_table = None
+            self.opt._pending_clip = (self.opt._gnorm, self.max_norm)
+            self.opt.launch_step()
+            self.opt.mark_updated()
 
     def _eager(self, batch, task):
         loss = self.loss_fn(self.model, batch, task)
@@ -91,6 +115,7 @@ class GraphedTrainStep:
     def _capture(self, key, batch, task):
         if not self._custom_loss:
             self._check_capturable(batch, task)
+        self.finish()
         src = batch
         batch = copy.copy(src)                 # the graph's static inputs: replays read THESE tensors (step() refills them)
         for k, v in src.items():
@@ -104,6 +129,7 @@ class GraphedTrainStep:
             loss = self._eager(batch, task).detach()      # .detach(): do not keep this step's autograd graph alive
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        self.opt.wait_update()                 # (host flag only: the warm-up step's update has finished)
         if self.grad_sync is not None:
             # RCCL's watchdog thread polls the events of collectives it has not reaped yet, and an event query from any
             # thread while this process captures aborts it (hipErrorCapturedEvent, in "thread_local" mode too on
@@ -119,9 +145,15 @@ class GraphedTrainStep:
         if overl:
             self.grad_sync.mode = "plan"       # the end-of-backward flush only builds the plan during the capture
         with torch.cuda.graph(g, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
+            if self.lag:                       # the update of the step replayed before this one (device table: which parameters)
+                self.opt.launch_step_overlapped(self.opt._gnorm, self.max_norm)
             loss_c = self.loss_fn(self.model, batch, task)
             loss_c.backward()
-            if self.grad_sync is None:
+            if self.lag:
+                self.opt.wait_update()         # (a loss_fn that never ran the attached model's forward: join the update stream)
+                self.opt.global_grad_sumsq()   # -> opt._gnorm, read by the update at the head of the next replay
+                ops.advance_rng_epoch(dev)
+            elif self.grad_sync is None:
                 self._update(dev)
             else:
                 self.opt._pack_grads()
@@ -177,6 +209,11 @@ class GraphedTrainStep:
             return self._capture(key, batch, task)
         g, loss_c, active, plan, static = ent
         self._refill(static, batch, key)
+        if self.lag:
+            self.opt.upload_table(self._pending_table)        # None: no update pending, the leading update touches nothing
+            self._pending_table = self.opt.host_table(active)   # this step's update (today's learning rates), applied by the next replay
+            g.replay()
+            return loss_c
         self.opt.prepare_step(active)
         g.replay()
         if self.grad_sync is not None:

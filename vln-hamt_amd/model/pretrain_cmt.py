@@ -63,6 +63,7 @@ class ItmPrediction(_MlpHead):                 # pretrain_cmt.py:62-71
 
 class MultiStepNavCMTPreTraining(BertPreTrainedModel):
     """pretrain_cmt.py:73-262."""
+    _hamt_container = True      # (optim.AdamW.attach) forward reads parameters only through self.bert / the heads' __call__
 
     def __init__(self, config):
         super().__init__(config)

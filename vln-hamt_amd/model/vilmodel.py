@@ -181,6 +181,7 @@ class BertLayer(nn.Module):
 
 class BertEncoder(nn.Module):
     """stack of BertLayer (vilmodel.py:204-234)."""
+    _hamt_container = True      # forward reads parameters only through its layers' __call__ (optim.AdamW.attach)
 
     def __init__(self, config):
         super().__init__()
@@ -351,7 +352,7 @@ class LXRTXLayer(nn.Module):
         if XBIDIR and blocks.usable(xa.att.prec, lang_feats) and blocks.usable(xa.att.prec, visn_feats):
             # the shared cross attention of both directions is ONE node on `main`; the streams fork behind it
             lang_x, visn_x = self.cross_att(lang_feats, lang_mask, visn_feats, visn_mask)
-            side.wait_stream(main)
+            streams.fork(main, side)
             for t in (visn_x, getattr(visn_x, "_hamt_bf16", (None,))[0], visn_mask):
                 if t is not None:
                     streams.share(t, side)
@@ -360,14 +361,14 @@ class LXRTXLayer(nn.Module):
                 visn_out = _ffn(self.visn_inter, self.visn_output, visn[0], self.training)
             lang = self.lang_self_att(lang_x, lang_mask)
             lang_out = _ffn(self.lang_inter, self.lang_output, lang[0], self.training)
-            main.wait_stream(side)
+            streams.join(main, side)
             streams.share(visn_out, main)
             return lang_out, visn_out
         # the shared cross-attention is applied on BOTH streams: build its lazily cached bf16 weight images (only used when
         # the optimizer's bf16 arena is not there) on `main` before the fork, not concurrently on whichever stream is first
         for lin in (xa.att.query, xa.att.key, xa.att.value, xa.output.dense):
             ops.weight_operand(lin.weight, xa.att.prec)
-        side.wait_stream(main)
+        streams.fork(main, side)
         for t in (lang_feats, visn_feats, lang_mask, visn_mask):
             streams.share(t, side)                      # inputs produced on `main`, read by the vision-side kernels
         with torch.cuda.stream(side):
@@ -377,13 +378,14 @@ class LXRTXLayer(nn.Module):
         lang = self.visual_attention(lang_feats, visn_feats, ctx_att_mask=visn_mask)
         lang = self.lang_self_att(lang[0] if isinstance(lang, tuple) else lang, lang_mask)
         lang_out = _ffn(self.lang_inter, self.lang_output, lang[0], self.training)
-        main.wait_stream(side)
+        streams.join(main, side)
         streams.share(visn_out, main)                   # produced on `side`, consumed on `main` from here on
         return lang_out, visn_out
 
 
 class LxmertEncoder(nn.Module):
     """text layers, then cross-modal layers over text <-> {history (+) observation} (vilmodel.py:414-478)."""
+    _hamt_container = True
 
     def __init__(self, config):
         super().__init__()
@@ -543,6 +545,7 @@ class HistoryEmbeddings(nn.Module):
 
 class NavPreTrainedModel(BertPreTrainedModel):
     """trunk: text / history / observation embedders + LxmertEncoder (vilmodel.py:578-724)."""
+    _hamt_container = True      # (its one direct parameter read, the token-type row of the observation tokens, is gated explicitly)
 
     def __init__(self, config):
         super().__init__(config)
@@ -574,6 +577,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
             ob = None
             if ob_img_feats is not None:
                 ones = torch.ones(B, dtype=torch.long, device=txt_ids.device)
+                streams.gate(self.embeddings.token_type_embeddings.weight)
                 tt = ops.gather_rows(self.embeddings.token_type_embeddings.weight, ones).view(B, 1, -1)
                 ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)
             return hist, ob
@@ -583,13 +587,13 @@ class NavPreTrainedModel(BertPreTrainedModel):
             # and the text-only layers: the two chains do not meet before the first cross-modal layer
             main = torch.cuda.current_stream()
             side = streams.side_stream(txt_ids.device)
-            side.wait_stream(main)
+            streams.fork(main, side)
             for t in (hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, ob_img_feats, ob_ang_feats, ob_nav_types):
                 streams.share(t, side)
             with torch.cuda.stream(side):
                 hist, ob = vision_side()
             txt = self.encoder.text_layers(self.embeddings(txt_ids), txt_m)
-            main.wait_stream(side)
+            streams.join(main, side)
             streams.share(hist, main)
             streams.share(ob, main)
             return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True)
@@ -649,14 +653,14 @@ class NavPreTrainedModel(BertPreTrainedModel):
         if txt_ids.is_cuda and streams.two_stream_enabled():     # history side next to the text side, as in forward()
             main = torch.cuda.current_stream()
             side = streams.side_stream(dev)
-            side.wait_stream(main)
+            streams.fork(main, side)
             for t in (hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, hist_m, neg_idxs,
                       *(shuffled_pos_ids or [])):
                 streams.share(t, side)
             with torch.cuda.stream(side):
                 vis, vis_m = vision_side(neg_idxs, shuffled_pos_ids)
             txt, txt_m = text_side()
-            main.wait_stream(side)
+            streams.join(main, side)
             streams.share(vis, main)
             streams.share(vis_m, main)
         else:

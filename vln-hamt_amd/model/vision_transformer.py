@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from .. import blocks_preln, ops
+from .. import blocks_preln, ops, streams
 from ..ops import _p, _stream
 
 
@@ -147,6 +147,7 @@ class VisionTransformer(nn.Module):
         nn.init.trunc_normal_(self.cls_token, std=0.02)
 
     def forward_features(self, x):
+        streams.gate(self.cls_token, self.pos_embed, self.norm)                      # (called as a method: no module hook in front)
         x = self.patch_embed(x)                                                      # (B, N, D)
         B, N, D = x.shape
         x = torch.cat([self.cls_token.expand(B, -1, -1), x], 1).view(B * (N + 1), D)  # :337-339

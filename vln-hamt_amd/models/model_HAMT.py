@@ -48,6 +48,8 @@ class HistoryCache:
 
 
 class VLNBertCMT(nn.Module):
+    _hamt_container = True      # (optim.AdamW.attach) reads parameters only through self.vln_bert's __call__
+
     def __init__(self, args):
         super().__init__()
         self.args = args

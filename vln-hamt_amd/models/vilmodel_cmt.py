@@ -14,7 +14,7 @@ import copy
 import torch
 from torch import nn
 
-from .. import blocks, ops
+from .. import blocks, ops, streams
 from ..model import vilmodel as V
 from ..model.pretrain_cmt import _MlpHead
 from ..modeling import HamtPreTrainedModel, precision_of
@@ -155,6 +155,7 @@ class NextActionPrediction(_MlpHead):          # vilmodel_cmt.py:596-607
 
 class NavCMT(BertPreTrainedModel):
     """vilmodel_cmt.py:610-728: `language` (once per episode), `history` (one step), `visual` (one decision)."""
+    _hamt_container = True      # (optim.AdamW.attach) direct parameter reads below are behind streams.gate
 
     def __init__(self, config):
         super().__init__(config)
@@ -183,6 +184,7 @@ class NavCMT(BertPreTrainedModel):
             if cfg.no_lang_ca:      # the text stream is step-invariant: precompute its per-x-layer self-att/FFN outputs
                 outs = [txt]
                 for layer in self.encoder.x_layers:
+                    streams.gate(layer)            # (lang_inter / lang_output / the cross-attention K, V weights are read right here)
                     att = layer.lang_self_att(txt, txt_m)[0]
                     outs.append(V._ffn(layer.lang_inter, layer.lang_output, att, self.training))
                 # ... and, beyond the reference, what every later `visual` call would re-derive from them: the key / value
@@ -207,6 +209,7 @@ class NavCMT(BertPreTrainedModel):
             ob_m = self._extend(ob_masks)
             B = ob_img_feats.size(0)
             ones = torch.ones(B, dtype=torch.long, device=ob_img_feats.device)
+            streams.gate(self.embeddings.token_type_embeddings.weight)
             tt = ops.gather_rows(self.embeddings.token_type_embeddings.weight, ones).view(B, 1, -1)
             ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)
             if self.encoder.r_layers is not None:

@@ -679,6 +679,7 @@ class GatherRowsFn(torch.autograd.Function):
                 # an embedding table that owns a slot in the optimizer's gradient arena (zero at the start of a step): add the rows
                 # there -- no 94 MB zero fill for the 30 522 x 768 word table, no copy into the arena afterwards; published as
                 # `.grad` at the end of the pass (the tied MLM decoder's queued weight gradient then accumulates on top)
+                wgrad.queue(slot.device).current()         # (opens the pass: orders this stream behind an overlapped optimizer update)
                 L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(slot), W, _stream()), "hamt_scatter_add_rows")
                 wgrad.publish_slot_grad(p, slot)
             else:

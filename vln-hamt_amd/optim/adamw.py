@@ -27,6 +27,7 @@ import torch
 from torch.optim import Optimizer
 
 from .. import _lib as L
+from .. import streams
 from ..ops import _p, _stream
 
 ALIGN = 8   # elements: keeps every tensor 32-byte aligned in the fp32 arenas and 16-byte aligned in the bf16 shadow
@@ -38,6 +39,101 @@ def shadow_only(p) -> bool:
     vectors, embedding tables (gathered in fp32; `_hamt_fp32_read`, set by modeling.HamtPreTrainedModel), skinny or odd-width
     matrices that go through the exact-fp32 GEMM -- is read from the fp32 master."""
     return p.dim() == 2 and p.shape[1] % 64 == 0 and p.shape[0] % 8 == 0 and p.shape[0] >= 64 and not getattr(p, "_hamt_fp32_read", False)
+
+
+class _Overlap:
+    """State of AdamW.attach(): the update stream, the chunk list with one event per chunk, the module hooks."""
+
+    def __init__(self, opt, model, chunk_elems):
+        self.opt, self.model = opt, model
+        self.stream = torch.cuda.Stream(device=opt._flat_p.device)
+        # chunk 0: the fp32-read region (biases, LayerNorm, embedding tables: the first kernels of a forward pass read those);
+        # then the GEMM-weight region in arena (= registration = use) order, cut at parameter boundaries
+        n_a, n = opt._n_shadow_only, opt._n
+        ends = [int(e) for e in opt._ends.tolist()]
+        chunks = [(n_a, n - n_a)] if n > n_a else []
+        lo = 0
+        for e in ends:
+            if e > n_a:
+                break
+            if e - lo >= chunk_elems:
+                chunks.append((lo, e - lo))
+                lo = e
+        if lo < n_a:
+            chunks.append((lo, n_a - lo))
+        self.chunks = chunks
+        self.events = [torch.cuda.Event() for _ in chunks]
+        self.chunk_of = {}
+        for p, o in zip(opt._params, opt._offs):
+            for i, (f, c) in enumerate(chunks):
+                if f <= o < f + c:
+                    self.chunk_of[id(p)] = i
+                    break
+        self.pending = False
+        self.waited: dict = {}           # stream id -> highest chunk this stream already waits for
+        self.wait_cache: dict = {}
+        self.handles = [m.register_forward_pre_hook(self._pre) for m in model.modules()]
+        self.handles.append(model.register_forward_hook(self._post))
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+    def _own_chunk(self, mod) -> int:
+        """the chunk a stream has to wait for before `mod`'s forward runs: none for a declared container (its forward reads
+        parameters only through child modules' __call__ or behind an explicit streams.gate), else the last chunk that holds
+        any parameter of its subtree"""
+        if getattr(mod, "_hamt_container", False) or isinstance(mod, (torch.nn.ModuleList, torch.nn.ModuleDict, torch.nn.Sequential)):
+            return -1
+        c = -1
+        for p in mod.parameters():
+            c = max(c, self.chunk_of.get(id(p), -1))
+        return c
+
+    def _wait(self, c: int):
+        if c < 0:
+            return
+        st = torch.cuda.current_stream()
+        if self.waited.get(st.cuda_stream, -1) >= c:
+            return
+        st.wait_event(self.events[c])
+        self.waited[st.cuda_stream] = c
+
+    def inherit(self, dst, src):
+        c = self.waited.get(src.cuda_stream, -1)
+        if c > self.waited.get(dst.cuda_stream, -1):
+            self.waited[dst.cuda_stream] = c
+
+    def gate(self, what):
+        if not self.pending:
+            return
+        c = -1
+        for w in what:
+            if isinstance(w, torch.nn.Module):
+                for p in w.parameters():
+                    c = max(c, self.chunk_of.get(id(p), -1))
+            elif w is not None:
+                c = max(c, self.chunk_of.get(id(w), -1))
+        self._wait(c)
+
+    def _pre(self, mod, args):
+        if not self.pending:
+            return
+        c = self.wait_cache.get(mod)
+        if c is None:
+            c = self.wait_cache[mod] = self._own_chunk(mod)
+        self._wait(c)
+
+    def check_read(self, p):
+        """debugging aid (tests): is a read of parameter `p` on the current stream ordered behind its chunk?"""
+        if not self.pending:
+            return True
+        c = self.chunk_of.get(id(p), -1)
+        return c < 0 or self.waited.get(torch.cuda.current_stream().cuda_stream, -1) >= c
+
+    def _post(self, mod, args, out):
+        self.opt.wait_update()
 
 
 class AdamW(Optimizer):
@@ -55,6 +151,7 @@ class AdamW(Optimizer):
         self._pending_clip = None   # (gnorm_sq device scalar, max_norm)
         self._packed = False
         self._active: Optional[List[bool]] = None
+        self._ov = None             # _Overlap: the update runs on its own stream next to the following forward pass (attach())
 
     # ---------------------------------------------------------------- arenas
     def _build(self):
@@ -127,6 +224,7 @@ class AdamW(Optimizer):
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow arena from the fp32 masters (after loading / broadcasting parameters in place)."""
+        self.wait_update()
         L.check(L.load().hamt_cast_f32_bf16(self._n, _p(self._flat_p), _p(self._flat_p16), _stream()), "hamt_cast_f32_bf16")
         torch.autograd.graph.increment_version(self._flat_p)
         self._sync_shadow_views()
@@ -140,6 +238,7 @@ class AdamW(Optimizer):
     def _pack_grads(self):
         """Copy the autograd-produced gradients into the flat arena (one fused multi-tensor copy)."""
         self.materialize()
+        self.wait_update()
         src, dst, active = [], [], []
         for p, o in zip(self._params, self._offs):
             a = p.grad is not None
@@ -156,13 +255,14 @@ class AdamW(Optimizer):
         """device scalar sum(g^2) over every parameter that has a gradient (slots of the others are zero)."""
         if not self._packed:
             self._pack_grads()
+        self.wait_update()
         L.check(L.load().hamt_sumsq(self._n, _p(self._flat_g), _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq")
         return self._gnorm
 
     # ---------------------------------------------------------------- step = host part + launches
-    def prepare_step(self, active: Optional[List[bool]] = None):
-        """Host side of a step: advance the per-parameter step counts, refresh the device hyper-parameter table
-        (async copy from pinned memory on the current stream).  `active` defaults to "has a gradient now"."""
+    def host_table(self, active: Optional[List[bool]] = None) -> np.ndarray:
+        """Host side of a step: advance the per-parameter step counts and return the [nparams, 4] table {lr, bias-corrected
+        step size, weight decay, active} for `upload_table`.  `active` defaults to "has a gradient now"."""
         self.materialize()
         if active is None:
             active = self._active if self._active is not None else [p.grad is not None for p in self._params]
@@ -174,16 +274,32 @@ class AdamW(Optimizer):
         wd = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float64)[self._gidx_np]
         cb = np.array([bool(g["correct_bias"]) for g in self.param_groups])[self._gidx_np]
         ss = np.where(cb, lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t), lr)
+        h = np.empty((len(self._params), 4), dtype=np.float32)
+        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, act
+        return h
+
+    def upload_table(self, table: Optional[np.ndarray]):
+        """Async copy of a host_table() result (None: nothing active -- the update kernel then touches no parameter) into the
+        device table, from a ring of pinned staging buffers, on the current stream."""
+        self.materialize()
         k = self._hyp_slot
         self._hyp_slot = (k + 1) % len(self._hyp_ring)
         if self._hyp_events[k] is not None:
             self._hyp_events[k].synchronize()   # only blocks when the GPU is >= 4 steps behind the host
         h = self._hyp_ring[k].numpy()           # pinned memory, shared with the tensor
-        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, act
+        if table is None:
+            h[:] = 0.0
+        else:
+            h[:] = table
         self._hyp.copy_(self._hyp_ring[k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._hyp_events[k] = ev
+
+    def prepare_step(self, active: Optional[List[bool]] = None):
+        """Host side of a step: advance the per-parameter step counts, refresh the device hyper-parameter table
+        (async copy from pinned memory on the current stream).  `active` defaults to "has a gradient now"."""
+        self.upload_table(self.host_table(active))
 
     def launch_step(self, zero_grad_arena: bool = True):
         """Device side of a step (static launch sequence; capturable)."""
@@ -196,13 +312,66 @@ class AdamW(Optimizer):
                                           float(max_norm), b1, b2, self.param_groups[0]["eps"], int(zero_grad_arena), _stream()),
                 "hamt_adamw_table")
 
+    # ---------------------------------------------------------------- update next to the following forward pass
+    def attach(self, model: torch.nn.Module, chunk_elems: int = 8 << 20):
+        """Let `step()` (and graph.GraphedTrainStep) run the update on a stream of its own, chunk by chunk in the order the
+        forward pass reads the parameters, while the NEXT forward pass of `model` already runs: the update streams 34 bytes
+        per parameter through HBM and no matrix core, the forward pass is the opposite.  Forward pre-hooks on the modules of
+        `model` make the stream a module runs on wait for the chunk(s) holding the parameters of that module's subtree --
+        except for classes that declare `_hamt_container = True` (their forward reads parameters only through child modules'
+        __call__, or behind an explicit streams.gate(...)): without such declarations the root waits for everything and
+        nothing overlaps, which is slow but never wrong.  A forward hook on `model` itself waits for the whole update, so everything behind a forward pass (backward, gradient norm,
+        the next update) is ordered as before.  Anything else that reads parameters or the arenas directly must call
+        `wait_update()` first (state_dict / load_state_dict / refresh_shadow / gradient packing here do)."""
+        self.materialize()
+        self._ov = _Overlap(self, model, chunk_elems)
+        return self
+
+    def detach(self):
+        if self._ov is not None:
+            self.wait_update()
+            self._ov.remove()
+            self._ov = None
+
+    def wait_update(self):
+        """Order the current stream behind an update still running on the update stream (no-op otherwise)."""
+        ov = self._ov
+        if ov is not None and ov.pending:
+            torch.cuda.current_stream().wait_event(ov.events[-1])
+            ov.pending = False
+            streams.pending_updates.discard(self)
+
+    def launch_step_overlapped(self, gnorm_sq=None, max_norm: float = 0.0):
+        """launch_step on the update stream, one launch + one event per chunk (capturable: a fork of the capturing stream that
+        the forward hooks join again)."""
+        ov = self._ov
+        b1, b2 = self.param_groups[0]["betas"]
+        if gnorm_sq is None and self._pending_clip is not None:
+            gnorm_sq, max_norm = self._pending_clip
+        self._flat_g._hamt_dirty = False
+        lib = L.load()
+        ov.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ov.stream):
+            for i, (f, c) in enumerate(ov.chunks):
+                L.check(lib.hamt_adamw_table_range(f, c, _p(self._flat_p[f:f + c]), _p(self._flat_g[f:f + c]), _p(self._flat_m[f:f + c]),
+                                                   _p(self._flat_v[f:f + c]), _p(self._flat_p16[f:f + c]), _p(self._ends), _p(self._hyp),
+                                                   len(self._params), _p(gnorm_sq), float(max_norm), b1, b2, self.param_groups[0]["eps"], 1,
+                                                   _stream()), "hamt_adamw_table_range")
+                ov.events[i].record(ov.stream)
+        ov.pending = True
+        ov.waited.clear()
+        streams.pending_updates.add(self)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if not self._packed:
             self._pack_grads()
         self.prepare_step()
-        self.launch_step()
+        if self._ov is not None:
+            self.launch_step_overlapped()
+        else:
+            self.launch_step()
         self.mark_updated()
         return loss
 
@@ -220,6 +389,7 @@ class AdamW(Optimizer):
         self._packed = False
         from .. import wgrad
         if self._built and getattr(self._flat_g, "_hamt_dirty", False):
+            self.wait_update()
             # something accumulated into arena slots it assumed zero and no update (which zeroes the arena) has run since
             self._flat_g.zero_()
             self._flat_g._hamt_dirty = False
@@ -233,6 +403,7 @@ class AdamW(Optimizer):
         (copies of the arena slots), plus param_groups -- what ModelSaver writes to train_state_*.pt."""
         if not self._built:
             return super().state_dict()
+        self.wait_update()
         self.state.clear()
         for i, (p, o) in enumerate(zip(self._params, self._offs)):
             if self._steps[i] > 0:
@@ -250,6 +421,7 @@ class AdamW(Optimizer):
         normally follows a model.load_state_dict)."""
         super().load_state_dict(state_dict)
         self.materialize()
+        self.wait_update()
         self._flat_m.zero_()
         self._flat_v.zero_()
         self._steps[:] = 0

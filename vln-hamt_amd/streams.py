@@ -47,3 +47,38 @@ def join_all():
     for s in _side.values():
         if s.device == cur.device:
             cur.wait_stream(s)
+
+
+pending_updates: set = set()     # optimizers (optim.AdamW.attach) whose update may still be running on their update stream
+
+
+def wait_pending_updates():
+    """Order the current stream behind every overlapped optimizer update still in flight (cheap when there is none).  Called by
+    whatever writes into the gradient arena outside a module's forward pass (wgrad.py, the embedding-table scatter-add)."""
+    for o in list(pending_updates):
+        o.wait_update()
+
+
+def fork(main: torch.cuda.Stream, side: torch.cuda.Stream):
+    """`side` continues from where `main` is (side.wait_stream(main)); what `main` already waits for of an overlapped optimizer
+    update, `side` now waits for as well."""
+    side.wait_stream(main)
+    for o in pending_updates:
+        o._ov.inherit(side, main)
+
+
+def join(main: torch.cuda.Stream, side: torch.cuda.Stream):
+    """`main` continues behind everything enqueued on `side` (main.wait_stream(side))."""
+    main.wait_stream(side)
+    for o in pending_updates:
+        o._ov.inherit(main, side)
+
+
+def gate(*what):
+    """The caller is about to read these parameters (or the parameters of these modules) directly, i.e. not through a module's
+    __call__: order the current stream behind the chunk(s) of an overlapped optimizer update that hold them.  Needed only in
+    the forward() of classes that declare `_hamt_container = True` (see optim.AdamW.attach); free when no update is in flight."""
+    if not pending_updates:
+        return
+    for o in list(pending_updates):
+        o._ov.gate(what)

@@ -73,6 +73,8 @@ class WgradQueue:
                               "not finish (exception inside backward?)", RuntimeWarning)
             ps = self.passes[tid] = _Pass()
             torch.autograd.Variable._execution_engine.queue_callback(lambda: self.flush(tid))
+            from . import streams
+            streams.wait_pending_updates()       # (a backward pass not preceded by a forward pass of the attached model)
         return ps
 
     def pending(self) -> int:
@@ -230,6 +232,7 @@ def _flush_pass(ps: _Pass, handler):
     if not items and not lnred and not vecs:
         return
     from . import streams
+    streams.wait_pending_updates()
     streams.join_all()                # operands queued by backward nodes that ran on the second compute stream
     if lnred:                         # every LayerNorm's dgamma / dbeta / bias-gradient partials: one launch
         n = len(lnred)
