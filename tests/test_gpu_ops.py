@@ -141,7 +141,9 @@ def test_gemm_epilogues(prec):
     ("nt", (1280, 768, 3072), "gemm_kg_kernel<32, 2, 4"), ("nn", (1280, 768, 2304), "gemm_kg_kernel<32, 2, 4"),
     ("nt", (1968, 768, 3072), "gemm_kg_kernel<64, 3, 2"), ("nn", (1968, 768, 2304), "gemm_kg_kernel<64, 3, 2"),
     ("nt", (688, 768, 768), "gemm_kg_kernel<32, 2, 4"), ("nt", (100, 130, 1536), "gemm_kg_kernel<32, 2, 4"),
-    ("nn", (1301, 700, 1600), "gemm_kg_kernel<32, 2, 4"), ("nn", (2500, 520, 1664), "gemm_kg_kernel<64, 3, 2")])
+    ("nn", (1301, 700, 1600), "gemm_kg_kernel<32, 2, 4"), ("nn", (2500, 520, 1664), "gemm_kg_kernel<64, 3, 2"),
+    ("nt", (5120, 768, 3072), "gemm_kg_kernel<128, 2, 2"), ("nn", (2752, 768, 2304), "gemm_kg_kernel<128, 2, 2"),
+    ("nn", (4001, 1000, 2368), "gemm_kg_kernel<128, 2, 2")])
 def test_gemm_k_groups(layout, shape, variant):
     """Small grids with a long reduction run as K groups inside one workgroup (gemm_kg_kernel): every k-tile residue class,
     ragged edges, the run-time epilogue (bias, accumulate, bf16 output with an aux multiply, dropout + residual)."""
