@@ -360,7 +360,7 @@ def main():
                                "algorithmic_work_per_launch": dom["work_per_launch"],
                                "how": "dominant kernel of the step = largest per-step total among the kernels of one task-mix cycle; its launches are "
                                       "re-issued (same operands, same epilogues) as a captured hipGraph and timed with HIP events on the launch stream; "
-                                      "work = 2MNK per GEMM launch (34 B per parameter for the AdamW kernel)"}
+                                      "work = 2MNK per GEMM launch (30 B per parameter, + 4 where the gradient slot is zeroed, for the AdamW kernel)"}
             out["kernel_table"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in table[:12]]
             out["roofline_subblock_xattn"] = rp.subblock_xattn(model, args.batch, device)
             out["roofline_probe_xattn"] = time_xattn_probe(args.batch, device)

@@ -328,6 +328,13 @@ int hamt_adamw_table(size_t n, float* p, float* g, float* m, float* v, void* p16
 int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g, float* m, float* v, void* p16,
                            const int* ends, const float* hyp, int nparams, const float* gnorm_sq,
                            float max_norm, float beta1, float beta2, float eps, int zero_grad, void* stream);
+/* active == 2 in hyp: update like 1 but leave the gradient slot as it is (zero_grad then only applies to the active == 1
+ * parameters): for slots whose producer overwrites them (the grouped weight-gradient launch stores, it does not accumulate).
+ * hamt_sumsq_table: sum(g^2) over the ACTIVE parameters of the arena elements [first, first + n) (g points at element `first`;
+ * same `ends` / `hyp` tables): the global-norm reduction that goes with it -- slots of inactive parameters are not read,
+ * whatever they hold (torch clip_grad_norm_ over the parameters that have a gradient, main_r2r.py:271-273).  ws: 1024 floats. */
+int hamt_sumsq_table(size_t first, size_t n, const float* g, const int* ends, const float* hyp, int nparams,
+                     float* out, int accumulate, float* ws, void* stream);
 /* g *= min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  -- standalone clip for torch-optimiser users */
 int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream);
 

@@ -11,7 +11,7 @@ kernel and its achieved rate without a profiler attached:
   * the optimizer's update kernel is timed on the real arenas.
 
 Per-step time of a kernel = sum over tasks of (task frequency in the 5:1:1:1:2:2 mix) x (time of its launches in that task's
-step).  Algorithmic work: 2 M N K per GEMM launch; 34 bytes per parameter for the AdamW table kernel (SURVEY 8d / DESIGN 4).
+step).  Algorithmic work: 2 M N K per GEMM launch; 30 bytes per parameter (+ 4 where the gradient slot is zeroed) for the AdamW table kernel (SURVEY 8d / DESIGN 4).
 """
 from __future__ import annotations
 
@@ -146,7 +146,7 @@ def kernel_table(model, opt, cycle, device):
     opt._packed = True
     opt.prepare_step([True] * len(opt._params))
     dt = _graph_time(lambda: opt.launch_step(), st)
-    nbytes = 34.0 * opt._n
+    nbytes = opt.update_bytes()       # 30 B per element (+ 4 where the gradient slot is zeroed too)
     rows.append({"kernel": "adamw_table_kernel<4, true, false>", "bound": "hbm", "per_step_ms": round(dt * 1e3, 3), "launches_per_step": 1.0,
                  "avg_launch_us": round(dt * 1e6, 2), "achieved": round(nbytes / dt / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
                  "frac": round(nbytes / dt / 1e9 / PEAK_HBM_GBS, 4), "work_per_launch": nbytes})

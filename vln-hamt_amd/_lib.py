@@ -103,6 +103,7 @@ SIGNATURES = {
     "hamt_a2c_fwd": [i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp],
     "hamt_a2c_bwd": [i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "hamt_sumsq": [sz, vp, vp, i32, vp, vp],
+    "hamt_sumsq_table": [sz, sz, vp, vp, vp, i32, vp, i32, vp, vp],
     "hamt_adamw_flat": [sz, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table": [sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table_range": [sz, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(size_t n, float* __restrict_
 }
 // One launch for the whole arena: per-parameter hyper-parameters come from a device table
 // (ends[i] = exclusive end offset of parameter i, hyp[i] = {lr, step_size, weight_decay, active}); parameters with
-// active == 0 (grad is None this step -- the reference's `continue`, adamw.py:70-71) are left untouched.
+// active == 0 (grad is None this step -- the reference's `continue`, adamw.py:70-71) are left untouched.  active == 2: updated
+// like 1, but the gradient slot is NOT zeroed (its producer overwrites it: the grouped weight-gradient launch stores, it does
+// not accumulate) -- 30 instead of 34 bytes per parameter; hamt_sumsq_table skips inactive slots, whatever they hold.
 // Offsets are multiples of 8, so a 4-element chunk never straddles two parameters.
 template <int U, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __res
     const size_t pend = pi < nparams - 1 ? min(hi, ((size_t)ends[pi] >> 2) - first4) : hi;   // offsets are multiples of 8 elements
     const float4 h = hyp[pi];
     if (h.w != 0.f) {
+      const bool zg = zero_grad && h.w == 1.f;
       for (size_t i = seg + threadIdx.x; i < pend; i += 256 * U) {
         f4 P[U], G[U], M[U], V[U];
 #pragma unroll
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __res
               __builtin_nontemporal_store(P[u], (f4*)p + j);
               __builtin_nontemporal_store(M[u], (f4*)m + j);
               __builtin_nontemporal_store(V[u], (f4*)v + j);
-              if (zero_grad) __builtin_nontemporal_store((f4){0.f, 0.f, 0.f, 0.f}, (f4*)g + j);
+              if (zg) __builtin_nontemporal_store((f4){0.f, 0.f, 0.f, 0.f}, (f4*)g + j);
             } else {
               ((f4*)p)[j] = P[u]; ((f4*)m)[j] = M[u]; ((f4*)v)[j] = V[u];
-              if (zero_grad) ((f4*)g)[j] = (f4){0.f, 0.f, 0.f, 0.f};
+              if (zg) ((f4*)g)[j] = (f4){0.f, 0.f, 0.f, 0.f};
             }
             if (p16) ((uint2*)p16)[j] = make_uint2(pack_bf2(P[u][0], P[u][1]), pack_bf2(P[u][2], P[u][3]));
           }
@@ -130,6 +133,42 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(size_t n, float* __res
     }
     seg = pend;
   }
+}
+// sum(g^2) over the ACTIVE parameters of an arena range (same segment walk as adamw_table_kernel): slots of inactive
+// parameters are not read (they may hold a stale gradient, see active == 2 above).  One partial per block, summed in block
+// order by sumsq_final_kernel: deterministic.
+__global__ __launch_bounds__(256) void sumsq_table_partial_kernel(size_t n, const float* __restrict__ g, const int* __restrict__ ends,
+                                                                  const float4* __restrict__ hyp, int nparams, size_t first4,
+                                                                  float* __restrict__ ws) {
+  const size_t n4 = n >> 2;
+  const size_t per_block = (n4 + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per_block, hi = min(n4, lo + per_block);
+  int pi = 0;
+  {
+    int a = 0, b = nparams - 1;
+    const long e0 = (long)(lo + first4) * 4;
+    while (a < b) { const int mid = (a + b) >> 1; if ((long)ends[mid] > e0) b = mid; else a = mid + 1; }
+    pi = a;
+  }
+  float s = 0.f;
+  for (size_t seg = lo; seg < hi; ++pi) {
+    const size_t pend = pi < nparams - 1 ? min(hi, ((size_t)ends[pi] >> 2) - first4) : hi;
+    if (hyp[pi].w != 0.f) {
+      for (size_t i = seg + threadIdx.x; i < pend; i += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + (size_t)u * 256 < pend ? ((const float4*)g)[i + (size_t)u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+      }
+    }
+    seg = pend;
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void clip_scale_kernel(size_t n, float* __restrict__ g, const float* __restrict__ gnorm_sq, float max_norm) {
   const float coef = clip_coef(gnorm_sq, max_norm);
@@ -146,6 +185,18 @@ extern "C" int hamt_sumsq(size_t n, const float* g, float* out, int accumulate, 
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ws);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
   HAMT_CHECK_LAUNCH("hamt_sumsq");
+  return HAMT_OK;
+}
+extern "C" int hamt_sumsq_table(size_t first, size_t n, const float* g, const int* ends, const float* hyp, int nparams, float* out,
+                               int accumulate, float* ws, void* stream) {
+  HAMT_CHECK_ARG(g && out && ws && ends && hyp && nparams > 0 && n % 4 == 0 && first % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)hyp % 16) == 0,
+                 "hamt_sumsq_table: bad argument (ws needs 1024 floats, g / hyp 16-byte aligned, first and n multiples of 4)");
+  hipStream_t s = as_stream(stream);
+  size_t b = (n / 4 + 1023) / 1024;
+  int nb = (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  hipLaunchKernelGGL(sumsq_table_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ends, (const float4*)hyp, nparams, first / 4, ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
+  HAMT_CHECK_LAUNCH("hamt_sumsq_table");
   return HAMT_OK;
 }
 extern "C" int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v, void* p16, const float* hyper,

@@ -674,7 +674,7 @@ class GatherRowsFn(torch.autograd.Function):
             p = ctx.table_param
             slot = getattr(p, "_hamt_grad_slot", None) if p is not None else None
             from . import wgrad
-            if (slot is not None and wgrad.ENABLED and slot.shape == p.shape and slot.is_contiguous()
+            if (slot is not None and wgrad.ENABLED and slot.shape == p.shape and slot.is_contiguous() and getattr(p, "_hamt_slot_zeroed", False)
                     and (p.grad is None or p.grad.data_ptr() == slot.data_ptr()) and torch._C._current_graph_task_id() >= 0):
                 # an embedding table that owns a slot in the optimizer's gradient arena (zero at the start of a step): add the rows
                 # there -- no 94 MB zero fill for the 30 522 x 768 word table, no copy into the arena afterwards; published as

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 from typing import Iterable, List, Optional
@@ -30,6 +31,7 @@ from .. import _lib as L
 from .. import streams
 from ..ops import _p, _stream
 
+KEEP_GRAD = os.environ.get("HAMT_ZERO_ALL_GRADS") is None      # ablation: zero every gradient slot in the update (34 B / parameter)
 ALIGN = 8   # elements: keeps every tensor 32-byte aligned in the fp32 arenas and 16-byte aligned in the bf16 shadow
 REGION_ALIGN = 512   # elements: region / arena ends (8-element granules x up to 64 ranks)
 
@@ -152,6 +154,8 @@ class AdamW(Optimizer):
         self._packed = False
         self._active: Optional[List[bool]] = None
         self._ov = None             # _Overlap: the update runs on its own stream next to the following forward pass (attach())
+        self._table_ready = False   # the device table already describes the step whose gradients are packed now
+        self._table_lrs = None
 
     # ---------------------------------------------------------------- arenas
     def _build(self):
@@ -196,6 +200,9 @@ class AdamW(Optimizer):
         self._flat_p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
         L.check(L.load().hamt_cast_f32_bf16(n, _p(self._flat_p), _p(self._flat_p16), _stream()), "hamt_cast_f32_bf16")
         self._steps = np.zeros(len(ps), dtype=np.int64)
+        # GEMM weights of the bf16 path: their gradient slots are STORED by the grouped weight-gradient launch (or copied over by
+        # _pack_grads), never accumulated into from zero -> the update leaves them alone instead of zeroing 4 bytes per parameter
+        self._keep = np.array([1.0 + float(KEEP_GRAD and shadow_only(p)) for p in ps], dtype=np.float32)
         self._gidx_np = np.asarray(gidx, dtype=np.int64)
         ends = offs[1:] + [n]          # (alignment gaps count as the tail of the parameter in front of them: zeros that stay zeros)
         self._ends = torch.tensor(ends, dtype=torch.int32, device=dev)
@@ -212,8 +219,9 @@ class AdamW(Optimizer):
 
     def _publish_grad_slots(self):
         """Let the grouped weight-gradient launch (wgrad.py) write straight into the flat gradient arena."""
-        for p, o in zip(self._params, self._offs):
+        for p, o, k in zip(self._params, self._offs, self._keep):
             p._hamt_grad_slot = self._flat_g[o:o + p.numel()].view(p.shape)
+            p._hamt_slot_zeroed = bool(k == 1.0)      # producers that ADD into the slot from zero (ops.GatherRowsFn, LayerNorm partials) need this
 
     def _sync_shadow_views(self):
         """Publish the bf16 shadow of every >=2-D parameter as the GEMM weight operand (see ops.weight_operand)."""
@@ -221,6 +229,13 @@ class AdamW(Optimizer):
         for p, o in zip(self._params, self._offs):
             if p.dim() >= 2:
                 p._hamt_arena16 = (self._flat_p16[o:o + p.numel()].view(p.shape), self._flat_p, ver, p._version)
+
+    def update_bytes(self) -> float:
+        """algorithmic HBM bytes of one update of every parameter: read p, g, m, v + write p, m, v + bf16 shadow = 30 per element,
+        + 4 where the gradient slot is zeroed as well"""
+        self.materialize()
+        sizes = np.diff(np.concatenate([[0], self._ends.cpu().numpy()])).astype(np.float64)
+        return float((sizes * np.where(self._keep == 2.0, 30.0, 34.0)).sum())
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow arena from the fp32 masters (after loading / broadcasting parameters in place)."""
@@ -250,24 +265,33 @@ class AdamW(Optimizer):
             torch._foreach_copy_(dst, src)
         self._active = active
         self._packed = True
+        self._table_ready = False
 
     def global_grad_sumsq(self) -> torch.Tensor:
-        """device scalar sum(g^2) over every parameter that has a gradient (slots of the others are zero)."""
+        """device scalar sum(g^2) over every parameter that has a gradient (the active rows of the device table)."""
         if not self._packed:
             self._pack_grads()
         self.wait_update()
-        L.check(L.load().hamt_sumsq(self._n, _p(self._flat_g), _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq")
+        if self._ov is not None:
+            L.check(L.load().hamt_sumsq(self._n, _p(self._flat_g), _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq")
+            return self._gnorm
+        if not torch.cuda.is_current_stream_capturing():
+            self._ensure_table()            # (a captured step: the caller refreshes the table before every replay)
+        L.check(L.load().hamt_sumsq_table(0, self._n, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
+                                          _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
         return self._gnorm
 
     # ---------------------------------------------------------------- step = host part + launches
-    def host_table(self, active: Optional[List[bool]] = None) -> np.ndarray:
-        """Host side of a step: advance the per-parameter step counts and return the [nparams, 4] table {lr, bias-corrected
-        step size, weight decay, active} for `upload_table`.  `active` defaults to "has a gradient now"."""
+    def host_table(self, active: Optional[List[bool]] = None, advance: bool = True) -> np.ndarray:
+        """Host side of a step: advance the per-parameter step counts (unless `advance` is False: the table of the step that was
+        already counted, e.g. rebuilt for new learning rates) and return the [nparams, 4] table {lr, bias-corrected step size,
+        weight decay, active (2: leave the gradient slot unzeroed)} for `upload_table`.  `active` defaults to "has a gradient now"."""
         self.materialize()
         if active is None:
             active = self._active if self._active is not None else [p.grad is not None for p in self._params]
         act = np.asarray(active, dtype=bool)
-        self._steps[act] += 1
+        if advance:
+            self._steps[act] += 1
         t = np.maximum(self._steps, 1).astype(np.float64)
         b1, b2 = self.param_groups[0]["betas"]
         lr = np.array([g["lr"] for g in self.param_groups], dtype=np.float64)[self._gidx_np]
@@ -275,7 +299,8 @@ class AdamW(Optimizer):
         cb = np.array([bool(g["correct_bias"]) for g in self.param_groups])[self._gidx_np]
         ss = np.where(cb, lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t), lr)
         h = np.empty((len(self._params), 4), dtype=np.float32)
-        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, act
+        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, act * self._keep
+        self._table_active = act
         return h
 
     def upload_table(self, table: Optional[np.ndarray]):
@@ -300,6 +325,18 @@ class AdamW(Optimizer):
         """Host side of a step: advance the per-parameter step counts, refresh the device hyper-parameter table
         (async copy from pinned memory on the current stream).  `active` defaults to "has a gradient now"."""
         self.upload_table(self.host_table(active))
+        self._table_ready = True
+        self._table_lrs = [g["lr"] for g in self.param_groups]
+
+    def _ensure_table(self):
+        """The eager loop is clip_grad_norm_ -> step(): the norm already needs the table (which parameters are active), the
+        update needs it too -- built once per step, rebuilt (without counting the step again) if the learning rates changed
+        in between."""
+        if not self._table_ready:
+            self.prepare_step()
+        elif self._table_lrs != [g["lr"] for g in self.param_groups]:
+            self.upload_table(self.host_table(self._table_active, advance=False))
+            self._table_lrs = [g["lr"] for g in self.param_groups]
 
     def launch_step(self, zero_grad_arena: bool = True):
         """Device side of a step (static launch sequence; capturable)."""
@@ -325,6 +362,10 @@ class AdamW(Optimizer):
         `wait_update()` first (state_dict / load_state_dict / refresh_shadow / gradient packing here do)."""
         self.materialize()
         self._ov = _Overlap(self, model, chunk_elems)
+        # (graph.GraphedTrainStep replays the update of step t at the head of step t+1: the device table then describes the
+        # PREVIOUS step while this step's norm is reduced -> zero every slot and reduce the whole arena, as before)
+        self._keep[:] = 1.0
+        self._publish_grad_slots()
         return self
 
     def detach(self):
@@ -367,7 +408,7 @@ class AdamW(Optimizer):
         loss = closure() if closure is not None else None
         if not self._packed:
             self._pack_grads()
-        self.prepare_step()
+        self._ensure_table()
         if self._ov is not None:
             self.launch_step_overlapped()
         else:
@@ -383,6 +424,7 @@ class AdamW(Optimizer):
         self._pending_clip = None
         self._packed = False
         self._active = None
+        self._table_ready = False
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)

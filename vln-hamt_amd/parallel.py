@@ -434,7 +434,8 @@ class ShardedGradSync(OverlappedGradSync):
         o, lib = self.opt, L.load()
         segs = self.owned()
         for i, (f, c) in enumerate(segs):
-            L.check(lib.hamt_sumsq(c, _p(o._flat_g[f:f + c]), _p(self._gsq), int(i > 0), _p(o._ws), _stream()), "hamt_sumsq")
+            L.check(lib.hamt_sumsq_table(f, c, _p(o._flat_g[f:f + c]), _p(o._ends), _p(o._hyp), len(o._params), _p(self._gsq), int(i > 0),
+                                         _p(o._ws), _stream()), "hamt_sumsq_table")      # (active parameters only: see optim.AdamW._keep)
         if dist.is_initialized() and not DRY[0]:
             dist.all_reduce(self._gsq, op=dist.ReduceOp.SUM)          # 4 bytes: the global squared norm
         b1, b2 = o.param_groups[0]["betas"]

@@ -256,7 +256,8 @@ def _flush_pass(ps: _Pass, handler):
                 slot = getattr(p, "_hamt_grad_slot", None)
                 # (at most two contributions per slot: a two-term fp32 sum does not depend on the order the atomics land in;
                 # a parameter used more often -- every step of a finetune rollout -- keeps the ordered sum below)
-                if slot is not None and slot.numel() == H and uses[id(p)] <= 2 and (p.grad is None or p.grad.data_ptr() == slot.data_ptr()):
+                if (slot is not None and slot.numel() == H and uses[id(p)] <= 2 and getattr(p, "_hamt_slot_zeroed", False)
+                        and (p.grad is None or p.grad.data_ptr() == slot.data_ptr())):
                     # straight into the parameter's (zero-initialised) gradient-arena slot: a parameter shared by several LayerNorm
                     # calls (the cross-attention block runs twice per x-layer) needs no separate accumulation, and nothing to pack
                     ptrs[j] = slot.data_ptr()
