@@ -184,19 +184,24 @@ typedef struct {
   float eps, p_pre, p_post;
   uint32_t call_id;
   int Mpad16; /* rows of the optional bf16 images (y16 / dx16); rows [M, Mpad16) are written as zeros (0: no padding) */
+  int io16;   /* HAMT_LN_X_BF16: `x` is bf16 (the dense layer in front wrote bf16, as a linear does under autocast);
+               * HAMT_LN_Z_BF16: the saved pre-LN sum `z` is stored / read as bf16 (backward re-normalises it with the exact
+               * fp32 mean / rstd).  0: both fp32. */
 } hamt_ln_desc;
-int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
-                const float* beta, float* z, float* y, void* y16, float* mean, float* rstd,
+#define HAMT_LN_X_BF16 1
+#define HAMT_LN_Z_BF16 2
+int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* residual, const float* gamma,
+                const float* beta, void* z, float* y, void* y16, float* mean, float* rstd,
                 const uint64_t* rng, void* stream);
 /* dz = d(pre-LN sum) (also the residual gradient); dx = dropout_pre-masked dz (may be NULL); dx16 (optional) = the same
  * as bf16 [Mpad16, H] -- the operand of the dgrad/wgrad GEMMs of the dense layer that produced x; dxsum (optional) +=
  * column sums of dx = that layer's bias gradient; dgamma/dbeta/dxsum are STORED (overwritten).  ws: >= 3*256*H floats. */
-int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                 const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                 float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);
 /* pre-LN blocks (x + f(LN(x)), vision_transformer.py:196-197): dz = LayerNorm-backward(dy) + add, where `add` is the
  * gradient that reaches x through the residual path -- one pass instead of a LayerNorm backward and an add. */
-int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean, const float* rstd,
+int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean, const float* rstd,
                     const float* gamma, const float* add, float* dz, float* dgamma, float* dbeta, float* ws,
                     void* stream);
 /* The second half of hamt_ln_bwd / hamt_ln_bwd_add on its own: sums the per-block partials a call with

@@ -432,6 +432,31 @@ def test_ln_fwd_bwd(M, H, res):
     close(lng.bias.grad, lnd.bias.grad, 5e-5, "ln dbeta")
 
 
+@pytest.mark.parametrize("M,H", [(130, 768), (64, 128), (5, 512)])
+def test_ln_bf16_dense_input_and_bf16_saved_sum(M, H):
+    """hamt_ln_desc.io16: a bf16 dense output as `x` gives exactly what the same values give in fp32 (the kernel widens them);
+    the saved pre-LN sum kept in bf16 changes the backward by its rounding only (it is re-normalised with the exact fp32 mean /
+    rstd): bounded against the fp32-saved backward."""
+    ops = _ops()
+    x16 = rnd(M, H, seed=1).to(DEV).to(torch.bfloat16)
+    r = rnd(M, H, seed=2).to(DEV)
+    g, b = (1.0 + 0.1 * rnd(H, seed=3)).to(DEV), (0.1 * rnd(H, seed=4)).to(DEV)
+    ya, ya16, za, mean_a, rstd_a, _ = ops._ln_fwd(x16, r, g, b, 1e-12, 0.0, 0.0, True)
+    yb, yb16, zb, mean_b, rstd_b, _ = ops._ln_fwd(x16.float(), r, g, b, 1e-12, 0.0, 0.0, True)
+    assert za.dtype == torch.bfloat16 and zb.dtype == torch.float32
+    assert torch.equal(ya, yb) and torch.equal(ya16[:M], yb16[:M]) and torch.equal(mean_a, mean_b) and torch.equal(rstd_a, rstd_b)
+    assert torch.equal(za, zb.to(torch.bfloat16))
+    dy = rnd(M, H, seed=5).to(DEV)
+    dza, _, dxa16, dga, dba, _ = ops._ln_bwd(dy, za, mean_a, rstd_a, g, 1e-12, 0.0, 0.0, 0, False, True, False)
+    dzb, _, dxb16, dgb, dbb, _ = ops._ln_bwd(dy, zb, mean_b, rstd_b, g, 1e-12, 0.0, 0.0, 0, False, True, False)
+    assert torch.equal(dba, dbb)                                       # dbeta does not involve z
+    scale = float(dzb.abs().max())
+    assert float((dza - dzb).abs().max()) < 2e-2 * scale               # |z| rstd 2^-9 ~ 1e-2 of a unit-variance x_hat at the tails
+    assert float((dga - dgb).abs().max()) < 2e-2 * float(dgb.abs().max())
+    cos = float((dza * dzb).sum() / (dza.norm() * dzb.norm()))
+    assert cos > 0.9999, cos
+
+
 def test_ln_dropout_pre_post():
     ops = _ops()
     M, H, p = 512, 768, 0.1

@@ -62,8 +62,8 @@ def test_graph_step_trains_on_the_batch_it_is_given(tiny):
     gs.finish()
     torch.cuda.synchronize()
     assert len(gs.graphs) == 1
-    assert max(abs(a - b) for a, b in zip(l1, l2)) < 1e-4, (l1, l2)
-    assert len({round(x, 5) for x in l2}) == 4, l2                  # the four batches really differ
+    assert max(abs(a - b) for a, b in zip(l1, l2)) < 5e-4, (l1, l2)      # (bf16 operands one ulp apart move a loss of ~1.7 by ~1e-4)
+    assert len({round(x, 3) for x in l2}) == 4, l2                  # the four batches really differ
     w = _worst(m1, m2)
     assert w < 2e-5, w
     # the captured step's own inputs can be filled by the caller: nothing to copy then

@@ -40,8 +40,11 @@ class AttnDesc(C.Structure):
                 ("call_id", u32), ("prec", i32)]
 
 
+LN_X_BF16, LN_Z_BF16 = 1, 2      # hamt_ln_desc.io16
+
+
 class LnDesc(C.Structure):
-    _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32), ("Mpad16", i32)]
+    _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32), ("Mpad16", i32), ("io16", i32)]
 
 
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)

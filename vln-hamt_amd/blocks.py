@@ -35,6 +35,11 @@ NO_PACKED = os.environ.get("HAMT_NO_PACKED") is not None      # ablation switche
 NO_SHADOW = os.environ.get("HAMT_NO_SHADOW") is not None
 
 
+# dtype of the dense outputs that feed a LayerNorm (attention output projection, second FFN layer): bf16 like every other dense
+# output of the bf16 path; HAMT_DENSE_OUT_F32=1 keeps them in fp32 (ablation: +4 bytes per element through GEMM epilogue + LayerNorm)
+O_DTYPE = torch.float32 if os.environ.get("HAMT_DENSE_OUT_F32") == "1" else torch.bfloat16
+
+
 def _zeros_or_empty(rows_total, rows_valid, cols, device, dtype=torch.bfloat16):
     """buffer whose rows >= rows_valid must read as finite zeros (reduction padding of the k-strided GEMM operands)"""
     t = torch.empty(rows_total, cols, dtype=dtype, device=device)
@@ -163,7 +168,7 @@ class SelfAttnBlockFn(torch.autograd.Function):
         q, k, v = qkv16[:, :H], qkv16[:, H:2 * H], qkv16[:, 2 * H:]
         L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(lse), _p(rng), _stream()),
                 "hamt_attn_small_fwd")
-        o = torch.empty(M, H, dtype=torch.float32, device=dev)
+        o = torch.empty(M, H, dtype=O_DTYPE, device=dev)      # bf16: what a linear returns under autocast (ops._ln_fwd reads it as such)
         gemm(ctx16[:M], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
@@ -249,7 +254,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         d = _attn_desc(B, heads, Sq, Sk, H, H, 2 * H, 2 * H, p_attn, cid)
         L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(lse),
                                              _p(rng_state(dev)), _stream()), "hamt_attn_small_fwd")
-        o = torch.empty(Mq, H, dtype=torch.float32, device=dev)
+        o = torch.empty(Mq, H, dtype=O_DTYPE, device=dev)
         gemm(ctx16[:Mq], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma)
@@ -325,7 +330,7 @@ class XBidirBlockFn(torch.autograd.Function):
         dv_ = _attn_desc(B, heads, Sv, Sl, H, 3 * H, 3 * H, 3 * H, p_attn, cid_v)      # vis queries over lang keys / values
         L.check(lib.hamt_attn_small_fwd(C.byref(dv_), _p(qkv_v[:, :H]), _p(qkv_l[:, H:2 * H]), _p(qkv_l[:, 2 * H:]), _p(ml2), _p(ctx16[Mlp:]),
                                         _p(lse_v), _p(rng), _stream()), "hamt_attn_small_fwd")
-        o = torch.empty(Mlp + Mvp, H, dtype=torch.float32, device=dev)
+        o = torch.empty(Mlp + Mvp, H, dtype=O_DTYPE, device=dev)
         gemm(ctx16, weight_operand(wo, "bf16"), o, bias=bo.detach())
         yl, yl16, zl, mean_l, rstd_l, cln_l = _ln_fwd(o[:Ml], xl2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         yv, yv16, zv, mean_v, rstd_v, cln_v = _ln_fwd(o[Mlp:Mlp + Mv], xv2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
@@ -422,7 +427,7 @@ class FfnBlockFn(torch.autograd.Function):
         g16 = _zeros_or_empty(Mp, M, I, dev)
         pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(W1 x + b1), from the same erf/exp as gelu
         gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre)
-        o = torch.empty(M, H, dtype=torch.float32, device=dev)
+        o = torch.empty(M, H, dtype=O_DTYPE, device=dev)      # bf16: what a linear returns under autocast (ops._ln_fwd reads it as such)
         gemm(g16[:M], weight_operand(w2, "bf16"), o, bias=b2.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma)

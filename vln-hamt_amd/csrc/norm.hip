@@ -21,9 +21,9 @@ __device__ __forceinline__ void ln_keep4(RngKey k, int row, int c, float p, floa
 constexpr uint32_t POST_SALT = 0x5bd1e995u;
 
 template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const void* __restrict__ xv,
                                                      const float* __restrict__ res, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ z,
+                                                     const float* __restrict__ beta, void* __restrict__ zv,
                                                      float* __restrict__ y, bf16_t* __restrict__ y16,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                      const uint64_t* __restrict__ rng) {
@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
       const size_t o = (size_t)row * H + c;
-      float4 a = *(const float4*)(x + o);
+      float4 a;
+      if (d.io16 & HAMT_LN_X_BF16) {      // the dense layer in front wrote bf16 (what autocast does with a linear's output)
+        const uint2 u = *(const uint2*)((const bf16_t*)xv + o);
+        a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+      } else a = *(const float4*)((const float*)xv + o);
       if (d.p_pre > 0.f) {
         float f_[4]; ln_keep4(kpre, row, c, d.p_pre, ik_pre, f_);
         a.x *= f_[0]; a.y *= f_[1]; a.z *= f_[2]; a.w *= f_[3];
@@ -70,7 +74,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
       const size_t o = (size_t)row * H + c;
-      if (z) *(float4*)(z + o) = v[i];
+      if (zv) {
+        if (d.io16 & HAMT_LN_Z_BF16) *(uint2*)((bf16_t*)zv + o) = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
+        else *(float4*)((float*)zv + o) = v[i];
+      }
       const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
       float4 r;
       r.x = (v[i].x - mean) * rstd * g.x + b.x; r.y = (v[i].y - mean) * rstd * g.y + b.y;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const float
 
 template <int NV, int NWV>
 __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(hamt_ln_desc d, const float* __restrict__ dy,
-                                                     const float* __restrict__ z, const float* __restrict__ mean_i,
+                                                     const void* __restrict__ zv, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
                                                      float* __restrict__ dz, float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                      float* __restrict__ ws, const uint64_t* __restrict__ rng,
@@ -123,7 +130,11 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(hamt_ln_desc d, const 
           float f_[4]; ln_keep4(kpost, row, c, d.p_post, ik_post, f_);
           a.x *= f_[0]; a.y *= f_[1]; a.z *= f_[2]; a.w *= f_[3];
         }
-        const float4 zz = *(const float4*)(z + o);
+        float4 zz;
+        if (d.io16 & HAMT_LN_Z_BF16) {
+          const uint2 u = *(const uint2*)((const bf16_t*)zv + o);
+          zz = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        } else zz = *(const float4*)((const float*)zv + o);
         float4 h;
         h.x = (zz.x - mean) * rstd; h.y = (zz.y - mean) * rstd; h.z = (zz.z - mean) * rstd; h.w = (zz.w - mean) * rstd;
         dg[i].x += a.x * h.x; dg[i].y += a.y * h.y; dg[i].z += a.z * h.z; dg[i].w += a.w * h.w;
@@ -296,8 +307,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_grouped_kernel(const LnRedE
 
 }  // namespace
 
-extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const float* x, const float* residual, const float* gamma,
-                           const float* beta, float* z, float* y, void* y16, float* mean, float* rstd,
+extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* residual, const float* gamma,
+                           const float* beta, void* z, float* y, void* y16, float* mean, float* rstd,
                            const uint64_t* rng, void* stream) {
   HAMT_CHECK_ARG(d && x && gamma && beta && (y || y16) && mean && rstd, "hamt_ln_fwd: null pointer");
   HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_fwd: H=%d unsupported (need H%%4==0, H<=1024)", d->H);
@@ -330,7 +341,7 @@ static void ln_bwd_reduce_launch(int nb, int H, const float* ws, float* dgamma, 
   else hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 63) / 64), dim3(1024), 0, s, nb, H, ws, dgamma, dbeta, dxsum);
 }
 
-static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                        const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                        float* dbeta, float* dxsum, float* ws, const uint64_t* rng, const float* add, void* stream) {
   HAMT_CHECK_ARG(d && dy && z && mean && rstd && gamma && dz && ws, "hamt_ln_bwd: null pointer");
@@ -352,13 +363,13 @@ static int ln_bwd_impl(const hamt_ln_desc* d, const float* dy, const float* z, c
   return HAMT_OK;
 }
 
-extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+extern "C" int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                            const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                            float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream) {
   return ln_bwd_impl(d, dy, z, mean, rstd, gamma, dz, dx, dx16, dgamma, dbeta, dxsum, ws, rng, nullptr, stream);
 }
 
-extern "C" int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const float* z, const float* mean,
+extern "C" int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                                const float* rstd, const float* gamma, const float* add, float* dz, float* dgamma,
                                float* dbeta, float* ws, void* stream) {
   HAMT_CHECK_ARG(add && d && !(d->p_pre > 0.f) && !(d->p_post > 0.f), "hamt_ln_bwd_add: needs `add`, and no dropout inside the LayerNorm");
