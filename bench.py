@@ -330,6 +330,9 @@ def main():
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
             "exposed_comm_ms_per_step": exposed_comm_ms,
+            # the timed steps trained a real model: every master parameter and both moments are finite afterwards (a NaN anywhere
+            # spreads within a few steps; NaN-filled operands also run at other clocks than real data, see DESIGN 4 on DVFS)
+            "state_finite_after_timed_region": bool(torch.isfinite(opt._flat_p).all() and torch.isfinite(opt._flat_m).all() and torch.isfinite(opt._flat_v).all()),
         }
         # the other two per-GPU batches SURVEY 8d names next to the headline one -- 16 is the reference's own (pretrain_r2r.json:9) -- on
         # the same model / optimizer / number of steps

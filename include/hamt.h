@@ -279,6 +279,8 @@ int hamt_wire_unpack_bf16(size_t n, const void* y, float* x, void* stream);
 int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, void* stream);
 /* out[i] = (1 - mask[i]) * -10000: the additive attention mask of a bool (1 byte / element) keep-mask (vilmodel.py:597-599) */
 int hamt_extend_mask(size_t n, const void* mask_u8, float* out, void* stream);
+/* test aid: fill the LDS of every CU with `pattern` (a kernel that reads LDS it has not written then shows it) */
+int hamt_debug_fill_lds(uint32_t pattern, void* stream);
 /* dx = dy * act'(h): mode 1 erf-GELU (vilmodel.py:23-29), mode 2 ReLU (h may be the ReLU output) */
 int hamt_act_bwd(size_t n, const float* dy, const float* h, int mode, float* dx, void* stream);
 

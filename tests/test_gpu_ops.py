@@ -222,16 +222,23 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
     specs = [  # (K rows, M out, N in, accum_dw, with_db, accum_db)
         (5120, 768, 768, 0, True, 0), (5120, 768, 3072, 0, False, 0), (5120, 3072, 768, 1, True, 1), (384, 768, 768, 0, True, 0),
         (2368 + 64 - 2368 % 64, 104, 136, 0, True, 0), (64, 8, 128, 1, False, 0), (11520, 768, 768, 0, True, 1), (640, 2304, 768, 0, True, 0),
+        (384, 256 + 58, 768, 0, True, 0), (384, 4 * 256 + 186, 256, 1, True, 0),      # ragged last 256-row tile WITH a bias gradient
     ]
     specs = specs * 6      # > one kernarg table (60 entries) => several table-write launches
     keep, refs = [], []
     descs = (L.WgradDesc * len(specs))()
     for i, (K, M, N, aw, wdb, ab) in enumerate(specs):
         valid = K - (i % 3) * 7                    # rows >= valid are zero padding
-        dyf = rnd(K, max(M + 8, 256), seed=3 * i, scale=0.5)
+        dyf = rnd(K, (max(M + 8, 256) + 8 + 7) // 8 * 8, seed=3 * i, scale=0.5)
         dyf[valid:] = 0
+        # what lies behind an operand's last column (row padding of the buffer it is a slice of, the next tensor) must not
+        # matter: NaN there.  (The 256-square tile's folded bias sums once let a NaN of an out-of-range row into the sums of
+        # valid rows: 0 x NaN; the MLM decoder bias, 30 522 = 119 x 256 + 58 rows, caught it in training.)
+        dyf[:, 8 * (i % 2) + M:] = float("nan")
         dy = dyf.to(torch.bfloat16).to(DEV)[:, 8 * (i % 2):8 * (i % 2) + M]   # column slice of a wider buffer
-        x = rnd(K, max(N, 256), seed=3 * i + 1).to(torch.bfloat16).to(DEV)[:, :N]
+        xf = rnd(K, (max(N, 256) + 8 + 7) // 8 * 8, seed=3 * i + 1)
+        xf[:, N:] = float("nan")
+        x = xf.to(torch.bfloat16).to(DEV)[:, :N]
         dw0 = rnd(M, N, seed=3 * i + 2)
         db0 = rnd(M, seed=3 * i + 5)
         dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
@@ -243,6 +250,7 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         rb = (dy.double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
         refs.append((dw, db, rw, rb))
     tab = torch.empty(sum((sp[1] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
+    L.check(lib.hamt_debug_fill_lds(0x7FC07FC0, ops._stream()), "hamt_debug_fill_lds")     # every CU's LDS = bf16 NaNs: a tile read before its DMA landed shows
     L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     torch.cuda.synchronize()
     for i, (dw, db, rw, rb) in enumerate(refs):

@@ -470,3 +470,24 @@ extern "C" int hamt_extend_mask(size_t n, const void* mask_u8, float* out, void*
   HAMT_CHECK_LAUNCH("hamt_extend_mask");
   return HAMT_OK;
 }
+
+// Test aid: fill the LDS of every CU with `pattern` (e.g. 0x7FC07FC0 = two bf16 NaNs) -- a kernel that reads LDS it has not
+// written (a missing wait in front of a DMA-filled tile) then produces NaNs instead of silently re-using whatever the
+// previous launch left there (tests/test_gpu_ops.py: the tiled GEMM kernels after a poisoned LDS).
+__global__ __launch_bounds__(256) void lds_fill_kernel(uint32_t pattern, int words) {
+  extern __shared__ uint32_t lds_fill_sm[];
+  for (int i = threadIdx.x; i < words; i += 256) lds_fill_sm[i] = pattern;
+  __syncthreads();
+  if (lds_fill_sm[(threadIdx.x * 7) % words] != pattern) __builtin_trap();   // keeps the stores
+}
+extern "C" int hamt_debug_fill_lds(uint32_t pattern, void* stream) {
+  static bool raised = false;
+  const int bytes = 150 * 1024;
+  if (!raised) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    raised = true;
+  }
+  hipLaunchKernelGGL(lds_fill_kernel, dim3(1024), dim3(256), bytes, as_stream(stream), pattern, bytes / 4);
+  HAMT_CHECK_LAUNCH("hamt_debug_fill_lds");
+  return HAMT_OK;
+}

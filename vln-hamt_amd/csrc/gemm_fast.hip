@@ -127,7 +127,8 @@ template <bool KM, int R, int NW> struct TileSrc {
         const int kk = w * PER_WAVE + j * RPI + lane / CH;
         const int chunk = (lane % CH) ^ col_swz<R>(kk);
         int c = r0 + chunk * 8;
-        c = c < ld - 8 ? c : ld - 8;
+        const int cmax = min(ld - 8, (rmax >> 3) << 3);     // (see p8_src_init: clamp inside the operand, not inside the row stride)
+        c = c < cmax ? c : cmax;
         off[j] = (unsigned)c * 2u;
       }
     }
@@ -680,7 +681,8 @@ __device__ __forceinline__ void p8_src_init(P8Src<KM>& sd, int ld, int o0, int o
         const int kk = w * 8 + j * 4 + (lane >> 4);
         const int chunk = (lane & 15) ^ col_swz<128>(kk);
         int c = o0 + p8_index<GS>(chunk * 8, h);
-        c = c < ld - 8 ? c : ld - 8;
+        const int cmax = min(ld - 8, (omax >> 3) << 3);     // never behind the last 8-column chunk that holds a needed column:
+        c = c < cmax ? c : cmax;                            // stays inside the operand (a slice of a wider buffer, the buffer's last row)
         sd.off[h][j] = (unsigned)c;
         sd.kk[j] = kk;
       }
@@ -799,8 +801,18 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
           const uint32_t o2 = (lane & 15) == I0 + i ? 0x3F803F80u : 0u;       // bf16 ones in row I0 + i of the operand
           union { uint4 u; bf16x8 v; } sel;
           sel.u = make_uint4(o2, o2, o2, o2);
+          // Rows of A beyond M (a ragged last tile) hold whatever lies behind the operand's last column -- padding, the next
+          // row -- possibly NaN bit patterns.  In the main product such a row only feeds its own (unstored) output row; HERE
+          // every fragment accumulates into the same 16 x 16 block, and 0 x NaN from fragment 3's row 58 poisoned the column
+          // sums of rows 10, 26, 42 of fragments 0 .. 2 (first seen as a NaN gradient of the 30 522-row MLM decoder bias).
+          const bool live = m0 + 128 * wr + 64 * P + 16 * i + (lane & 15) < g.M;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel.v, af[i][s], cs, 0, 0, 0);
+          for (int s = 0; s < 2; ++s) {
+            union { uint4 u; bf16x8 v; } a_;
+            a_.v = af[i][s];
+            if (!live) a_.u = make_uint4(0u, 0u, 0u, 0u);
+            cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel.v, a_.v, cs, 0, 0, 0);
+          }
         }
       }
     }
