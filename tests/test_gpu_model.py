@@ -936,6 +936,41 @@ def test_graphed_rollout_training_step_matches_eager():
     assert worst < 1e-4, worst
 
 
+class _NanScratch:
+    """While active, every float CUDA buffer the package takes from torch.empty is pre-filled with NaN (the package's modules see
+    a stand-in for the `torch` name whose `empty` fills)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        import vln_hamt_amd.blocks as blocks_m
+        import vln_hamt_amd.blocks_preln as preln_m
+        import vln_hamt_amd.ops as ops_m
+        import vln_hamt_amd.wgrad as wgrad_m
+        real_empty = torch.empty
+
+        class _T:
+            def __getattr__(self, k):
+                return getattr(torch, k)
+
+            @staticmethod
+            def empty(*a, **k):
+                t = real_empty(*a, **k)
+                if t.is_floating_point() and t.is_cuda:
+                    t.fill_(float("nan"))
+                return t
+        self.saved = [(m, m.torch) for m in (blocks_m, preln_m, ops_m, wgrad_m)]
+        if self.on:
+            for m, _ in self.saved:
+                m.torch = _T()
+        return self
+
+    def __exit__(self, *a):
+        for m, t in self.saved:
+            m.torch = t
+
+
 @pytest.mark.parametrize("B", [5, 32])
 def test_uninitialised_memory_never_reaches_a_result(B):
     """Every scratch / output buffer of the package comes from torch.empty.  With each float buffer pre-filled with NaN (what the
@@ -943,10 +978,7 @@ def test_uninitialised_memory_never_reaches_a_result(B):
     SAME loss and the same finite gradients as without: nothing may read an element it (or a kernel before it) did not write --
     padding rows / columns, ragged last tiles, clamped rows.  B = 5 makes every row count ragged, B = 32 is the soak's."""
     import bench
-    import vln_hamt_amd.blocks as blocks_m
-    import vln_hamt_amd.blocks_preln as preln_m
     import vln_hamt_amd.ops as ops_m
-    import vln_hamt_amd.wgrad as wgrad_m
     from vln_hamt_amd.synth import make_batch, make_itm_rng
     dev = torch.device(DEV)
     ops_m.manual_seed(1, dev)
@@ -955,25 +987,9 @@ def test_uninitialised_memory_never_reaches_a_result(B):
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
     named = list(model.named_parameters())
-    real_empty = torch.empty
-
-    class _T:                       # stands in for the `torch` name inside the package's modules
-        def __getattr__(self, k):
-            return getattr(torch, k)
-
-        @staticmethod
-        def empty(*a, **k):
-            t = real_empty(*a, **k)
-            if t.is_floating_point() and t.is_cuda:
-                t.fill_(float("nan"))
-            return t
     results = []
     for poisoned in (False, True):
-        saved = [(m, m.torch) for m in (blocks_m, preln_m, ops_m, wgrad_m)]
-        if poisoned:
-            for m, _ in saved:
-                m.torch = _T()
-        try:
+        with _NanScratch(poisoned):
             out = {}
             for it, task in enumerate(["mlm", "sap", "sar", "sprel", "mrc", "itm"]):
                 b = make_batch(task, B, cfg, seed=300 + it, txt_len=80, hist_len=5, ragged=True, mlm_exact=7 if task == "mlm" else None, device=dev)
@@ -987,9 +1003,6 @@ def test_uninitialised_memory_never_reaches_a_result(B):
                 torch.cuda.synchronize()
                 out[task] = (float(loss), {n: p.grad.detach().clone() for n, p in named if p.grad is not None})
             results.append(out)
-        finally:
-            for m, t in saved:
-                m.torch = t
     clean, dirty = results
     for task in clean:
         l0, g0 = clean[task]
@@ -1009,6 +1022,33 @@ def test_uninitialised_memory_never_reaches_a_result(B):
             assert float((a - c).abs().max()) <= tol * max(float(a.abs().max()), 1e-6), (task, n, float((a - c).abs().max()), float(a.abs().max()))
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("no_lang_ca", [True, False])
+def test_uninitialised_memory_never_reaches_a_rollout_result(no_lang_ca):
+    """The same for the finetune model: an imitation-learning rollout (language once, history / visual per step) and its backward."""
+    from vln_hamt_amd.synth import make_batch
+    T = 3
+    m = _tiny_navcmt(no_lang_ca=no_lang_ca, train=True, p_drop=0.0)
+    named = list(m.named_parameters())
+    b = make_batch("sap", 5, tiny_cfg(no_lang_ca=True, act_pred_token="ob"), seed=77, txt_len=23, hist_len=T, device=DEV)
+    b["step_ids"] = torch.arange(T, device=DEV)
+    res = []
+    for poisoned in (False, True):
+        with _NanScratch(poisoned):
+            for p in m.parameters():
+                p.grad = None
+            loss = _rollout_loss(m, b, T)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((float(loss), {n: p.grad.detach().clone() for n, p in named if p.grad is not None}))
+    (l0, g0), (l1, g1) = res
+    assert l1 == l1 and abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (l0, l1)
+    for n in g0:
+        a, c = g0[n].double(), g1[n].double()
+        assert bool(torch.isfinite(c).all()), n
+        if not n.endswith("key.bias"):
+            assert float((a - c).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1e-6), (n, float((a - c).abs().max()), float(a.abs().max()))
 
 
 def test_training_soak_losses_fall():
