@@ -631,6 +631,7 @@ class EmbedSumFn(torch.autograd.Function):
                 "hamt_embed_sum_fwd")
         ctx.save_for_backward(ids)
         ctx.shapes = (word.shape, pos.shape, typ.shape)
+        ctx.tables = (word, pos, typ)
         return z
 
     @staticmethod
@@ -640,13 +641,32 @@ class EmbedSumFn(torch.autograd.Function):
         dz = dz.contiguous()
         H = dz.shape[-1]
         dev = dz.device
-        dword = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
-        dpos = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
-        dtyp = torch.zeros(ctx.shapes[2], dtype=torch.float32, device=dev)
+        from . import wgrad
+        in_pass = wgrad.ENABLED and torch._C._current_graph_task_id() >= 0
+        outs, rets = [], []
+        for p, shape in zip(ctx.tables, ctx.shapes):
+            # a table that owns a (zero at the start of a step) slot in the optimizer's gradient arena: add there -- no zero fill
+            # of the 94 MB word table, no copy into the arena afterwards (as ops.GatherRowsFn does); published as `.grad` at the
+            # end of the pass, the tied MLM decoder's queued weight gradient then accumulates on top
+            slot = getattr(p, "_hamt_grad_slot", None) if (in_pass and p.is_leaf and p.requires_grad) else None
+            if (slot is not None and slot.shape == p.shape and slot.is_contiguous() and getattr(p, "_hamt_slot_zeroed", False)
+                    and (p.grad is None or p.grad.data_ptr() == slot.data_ptr())):
+                outs.append(slot)
+                rets.append(None)
+            else:
+                t = torch.zeros(shape, dtype=torch.float32, device=dev)
+                outs.append(t)
+                rets.append(t)
+        dword, dpos, dtyp = outs
+        if any(r is None for r in rets):
+            wgrad.queue(dev).current()              # (opens the pass: orders this stream behind an overlapped optimizer update)
         L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, _p(ids), _p(dz), _p(dword), _p(dpos), None, _stream()), "hamt_embed_sum_bwd")
         ws = torch.empty(64 * H, dtype=torch.float32, device=dev)
         L.check(L.load().hamt_sum_rows(B, Lq, H, _p(dz), 0, _p(dtyp), _p(ws), _stream()), "hamt_sum_rows")  # row 0 of the type table
-        return None, dword, dpos, dtyp
+        for p, r, o in zip(ctx.tables, rets, outs):
+            if r is None:
+                wgrad.publish_slot_grad(p, o)
+        return None, rets[0], rets[1], rets[2]
 
 
 class GatherRowsFn(torch.autograd.Function):

@@ -386,10 +386,12 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
     written: dict = {}
     per_group: List[list] = [[] for _ in range(ng)]
     for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
-        aw = 1 if (ow in written or (w.grad is not None and w.grad.data_ptr() != base + 4 * ow)) else 0
+        # (a gradient that exists already -- an autograd tensor the caller packs into the slot before the groups run, or the slot
+        # itself holding what was added in place during the pass: an embedding table tied to this weight -- is accumulated onto)
+        aw = 1 if (ow in written or w.grad is not None) else 0
         ab = 0
         if ob is not None:
-            ab = 1 if (ob in written or (b.grad is not None and b.grad.data_ptr() != base + 4 * ob)) else 0
+            ab = 1 if (ob in written or b.grad is not None) else 0
             written[ob] = True
         written[ow] = True
         per_group[group_of[i]].append((ow, ob, w, b, dy16, x16, aw, ab))
