@@ -948,6 +948,7 @@ class _NanScratch:
         import vln_hamt_amd.blocks_preln as preln_m
         import vln_hamt_amd.ops as ops_m
         import vln_hamt_amd.wgrad as wgrad_m
+        import vln_hamt_amd.model.vision_transformer as vit_m
         real_empty = torch.empty
 
         class _T:
@@ -960,7 +961,7 @@ class _NanScratch:
                 if t.is_floating_point() and t.is_cuda:
                     t.fill_(float("nan"))
                 return t
-        self.saved = [(m, m.torch) for m in (blocks_m, preln_m, ops_m, wgrad_m)]
+        self.saved = [(m, m.torch) for m in (blocks_m, preln_m, ops_m, wgrad_m, vit_m)]
         if self.on:
             for m, _ in self.saved:
                 m.torch = _T()

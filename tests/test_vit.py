@@ -255,3 +255,34 @@ def test_preln_blocks_with_branch_dropout_vs_torch():
     h = m1.view(B, S, I) * torch.nn.functional.gelu(ln @ w1.t() + b1)
     ref = x + m2.view(B, S, D) * (h @ w2.t() + b2)
     check("mlp", out, ref, [x, gam, bet, w1, b1, w2, b2])
+
+
+@pytest.mark.gpu
+def test_vit_uninitialised_memory_never_reaches_a_result():
+    """ViT-B/16 at full width, 3 images (591 token rows: ragged against every tile size), forward + backward in bf16 mode with every
+    scratch / output buffer of the package pre-filled with NaN: same features, same finite gradients (see test_gpu_model)."""
+    from oracle.hamt_oracle import VitConfig, make_vit_state_dict
+    from test_gpu_model import _NanScratch
+    from vln_hamt_amd.model.vision_transformer import VisionTransformer
+    c = VitConfig()
+    model = VisionTransformer(c.img_size, c.patch_size, c.in_chans, c.embed_dim, c.depth, c.num_heads, c.mlp_ratio, hamt_precision="bf16")
+    model.load_state_dict(make_vit_state_dict(c, seed=21), strict=True)
+    model = model.cuda().train(False)
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randn(3, 3, c.img_size, c.img_size, generator=g).cuda()
+    probe = torch.randn(3, c.embed_dim, generator=g).cuda()
+    res = []
+    for poisoned in (False, True):
+        with _NanScratch(poisoned):
+            for p in model.parameters():
+                p.grad = None
+            feats = model.forward_features(imgs)
+            (feats * probe).sum().backward()
+            torch.cuda.synchronize()
+            res.append((feats.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (f0, g0), (f1, g1) = res
+    assert bool(torch.isfinite(f1).all()) and torch.equal(f0, f1)
+    for k in g0:
+        assert bool(torch.isfinite(g1[k]).all()), k
+        if not k.endswith("qkv.bias"):
+            assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * max(float(g0[k].abs().max()), 1e-6), k
