@@ -137,11 +137,17 @@ typedef struct {
   float* db; /* may be NULL */
   int M, N, K, ldy, ldx, ldw;
   int accum_dw, accum_db; /* 0: store, 1: += */
+  float* ss; /* may be NULL.  ceil(M / 64) * ceil(N / 128) floats, ZERO on entry: every output tile stores the sum of squares of the
+              * values it wrote (after accumulation) into the slot of its origin [row / 64][column / 128] -- a tile of any size
+              * owns exactly one of these slots, the others stay zero -- so that sum(ss) = ||dW||^2 without reading dW back
+              * (the global-norm clip of the step: hamt_sumsq_partials + hamt_sumsq_table over the remaining parameters).
+              * Only meaningful for a dW written ONCE in the call sequence (a second, accumulating problem on the same dW
+              * must use the same tiling to overwrite the same slots: pass NULL for both and reduce that parameter from memory) */
 } hamt_wgrad_desc;
 /* `table`: caller-provided DEVICE scratch (16-byte aligned) that holds the launch table: HAMT_WGRAD_TABLE_ENTRY bytes per
  * entry, at most sum over the problems of ceil(M_p / 64) entries (large problems are cut into bands of tile rows); it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can
  * be captured in a hipGraph.  The table must stay untouched until the launches have run. */
-#define HAMT_WGRAD_TABLE_ENTRY 64
+#define HAMT_WGRAD_TABLE_ENTRY 72
 int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
@@ -342,6 +348,9 @@ int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g, float* m,
  * whatever they hold (torch clip_grad_norm_ over the parameters that have a gradient, main_r2r.py:271-273).  ws: 1024 floats. */
 int hamt_sumsq_table(size_t first, size_t n, const float* g, const int* ends, const float* hyp, int nparams,
                      float* out, int accumulate, float* ws, void* stream);
+/* active == 3: like 2, and hamt_sumsq_table skips the parameter as well -- its sum of squares comes from the weight-gradient
+ * tiles (hamt_wgrad_desc.ss).  hamt_sumsq_partials: out (+)= sum of the n floats of `partials` (fixed order). */
+int hamt_sumsq_partials(size_t n, const float* partials, float* out, int accumulate, void* stream);
 /* g *= min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  -- standalone clip for torch-optimiser users */
 int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream);
 

@@ -242,20 +242,27 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         dw0 = rnd(M, N, seed=3 * i + 2)
         db0 = rnd(M, seed=3 * i + 5)
         dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
-        keep += [dy, x, dw, db]
+        ss = torch.zeros(((M + 63) // 64) * ((N + 127) // 128), device=DEV) if i % 4 != 3 else None     # per-tile sums of squares (optional)
+        keep += [dy, x, dw, db, ss]
         d = descs[i]
         d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if wdb else None)
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = M, N, K, dy.stride(0), x.stride(0), N, aw, ab
+        d.ss = ss.data_ptr() if ss is not None else None
         rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
         rb = (dy.double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
-        refs.append((dw, db, rw, rb))
+        refs.append((dw, db, rw, rb, ss))
     tab = torch.empty(sum((sp[1] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
     L.check(lib.hamt_debug_fill_lds(0x7FC07FC0, ops._stream()), "hamt_debug_fill_lds")     # every CU's LDS = bf16 NaNs: a tile read before its DMA landed shows
     L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     torch.cuda.synchronize()
-    for i, (dw, db, rw, rb) in enumerate(refs):
+    for i, (dw, db, rw, rb, ss) in enumerate(refs):
         close(dw, rw, 3e-5, f"dW[{i}] {specs[i]}")
         close(db, rb, 3e-5, f"db[{i}] {specs[i]}")
+        if ss is not None:       # sum over the tiles' slots = ||dW||^2 of the FINAL values (after accumulation), whatever the tile size
+            want = float((rw ** 2).sum())
+            got = float(ss.double().sum())
+            assert abs(got - want) <= 2e-5 * want and bool(torch.isfinite(ss).all()), (i, specs[i], got, want)
+            assert int((ss != 0).sum()) <= ss.numel()
     # argument validation is loud
     descs[0].K = 100
     with pytest.raises(L.HamtError):

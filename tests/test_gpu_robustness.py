@@ -296,7 +296,9 @@ def test_unzeroed_weight_gradient_slots_do_not_leak(tiny, monkeypatch):
         norms, stale = [], None
         for i, (b, t) in enumerate(zip(bs, seq)):
             m(b, t, True).mean().backward()
+            ref = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
             norms.append(float(clip_grad_norm_(m.parameters(), 5.0, optimizer=o)))
+            assert abs(norms[-1] - ref) <= 1e-5 * ref, (i, t, norms[-1], ref)      # table norm + the weight-gradient tiles' sums == torch's norm
             o.step()
             o.zero_grad()
             if i == 1:          # after the mlm step: the sap head (net.0.weight is a GEMM weight) did not train in it
@@ -313,3 +315,47 @@ def test_unzeroed_weight_gradient_slots_do_not_leak(tiny, monkeypatch):
     w = _worst(m1, m0)
     assert w < 1e-6, w
     assert o1.update_bytes() < o0.update_bytes() == 34.0 * float(o0._ends[-1])
+
+
+def test_gradient_norm_tracks_gradients_changed_after_the_pass(tiny):
+    """The weight-gradient launch leaves each tile's sum of squares for the clip (hamt_wgrad_desc.ss) so that the norm does not
+    read the gradients back -- valid only while the gradients are what that launch wrote.  Accumulating a second micro-batch,
+    scaling the gradients in place, replacing a .grad or dropping one must all fall back to reducing from memory."""
+    from vln_hamt_amd.optim import clip_grad_norm_
+    from vln_hamt_amd.synth import make_batch
+    _, cfg, sd = tiny
+    b1 = make_batch("sap", 4, cfg, seed=61, txt_len=20, hist_len=4, device=DEV)
+    b2 = make_batch("sap", 4, cfg, seed=62, txt_len=20, hist_len=4, device=DEV)
+    m, o = _model_opt(cfg, sd)
+    o.materialize()
+
+    def torch_norm():
+        return float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+
+    def check(what):
+        ref = torch_norm()
+        got = float(clip_grad_norm_(m.parameters(), 5.0, optimizer=o))
+        assert abs(got - ref) <= 1e-5 * ref, (what, got, ref)
+
+    m(b1, "sap", True).mean().backward()
+    assert o._fused is not None and len(o._fused[1]) > 10          # the plain case does use the tile sums
+    check("one pass")
+    o.zero_grad()
+    m(b1, "sap", True).mean().backward()
+    m(b2, "sap", True).mean().backward()                              # second micro-batch accumulates into the same slots
+    check("two accumulated passes")
+    o.zero_grad()
+    m(b1, "sap", True).mean().backward()
+    for p in m.parameters():
+        if p.grad is not None:
+            p.grad.mul_(0.5)                                           # in place: the arena's version counter moves
+    check("scaled in place")
+    o.zero_grad()
+    m(b1, "sap", True).mean().backward()
+    w = m.bert.encoder.layer[0].attention.self.query.weight
+    w.grad = w.grad * 3.0                                              # replaced by a new tensor
+    check("one gradient replaced")
+    o.zero_grad()
+    m(b1, "sap", True).mean().backward()
+    m.bert.encoder.layer[0].intermediate.dense.weight.grad = None      # dropped
+    check("one gradient dropped")

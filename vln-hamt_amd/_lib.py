@@ -48,12 +48,12 @@ class LnDesc(C.Structure):
 
 
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
-WGRAD_TABLE_ENTRY = 64      # HAMT_WGRAD_TABLE_ENTRY
+WGRAD_TABLE_ENTRY = 72      # HAMT_WGRAD_TABLE_ENTRY
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32), ("ldy", i32),
-                ("ldx", i32), ("ldw", i32), ("accum_dw", i32), ("accum_db", i32)]
+                ("ldx", i32), ("ldw", i32), ("accum_dw", i32), ("accum_db", i32), ("ss", vp)]
 
 
 SIGNATURES = {
@@ -108,6 +108,7 @@ SIGNATURES = {
     "hamt_a2c_bwd": [i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "hamt_sumsq": [sz, vp, vp, i32, vp, vp],
     "hamt_sumsq_table": [sz, sz, vp, vp, vp, i32, vp, i32, vp, vp],
+    "hamt_sumsq_partials": [sz, vp, vp, i32, vp],
     "hamt_adamw_flat": [sz, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table": [sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table_range": [sz, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],

@@ -45,6 +45,7 @@ struct GemmArgsF {
   float p_drop;         // HAMT_EPI_DROPOUT
   uint32_t call_id;
   const uint64_t* rng;
+  float* ss;            // weight-gradient tiles: slot array for the sum of squares of each tile's FINAL values (or nullptr)
 };
 
 #ifdef HAMT_PROF   // cycle accounting of the main loop (tools/gemm_prof.py builds a private copy with -DHAMT_PROF)
@@ -202,7 +203,7 @@ template <int W> __device__ __forceinline__ void st_f(float* p, const float* v) 
 }
 
 template <int EPI, int W>
-__device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, const float* acc) {
+__device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, const float* acc, float* ssq = nullptr) {
   if (row >= g.M || col >= g.N) return;
   const int epi = EPI >= 0 ? EPI : (EPI == -2 ? (g.epi & HAMT_EPI_ACCUM) : g.epi);   // -2: plain store or C += only
   float v[W];
@@ -268,7 +269,29 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
     if (vc) {
       if (epi & HAMT_EPI_ACCUM) { float p[W]; ld_f<W>(c, p); for (int j = 0; j < W; ++j) v[j] += p[j]; }
       st_f<W>(c, v);
-    } else for (int j = 0; j < W; ++j) if (col + j < g.N) c[j] = (epi & HAMT_EPI_ACCUM) ? c[j] + v[j] : v[j];
+      if (ssq) for (int j = 0; j < W; ++j) *ssq += v[j] * v[j];
+    } else for (int j = 0; j < W; ++j) if (col + j < g.N) {
+      const float f = (epi & HAMT_EPI_ACCUM) ? c[j] + v[j] : v[j];
+      c[j] = f;
+      if (ssq) *ssq += f * f;
+    }
+  }
+}
+
+// One float per output tile: the sum of squares of what the tile stored (a weight-gradient tile's share of the global gradient
+// norm: the clip needs it before the update, and reading 0.6 GB of gradients back for it costs ~0.13 ms per step).  Slot = the
+// tile's origin in units of 64 rows x 128 columns, so the same array serves every tile size; summed in thread / wave order:
+// deterministic.  `red`: >= (threads / 64) floats of LDS nobody else is using.
+__device__ __forceinline__ void tile_sumsq_store(const GemmArgsF& g, int m0, int n0, float ssq, float* red) {
+  const int t = threadIdx.x, nw = blockDim.x >> 6;
+  ssq = wave_sum(ssq);
+  __syncthreads();
+  if ((t & 63) == 0) red[t >> 6] = ssq;
+  __syncthreads();
+  if (t == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += red[i];
+    g.ss[(size_t)(m0 >> 6) * ((g.N + 127) >> 7) + (n0 >> 7)] = tot;
   }
 }
 
@@ -379,6 +402,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       }
     }
   }
+  float tile_ssq = 0.f;
   // Epilogue through LDS.  A wave's store instructions are issue-bound (~70 cycles each whatever their width, see
   // MI355X_MICROARCH.md "store tail"), and the MFMA layout gives a lane only 4 consecutive columns (8 bytes of a bf16
   // row).  Re-tiling the fp32 accumulators through LDS gives every lane 8 consecutive columns -- one 16-byte store per
@@ -396,8 +420,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
         if (g.ksplit > 1) {
           float* P = g.part + (size_t)slice * g.M * g.N;
           if (row < g.M) for (int e = 0; e < 4; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = a4[e];
-        } else epi_store<EPI, 4>(g, row, col, a4);
+        } else epi_store<EPI, 4>(g, row, col, a4, (COLSUM && g.ss) ? &tile_ssq : nullptr);
       }
+    if constexpr (COLSUM) { if (g.ss) tile_sumsq_store(g, m0, n0, tile_ssq, (float*)lds); }
   } else {
     static_assert(BN == 128, "the staged epilogue is written for 128-column tiles");
     constexpr int RPP = NW * 4;                    // tile rows per pass: 16 threads per row
@@ -424,8 +449,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
           if (col + 8 <= g.N && (g.N & 3) == 0) st_f<8>(P + (size_t)row * g.N + col, v8);
           else for (int e = 0; e < 8; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v8[e];
         }
-      } else epi_store<EPI, 8>(g, row, col, v8);
+      } else epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
     }
+    if constexpr (COLSUM) { if (g.ss) tile_sumsq_store(g, m0, n0, tile_ssq, (float*)lds); }
   }
 #ifdef HAMT_PROF
   {   // one record per wave: [dma wait, barrier, dma issue, fragments + MFMA, loop, 1, k-tiles, prologue, epilogue] in shader cycles
@@ -564,11 +590,12 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
 // split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
-constexpr int WG_MAX = 60;                       // table entries carried by one kernarg block
+constexpr int WG_MAX = 54;                       // table entries carried by one kernarg block (72 bytes each, < 4 KiB)
 struct WgradProb {
-  const bf16_t* dy; const bf16_t* x; float* dw; float* db;
+  const bf16_t* dy; const bf16_t* x; float* dw; float* db; float* ss;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
 };
+static_assert(sizeof(WgradProb) == HAMT_WGRAD_TABLE_ENTRY, "HAMT_WGRAD_TABLE_ENTRY");
 struct WgradChunk { WgradProb p[WG_MAX]; };
 // The problem table lives in caller-provided device memory and is WRITTEN BY KERNELS whose kernargs carry it 60 entries
 // at a time: no host buffer has to outlive the call, so the whole sequence is hipGraph-capturable as is.
@@ -597,7 +624,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const Wgrad
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + BNT - 1) / BNT;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
-              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1};
+              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1, 0.f, 0u, nullptr, q.ss};
   gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, q.K / BK, 0, q.db, q.flags & 2);
 }
 
@@ -854,6 +881,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
     }
   }
   // epilogue: two passes (a0 rows, a1 rows) through this wave's own 16 KiB of LDS: [64][64] fp32, float4 slot ^= row & 7
+  float tile_ssq = 0.f;
   float* ct = (float*)lds + w * 4096;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -871,7 +899,13 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
       const f32x4 lo = *(const f32x4*)(ct + rl * 64 + (((2 * c8) ^ (rl & 7)) << 2));
       const f32x4 hi = *(const f32x4*)(ct + rl * 64 + (((2 * c8 + 1) ^ (rl & 7)) << 2));
       const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      epi_store<EPI, 8>(g, row, col, v8);
+      epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
+    }
+  }
+  if constexpr (COLSUM) {
+    if (g.ss) {
+      __shared__ float p8_red[8];
+      tile_sumsq_store(g, m0, n0, tile_ssq, p8_red);
     }
   }
 }
@@ -897,7 +931,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_p8_kernel(const WgradProb* 
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + 255) / 256;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
-              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1};
+              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1, 0.f, 0u, nullptr, q.ss};
   p8_tile<-2, true, true, true>(g, (local / tiles_n) * 256, (local % tiles_n) * 256, q.db, q.flags & 2);
 }
 
@@ -1195,7 +1229,9 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
         const hamt_wgrad_desc& d = probs[un.prob];
         tiles += un.tiles;
         flat.push_back(WgradProb{(const bf16_t*)d.dy + un.m_lo, (const bf16_t*)d.x, d.dw + (size_t)un.m_lo * d.ldw,
-                                 d.db ? d.db + un.m_lo : nullptr, un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
+                                 d.db ? d.db + un.m_lo : nullptr,
+                                 d.ss ? d.ss + (size_t)(un.m_lo >> 6) * ((d.N + 127) >> 7) : nullptr,     // (bands start on multiples of 64 rows)
+                                 un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
                                  (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles});
       }
       max_tiles = std::max(max_tiles, tiles);

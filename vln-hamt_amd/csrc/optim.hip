@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void sumsq_table_partial_kernel(size_t n, cons
   float s = 0.f;
   for (size_t seg = lo; seg < hi; ++pi) {
     const size_t pend = pi < nparams - 1 ? min(hi, ((size_t)ends[pi] >> 2) - first4) : hi;
-    if (hyp[pi].w != 0.f) {
+    if (hyp[pi].w != 0.f && hyp[pi].w != 3.f) {      // 3: accounted for by the weight-gradient tiles (hamt_wgrad_desc.ss)
       for (size_t i = seg + threadIdx.x; i < pend; i += 256 * 4) {
         float4 v[4];
 #pragma unroll
@@ -197,6 +197,12 @@ extern "C" int hamt_sumsq_table(size_t first, size_t n, const float* g, const in
   hipLaunchKernelGGL(sumsq_table_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ends, (const float4*)hyp, nparams, first / 4, ws);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
   HAMT_CHECK_LAUNCH("hamt_sumsq_table");
+  return HAMT_OK;
+}
+extern "C" int hamt_sumsq_partials(size_t n, const float* partials, float* out, int accumulate, void* stream) {
+  HAMT_CHECK_ARG(partials && out && n < (size_t)1 << 30, "hamt_sumsq_partials: bad argument");
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (int)n, partials, out, accumulate);
+  HAMT_CHECK_LAUNCH("hamt_sumsq_partials");
   return HAMT_OK;
 }
 extern "C" int hamt_adamw_flat(size_t n, float* p, float* g, float* m, float* v, void* p16, const float* hyper,

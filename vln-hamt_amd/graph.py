@@ -167,7 +167,8 @@ class GraphedTrainStep:
                 self.update_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.update_graph, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
                     self._update(dev)
-        active = list(self.opt.active_mask)
+        active = self.opt.table_flags()        # per-parameter flags of THIS key's step (incl. which norms the captured wgrad launch supplies)
+        self.opt._fused = None
         self.opt._pending_clip = None
         self.opt._packed = False
         for p in self.opt._params:             # the captured gradient buffers stay alive inside the graph's pool

@@ -156,6 +156,7 @@ class AdamW(Optimizer):
         self._ov = None             # _Overlap: the update runs on its own stream next to the following forward pass (attach())
         self._table_ready = False   # the device table already describes the step whose gradients are packed now
         self._table_lrs = None
+        self._fused = None          # (partial sums tensor, parameter index array): gradients whose sum of squares wgrad.py already has
 
     # ---------------------------------------------------------------- arenas
     def _build(self):
@@ -219,8 +220,12 @@ class AdamW(Optimizer):
 
     def _publish_grad_slots(self):
         """Let the grouped weight-gradient launch (wgrad.py) write straight into the flat gradient arena."""
+        import weakref
+        me = weakref.ref(self)
+        self._index_of = {id(p): i for i, p in enumerate(self._params)}
         for p, o, k in zip(self._params, self._offs, self._keep):
             p._hamt_grad_slot = self._flat_g[o:o + p.numel()].view(p.shape)
+            p._hamt_opt = me
             p._hamt_slot_zeroed = bool(k == 1.0)      # producers that ADD into the slot from zero (ops.GatherRowsFn, LayerNorm partials) need this
 
     def _sync_shadow_views(self):
@@ -261,6 +266,15 @@ class AdamW(Optimizer):
             if a and p.grad.data_ptr() != self._flat_g.data_ptr() + 4 * o:   # else: already written in place (wgrad.py)
                 src.append(p.grad.reshape(-1))
                 dst.append(self._flat_g[o:o + p.numel()])
+        if self._fused is not None:
+            # the tile sums describe gradients that sit in their slots as the weight-gradient launch left them: a fused parameter
+            # whose .grad was replaced (averaged over micro-batches / ranks into a new tensor) or dropped invalidates them
+            base = self._flat_g.data_ptr()
+            for i in self._fused[1]:
+                p = self._params[i]
+                if p.grad is None or p.grad.data_ptr() != base + 4 * self._offs[i]:
+                    self._fused = None
+                    break
         if src:
             torch._foreach_copy_(dst, src)
         self._active = active
@@ -269,6 +283,9 @@ class AdamW(Optimizer):
 
     def global_grad_sumsq(self) -> torch.Tensor:
         """device scalar sum(g^2) over every parameter that has a gradient (the active rows of the device table)."""
+        if self._fused is not None and self._fused[2] != self._flat_g._version:
+            self._fused = None              # the gradients were touched after the pass that produced the tile sums
+            self._table_ready = False
         if not self._packed:
             self._pack_grads()
         self.wait_update()
@@ -279,17 +296,45 @@ class AdamW(Optimizer):
             self._ensure_table()            # (a captured step: the caller refreshes the table before every replay)
         L.check(L.load().hamt_sumsq_table(0, self._n, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
                                           _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
+        if self._fused is not None:         # the table (flag 3) skipped these: their tiles' sums of squares
+            ss = self._fused[0]
+            L.check(L.load().hamt_sumsq_partials(ss.numel(), _p(ss), _p(self._gnorm), 1, _stream()), "hamt_sumsq_partials")
         return self._gnorm
 
     # ---------------------------------------------------------------- step = host part + launches
+    def note_fused_sumsq(self, ss: torch.Tensor, params):
+        """wgrad.py: the grouped weight-gradient launch of this pass left the sum of squares of these parameters' gradients in
+        `ss` (one float per output tile): the norm kernel skips them (table flag 3) and adds sum(ss) instead."""
+        if self._ov is not None:        # (update at the head of the next replay: the table describes the previous step, see attach())
+            return
+        # valid for as long as nothing else writes the gradient arena: any torch op on a gradient (averaging over micro-batches or
+        # ranks, scaling, a copy) bumps the arena's version counter and global_grad_sumsq then reduces everything from memory
+        self._fused = (ss, np.asarray([self._index_of[id(p)] for p in params], dtype=np.int64), self._flat_g._version)
+
+    def clear_fused_sumsq(self):
+        self._fused = None
+
+    def table_flags(self, active=None) -> np.ndarray:
+        """per parameter: 0 no gradient this step, 1 update + zero the gradient slot, 2 update and leave the slot to its producer,
+        3 like 2 and the gradient's sum of squares is already known (note_fused_sumsq)"""
+        if active is None:
+            active = self._active if self._active is not None else [p.grad is not None for p in self._params]
+        act = np.asarray(active)
+        if act.dtype != np.bool_:
+            return act.astype(np.float32)          # already flags (a captured step's own)
+        f = act.astype(np.float32) * self._keep
+        if self._fused is not None:
+            idx = self._fused[1]
+            f[idx] = np.where(f[idx] == 2.0, 3.0, f[idx])
+        return f
+
     def host_table(self, active: Optional[List[bool]] = None, advance: bool = True) -> np.ndarray:
         """Host side of a step: advance the per-parameter step counts (unless `advance` is False: the table of the step that was
         already counted, e.g. rebuilt for new learning rates) and return the [nparams, 4] table {lr, bias-corrected step size,
         weight decay, active (2: leave the gradient slot unzeroed)} for `upload_table`.  `active` defaults to "has a gradient now"."""
         self.materialize()
-        if active is None:
-            active = self._active if self._active is not None else [p.grad is not None for p in self._params]
-        act = np.asarray(active, dtype=bool)
+        flags = self.table_flags(active)
+        act = flags != 0
         if advance:
             self._steps[act] += 1
         t = np.maximum(self._steps, 1).astype(np.float64)
@@ -299,8 +344,8 @@ class AdamW(Optimizer):
         cb = np.array([bool(g["correct_bias"]) for g in self.param_groups])[self._gidx_np]
         ss = np.where(cb, lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t), lr)
         h = np.empty((len(self._params), 4), dtype=np.float32)
-        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, act * self._keep
-        self._table_active = act
+        h[:, 0], h[:, 1], h[:, 2], h[:, 3] = lr, ss, wd, flags
+        self._table_active = flags
         return h
 
     def upload_table(self, table: Optional[np.ndarray]):
@@ -425,10 +470,12 @@ class AdamW(Optimizer):
         self._packed = False
         self._active = None
         self._table_ready = False
+        self._fused = None
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
         self._packed = False
+        self._fused = None
         from .. import wgrad
         if self._built and getattr(self._flat_g, "_hamt_dirty", False):
             self.wait_update()

@@ -30,6 +30,7 @@ import torch
 from . import _lib as L
 
 ENABLED = os.environ.get("HAMT_NO_DEFER_WGRAD") is None     # ablation switch: compute every dW immediately
+FUSE_SUMSQ = os.environ.get("HAMT_NO_FUSED_SUMSQ") is None  # ablation switch: the gradient norm reads every gradient back
 
 stats = {"flushes": 0, "problems": 0, "dropped_stale": 0}
 
@@ -305,7 +306,29 @@ def _flush_pass(ps: _Pass, handler):
             groups.append([])
         groups[k].append((w, dy16, x16, tw, aw or k > 0, tb, ab or k > 0))
     lib = L.load()
-    for grp in groups:
+    # Sum of squares of the gradients while their tiles are still in registers (hamt_wgrad_desc.ss): for every weight whose
+    # gradient is STORED once in this pass straight into its gradient-arena slot -- the bulk of the parameters -- so that the
+    # global-norm clip does not have to read them back (optim.AdamW.global_grad_sumsq adds the slots' total to the table norm).
+    fused, ss_all, opt = [], None, None
+    for o in {id(r): r for r in (getattr(it[0], "_hamt_opt", None) for it in items) if r is not None}.values():
+        if o() is not None:
+            o().clear_fused_sumsq()            # whatever an earlier pass left (gradient accumulation: this pass adds on top)
+    if FUSE_SUMSQ and groups:
+        slots_of = lambda w: ((w.shape[0] + 63) // 64) * ((w.shape[1] + 127) // 128)
+        n_ss = 0
+        for (w, dy16, x16, tw, aw, tb, ab) in groups[0]:
+            o = getattr(w, "_hamt_opt", None)
+            o = o() if o is not None else None
+            slot = getattr(w, "_hamt_grad_slot", None)
+            if (o is not None and (opt is None or o is opt) and not aw and seen.get(id(tw), 0) == 1 and slot is not None
+                    and tw.data_ptr() == slot.data_ptr() and not getattr(w, "_hamt_slot_zeroed", True) and tw.stride(0) == w.shape[1]):
+                opt = o
+                fused.append((id(tw), w, n_ss))
+                n_ss += slots_of(w)
+        if fused:
+            ss_all = torch.zeros(n_ss, dtype=torch.float32, device=groups[0][0][3].device)
+    ss_of = {k: off for (k, _w, off) in fused}
+    for gi, grp in enumerate(groups):
         descs = (L.WgradDesc * len(grp))()
         for i, (w, dy16, x16, tw, aw, tb, ab) in enumerate(grp):
             d = descs[i]
@@ -313,7 +336,10 @@ def _flush_pass(ps: _Pass, handler):
             d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), tw.stride(0)
             d.accum_dw, d.accum_db = int(bool(aw)), int(bool(ab))
+            d.ss = (ss_all.data_ptr() + 4 * ss_of[id(tw)]) if (gi == 0 and id(tw) in ss_of) else None
         launch(descs, len(grp))
+    if fused:
+        opt.note_fused_sumsq(ss_all, [w for (_k, w, _o) in fused])
     stats["flushes"] += 1
     stats["problems"] += len(items)
     for p, t in fresh:
