@@ -972,12 +972,13 @@ class _NanScratch:
             m.torch = t
 
 
-@pytest.mark.parametrize("B", [5, 32])
+@pytest.mark.parametrize("B", [5, 32, 64])
 def test_uninitialised_memory_never_reaches_a_result(B):
     """Every scratch / output buffer of the package comes from torch.empty.  With each float buffer pre-filled with NaN (what the
     caching allocator can hand out: a freed block keeps its bytes) a forward + backward of every task at full width must give the
     SAME loss and the same finite gradients as without: nothing may read an element it (or a kernel before it) did not write --
-    padding rows / columns, ragged last tiles, clamped rows.  B = 5 makes every row count ragged, B = 32 is the soak's."""
+    padding rows / columns, ragged last tiles, clamped rows.  B = 5 makes every row count ragged, B = 32 is the soak's, B = 64 the
+    bench's (the 256-square forward / dgrad tiles only run there)."""
     import bench
     import vln_hamt_amd.ops as ops_m
     from vln_hamt_amd.synth import make_batch, make_itm_rng
