@@ -123,7 +123,8 @@ int hamt_smallk_wgrad(int M, int N, int K, const float* dy, int lddy, const floa
 /* Grouped weight gradients: n independent problems in as few launches as the kernarg table allows,
  *     dW_p[M_p][N_p] (+)= dY_p^T X_p      and, when db != NULL,      db_p[M_p] (+)= column sums of dY_p,
  * with dY_p bf16 [K_p][ldy] (its M_p columns = the layer's output features) and X_p bf16 [K_p][ldx] (the layer's input
- * image), both exactly as the forward / dgrad GEMMs left them (K_p = rows padded to a multiple of 64 with ZERO rows).
+ * image), both exactly as the forward / dgrad GEMMs left them (K_p = rows padded to a multiple of 64; the padding rows are
+ * zero, or of any content when K_valid names the valid rows).
  * Problems are packed into one launch per tile class (256-square tiles when the operand rows allow, else 128 / 64 rows).
  * This is what torch.autograd does one nn.Linear at a time in the reference (vilmodel.py: every nn.Linear backward);
  * weight gradients are not on the backward critical path, so the host queues them and hands the whole list over once per
@@ -143,11 +144,14 @@ typedef struct {
               * (the global-norm clip of the step: hamt_sumsq_partials + hamt_sumsq_table over the remaining parameters).
               * Only meaningful for a dW written ONCE in the call sequence (a second, accumulating problem on the same dW
               * must use the same tiling to overwrite the same slots: pass NULL for both and reduce that parameter from memory) */
+  int K_valid; /* 0 or K: every reduction row counts.  Else rows [K_valid, K) of dy and x are PADDING of any content
+                * (uninitialised memory included): they are neither read (the loads re-read row K_valid - 1) nor multiplied */
+  int reserved_;
 } hamt_wgrad_desc;
 /* `table`: caller-provided DEVICE scratch (16-byte aligned) that holds the launch table: HAMT_WGRAD_TABLE_ENTRY bytes per
  * entry, at most sum over the problems of ceil(M_p / 64) entries (large problems are cut into bands of tile rows); it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can
  * be captured in a hipGraph.  The table must stay untouched until the launches have run. */
-#define HAMT_WGRAD_TABLE_ENTRY 72
+#define HAMT_WGRAD_TABLE_ENTRY 80
 int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */

@@ -235,9 +235,14 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         # matter: NaN there.  (The 256-square tile's folded bias sums once let a NaN of an out-of-range row into the sums of
         # valid rows: 0 x NaN; the MLM decoder bias, 30 522 = 119 x 256 + 58 rows, caught it in training.)
         dyf[:, 8 * (i % 2) + M:] = float("nan")
-        dy = dyf.to(torch.bfloat16).to(DEV)[:, 8 * (i % 2):8 * (i % 2) + M]   # column slice of a wider buffer
         xf = rnd(K, (max(N, 256) + 8 + 7) // 8 * 8, seed=3 * i + 1)
         xf[:, N:] = float("nan")
+        kv = 0
+        if i % 2 == 1 and valid < K:          # K_valid: the padding rows of BOTH operands may hold anything -- NaN here
+            kv = valid
+            dyf[valid:] = float("nan")
+            xf[valid:] = float("nan")
+        dy = dyf.to(torch.bfloat16).to(DEV)[:, 8 * (i % 2):8 * (i % 2) + M]   # column slice of a wider buffer
         x = xf.to(torch.bfloat16).to(DEV)[:, :N]
         dw0 = rnd(M, N, seed=3 * i + 2)
         db0 = rnd(M, seed=3 * i + 5)
@@ -248,8 +253,10 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if wdb else None)
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = M, N, K, dy.stride(0), x.stride(0), N, aw, ab
         d.ss = ss.data_ptr() if ss is not None else None
-        rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
-        rb = (dy.double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
+        d.K_valid = kv
+        kr = kv if kv else K
+        rw = dy[:kr].double().cpu().t() @ x[:kr].double().cpu() + (dw0.double() if aw else 0)
+        rb = (dy[:kr].double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
         refs.append((dw, db, rw, rb, ss))
     tab = torch.empty(sum((sp[1] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
     L.check(lib.hamt_debug_fill_lds(0x7FC07FC0, ops._stream()), "hamt_debug_fill_lds")     # every CU's LDS = bf16 NaNs: a tile read before its DMA landed shows

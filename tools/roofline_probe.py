@@ -91,6 +91,7 @@ def _wgrad_launcher(items, device):
         d = descs[i]
         d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), (db.data_ptr() if bb is not None else None)
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], 0, 0
+        d.K_valid = wgrad.valid_rows(dy16)
         flops += 2.0 * w.shape[0] * w.shape[1] * dy16.shape[0]
     tab = torch.empty(max(1, wgrad.table_entries(descs, n)) * Lb.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=device)
     keep.append(tab)

@@ -35,6 +35,7 @@ def run(tile=None):
         d = descs[i]
         d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = w.shape[0], w.shape[1], dy16.shape[0], dy16.stride(0), x16.stride(0), w.shape[1], int(acc), int(acc)
+        d.K_valid = wgrad.valid_rows(dy16)
     tab = torch.empty(max(1, wgrad.table_entries(descs, n)) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=dev)
     L.check(lib.hamt_wgrad_grouped(n, descs, tab.data_ptr(), tab.numel(), ops._stream()), "wgrad")
     return outs

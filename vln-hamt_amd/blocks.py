@@ -40,10 +40,15 @@ NO_SHADOW = os.environ.get("HAMT_NO_SHADOW") is not None
 O_DTYPE = torch.float32 if os.environ.get("HAMT_DENSE_OUT_F32") == "1" else torch.bfloat16
 
 
+ZERO_PAD = os.environ.get("HAMT_ZERO_PAD_ROWS") == "1"       # ablation: zero the padding rows as before (one fill launch per buffer)
+
+
 def _zeros_or_empty(rows_total, rows_valid, cols, device, dtype=torch.bfloat16):
-    """buffer whose rows >= rows_valid must read as finite zeros (reduction padding of the k-strided GEMM operands)"""
+    """bf16 image whose rows >= rows_valid are reduction padding of the weight-gradient GEMMs.  Nothing has to be written there:
+    every consumer names the valid rows (`_wgrad` / `_proj_bwd`: hamt_wgrad_desc.K_valid, `gemm(k_valid=)`), the kernels re-read
+    the last valid row for the padding and zero its products -- at B = 16 these fills were 27 launches per step."""
     t = torch.empty(rows_total, cols, dtype=dtype, device=device)
-    if rows_total != rows_valid:
+    if ZERO_PAD and rows_total != rows_valid:
         t[rows_valid:].zero_()
     return t
 
@@ -120,11 +125,11 @@ def _proj_bwd(d16, M, x16, ws, bs, dx_accum_into=None, need_dx=True):
         c = 0
         for w, b in zip(ws, bs):                 # queued: one grouped launch per backward pass (wgrad.py)
             n = w.shape[0]
-            wgrad.defer(w, b, d16[:, c:c + n], x16)
+            wgrad.defer(w, b, d16[:, c:c + n], x16, rows=M)
             c += n
         return dx, [None] * len(ws), [None] * len(ws)
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    gemm(d16, x16, dW, a_kmajor=True, b_kmajor=True)
+    gemm(d16, x16, dW, a_kmajor=True, b_kmajor=True, k_valid=M)
     db = colsum(d16[:M])
     dws, dbs, c = [], [], 0
     for w in ws:
@@ -138,10 +143,10 @@ def _proj_bwd(d16, M, x16, ws, bs, dx_accum_into=None, need_dx=True):
 def _wgrad(w, b, dy16, x16, M):
     """(dW, db) now, or (None, None) after queueing them for the grouped end-of-pass launch"""
     if wgrad.eligible(w, dy16, x16):
-        wgrad.defer(w, b, dy16, x16)
+        wgrad.defer(w, b, dy16, x16, rows=M)
         return None, None
     dw = torch.empty(w.shape, dtype=torch.float32, device=dy16.device)
-    gemm(dy16, x16, dw, a_kmajor=True, b_kmajor=True)
+    gemm(dy16, x16, dw, a_kmajor=True, b_kmajor=True, k_valid=M)
     return dw, (colsum(dy16[:M]) if b is not None else None)
 
 

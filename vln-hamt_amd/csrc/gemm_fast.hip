@@ -168,6 +168,23 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* lds, int r16, int s, int la
   return f.v;
 }
 
+// A K-strided A operand (weight-gradient form: A = dY stored [K][M]) whose reduction rows [kvalid, K) are padding: the DMA
+// re-reads row kvalid - 1 for them (finite values, never beyond the operand), and the fragments of the k-tile that holds the
+// boundary are zeroed HERE for k >= kvalid -- so the padding rows of NEITHER operand need to hold anything in particular (they
+// used to have to be zero in at least one and finite in the other; one uninitialised NaN there is a NaN gradient).  `kbase` =
+// first reduction row of this 32-wide k-step; a lane of group g = lane >> 4 holds k = kbase + 8 g .. + 7 in element order.
+__device__ __forceinline__ bf16x8 mask_k_tail(bf16x8 v, int kbase, int lane, int kvalid) {
+  union { bf16x8 v; uint32_t w[4]; } f;
+  f.v = v;
+  const int k0 = kbase + 8 * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t lo = k0 + 2 * j < kvalid ? 0x0000ffffu : 0u, hi = k0 + 2 * j + 1 < kvalid ? 0xffff0000u : 0u;
+    f.w[j] &= lo | hi;
+  }
+  return f.v;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt();
 template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
@@ -370,6 +387,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       bf16x8 af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = frag<A_KM, BM>(As, wm * TM + i * 16, s, lane);
+      if constexpr (A_KM) {
+        const int kbase = (kt0 + kt) * BK + 32 * s;
+        if (kbase + 32 > g.ka_max + 1) {       // wave-uniform: this k-step crosses the operand's last valid reduction row
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[i] = mask_k_tail(af[i], kbase, lane, g.ka_max + 1);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < FN; ++j) bfr[j] = frag<B_KM, BN>(Bs, wn * TN + j * 16, s, lane);
       __builtin_amdgcn_s_setprio(1);             // the co-resident wave (other workgroup / other half) is in its load phase
@@ -590,10 +614,11 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
 // split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
-constexpr int WG_MAX = 54;                       // table entries carried by one kernarg block (72 bytes each, < 4 KiB)
+constexpr int WG_MAX = 48;                       // table entries carried by one kernarg block (80 bytes each, < 4 KiB)
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db; float* ss;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
+  int kv, pad_;                                  // kv: valid reduction rows (<= K): rows behind are padding of any content
 };
 static_assert(sizeof(WgradProb) == HAMT_WGRAD_TABLE_ENTRY, "HAMT_WGRAD_TABLE_ENTRY");
 struct WgradChunk { WgradProb p[WG_MAX]; };
@@ -624,7 +649,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const Wgrad
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + BNT - 1) / BNT;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
-              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1, 0.f, 0u, nullptr, q.ss};
+              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
   gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, q.K / BK, 0, q.db, q.flags & 2);
 }
 
@@ -798,6 +823,14 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i][s] = frag<A_KM, 128>(buf + 3 * P8_UNIT, 64 * wr + i * 16, s, lane);
     }
+    if constexpr (A_KM) {
+      if (kt * BK + BK > g.ka_max + 1) {       // wave-uniform: the k-tile that holds the last valid reduction row (or lies behind it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i][s] = mask_k_tail(af[i][s], kt * BK + 32 * s, lane, g.ka_max + 1);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (P == 0) {       // A(t): Y1, X1 of k-tile t+1; the next phase reads X1(t)
       if constexpr (MODE < 2) { issue_y(kt + 1, 1); issue_x(kt + 1, 1); p8_wait<8>(); }
@@ -931,7 +964,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_p8_kernel(const WgradProb* 
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + 255) / 256;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
-              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.K - 1, q.K - 1, 0.f, 0u, nullptr, q.ss};
+              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
   p8_tile<-2, true, true, true>(g, (local / tiles_n) * 256, (local % tiles_n) * 256, q.db, q.flags & 2);
 }
 
@@ -1157,6 +1190,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
                    "hamt_wgrad_grouped: problem %d: bad leading dimension (ldy %d, ldx %d, ldw %d)", i, d.ldy, d.ldx, d.ldw);
     HAMT_CHECK_ARG((uintptr_t)d.dy % 16 == 0 && (uintptr_t)d.x % 16 == 0, "hamt_wgrad_grouped: problem %d: operands must be 16-byte aligned", i);
     HAMT_CHECK_ARG(2.0 * d.K * d.ldy < 4294967296.0 && 2.0 * d.K * d.ldx < 4294967296.0, "hamt_wgrad_grouped: problem %d: operands must be smaller than 4 GiB (32-bit DMA offsets)", i);
+    HAMT_CHECK_ARG(d.K_valid >= 0 && d.K_valid <= d.K, "hamt_wgrad_grouped: problem %d: K_valid = %d outside [0, K = %d]", i, d.K_valid, d.K);
     if (d.K > 0) order.push_back(i);
     else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
   }
@@ -1232,7 +1266,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
                                  d.db ? d.db + un.m_lo : nullptr,
                                  d.ss ? d.ss + (size_t)(un.m_lo >> 6) * ((d.N + 127) >> 7) : nullptr,     // (bands start on multiples of 64 rows)
                                  un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
-                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles});
+                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, (d.K_valid > 0 && d.K_valid < d.K) ? d.K_valid : d.K, 0});
       }
       max_tiles = std::max(max_tiles, tiles);
     }

@@ -108,9 +108,11 @@ def _operand(t: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------ raw GEMM
 def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, aux=None, prec="bf16", alpha=1.0,
-         k_red=None, drop=None):
+         k_red=None, drop=None, k_valid=None):
     """out[M,N] = epi(alpha * op(a) @ op(b)); 2-D views with unit inner stride (strided rows allowed).
-    drop = (p, call_id): HAMT_EPI_DROPOUT on the epilogue value (before the residual add)."""
+    drop = (p, call_id): HAMT_EPI_DROPOUT on the epilogue value (before the residual add).
+    k_valid (K-strided operands: the weight-gradient form): only the first k_valid reduction rows count, the rest is padding of any
+    content (the kernels re-read the last valid row instead and zero its products)."""
     _chk(a, "gemm")
     a, b = _operand(a), _operand(b)
     M, N = out.shape
@@ -126,6 +128,9 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=0, au
     d = L.GemmDesc(M, N, K, _ld(a), _ld(b), _ld(out), _ld(aux) if aux is not None else 0, int(a_kmajor), int(b_kmajor),
                    _dt(a), _dt(b), _dt(out), _dt(aux) if aux is not None else 0, _prec(prec),
                    epilogue | (L.EPI_BIAS if bias is not None else 0), alpha, ka if ka < K else 0, kb if kb < K else 0, 0.0, 0, None)
+    if k_valid is not None and k_valid < K:
+        assert a_kmajor and b_kmajor and 0 < k_valid
+        d.ka_rows, d.kb_rows = min(ka, k_valid), min(kb, k_valid)
     if drop is not None and drop[0] > 0.0:
         d.epilogue |= L.EPI_DROPOUT
         d.p_drop, d.call_id, d.rng = float(drop[0]), int(drop[1]), rng_state(out.device).data_ptr()

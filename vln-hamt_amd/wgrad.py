@@ -149,11 +149,20 @@ def eligible(w: torch.Tensor, dy16: torch.Tensor, x16: torch.Tensor) -> bool:
     return True
 
 
-def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: torch.Tensor):
-    """Queue dW (+ db when `b` is a parameter that needs a gradient).  Must be called from inside a backward pass."""
+def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: torch.Tensor, rows: Optional[int] = None):
+    """Queue dW (+ db when `b` is a parameter that needs a gradient).  Must be called from inside a backward pass.
+    `rows`: the valid reduction rows of dy16 / x16 (hamt_wgrad_desc.K_valid); default: all of them count (padding rows zero)."""
     if b is not None and not b.requires_grad:
         b = None
+    if rows is not None:
+        dy16._hamt_rows = int(rows)          # rides on the operand: the queue entries stay (w, b, dy16, x16)
     queue(dy16.device).current().items.append((w, b, dy16, x16))
+
+
+def valid_rows(dy16: torch.Tensor) -> int:
+    """hamt_wgrad_desc.K_valid of a queued operand (0: every row counts)"""
+    r = int(getattr(dy16, "_hamt_rows", 0))
+    return r if 0 < r < dy16.shape[0] else 0
 
 
 def defer_ln_reduce(ws, red, M, H, want_dxsum, pairs):
@@ -336,6 +345,7 @@ def _flush_pass(ps: _Pass, handler):
             d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), tw.stride(0)
             d.accum_dw, d.accum_db = int(bool(aw)), int(bool(ab))
+            d.K_valid = valid_rows(dy16)
             d.ss = (ss_all.data_ptr() + 4 * ss_of[id(tw)]) if (gi == 0 and id(tw) in ss_of) else None
         launch(descs, len(grp))
     if fused:
@@ -430,6 +440,7 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
             d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), w.shape[1]
             d.accum_dw, d.accum_db = aw, ab
+            d.K_valid = valid_rows(dy16)
         plan.groups.append((descs, len(grp)))
         plan.tables.append(torch.empty(max(1, table_entries(descs, len(grp))) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=flat_g.device))
     # arena ranges and the launch group after which each is final
