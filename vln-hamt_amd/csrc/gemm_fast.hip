@@ -823,8 +823,8 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i][s] = frag<A_KM, 128>(buf + 3 * P8_UNIT, 64 * wr + i * 16, s, lane);
     }
-    if constexpr (A_KM) {
-      if (kt * BK + BK > g.ka_max + 1) {       // wave-uniform: the k-tile that holds the last valid reduction row (or lies behind it)
+    if constexpr (A_KM && MODE == 2) {        // (the launcher shrinks K to the 64-row tile that holds the last valid row: only the
+      if (kt * BK + BK > g.ka_max + 1) {       // LAST k-tile can cross it -- masking code in every phase instance spilled registers)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1179,6 +1179,9 @@ extern "C" int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dty
   return HAMT_OK;
 }
 
+static inline int kv_of(const hamt_wgrad_desc& d) { return (d.K_valid > 0 && d.K_valid < d.K) ? d.K_valid : d.K; }
+static inline int keff(const hamt_wgrad_desc& d) { return (kv_of(d) + 63) / 64 * 64; }   // reduction rows actually multiplied
+
 extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream) {
   HAMT_CHECK_ARG(n >= 0 && (n == 0 || probs), "hamt_wgrad_grouped: bad argument");
   std::vector<int> order;
@@ -1200,7 +1203,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   // Two launch classes: problems whose operand rows are >= 256 elements wide can use 256-square tiles; the rest 128 / 64
   // rows.  Within a class: longest reductions first, the short tail tiles fill in behind them.
   std::vector<int> cls[2];
-  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && probs[i].K >= 128) ? 0 : 1].push_back(i);
+  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && keff(probs[i]) >= 128) ? 0 : 1].push_back(i);
   static const int use_p8 = getenv("HAMT_WGRAD_P8") ? atoi(getenv("HAMT_WGRAD_P8")) : 1;   // 0: the one-phase 256-square tile
   const char* fenv = getenv("HAMT_WGRAD_TILE");   // test / tuning override: 256, 128 or 64 (read per call)
   const int force = fenv ? atoi(fenv) : 0;
@@ -1215,7 +1218,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   for (int c = 0; c < 2; ++c) {
     std::vector<int>& v = cls[c];
     if (v.empty()) continue;
-    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return probs[a].K > probs[b].K; });
+    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return keff(probs[a]) > keff(probs[b]); });
     long t128 = 0, t256 = 0;
     for (int i : v) {
       t128 += (long)((probs[i].M + 127) / 128) * ((probs[i].N + 127) / 128);
@@ -1235,7 +1238,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
       for (int r = 0; r < tm; r += band) {
         const int rows = std::min(band * bm, d.M - r * bm);
         const int t = ((rows + bm - 1) / bm) * tn;
-        units.push_back(Unit{i, r * bm, rows, t, (double)t * d.K});
+        units.push_back(Unit{i, r * bm, rows, t, (double)t * keff(d)});
       }
     }
     std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
@@ -1256,7 +1259,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     int max_tiles = 0;
     for (int x = 0; x < 8; ++x) {
       xs.start[x] = (int)flat.size();
-      std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return probs[units[a].prob].K > probs[units[b].prob].K; });
+      std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return keff(probs[units[a].prob]) > keff(probs[units[b].prob]); });
       int tiles = 0;
       for (int u : xq[x]) {
         const Unit& un = units[u];
@@ -1266,7 +1269,8 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
                                  d.db ? d.db + un.m_lo : nullptr,
                                  d.ss ? d.ss + (size_t)(un.m_lo >> 6) * ((d.N + 127) >> 7) : nullptr,     // (bands start on multiples of 64 rows)
                                  un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
-                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, (d.K_valid > 0 && d.K_valid < d.K) ? d.K_valid : d.K, 0});
+                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, kv_of(d), 0});
+        flat.back().K = keff(d);                        // whole k-tiles behind the last valid row are not multiplied at all
       }
       max_tiles = std::max(max_tiles, tiles);
     }
