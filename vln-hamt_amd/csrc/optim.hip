@@ -199,9 +199,32 @@ extern "C" int hamt_sumsq_table(size_t first, size_t n, const float* g, const in
   HAMT_CHECK_LAUNCH("hamt_sumsq_table");
   return HAMT_OK;
 }
+// out (+)= sum of n floats, one block of 1024 threads, four independent 16-byte loads in flight per thread (the ~18 k tile
+// slots of a step's weight gradients: 4 us instead of 15 with the 256-thread scalar loop); fixed order: deterministic
+__global__ __launch_bounds__(1024) void sum_partials_kernel(size_t n, const float* __restrict__ x, float* __restrict__ out, int accumulate) {
+  float s = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = threadIdx.x; i < n4; i += 4096) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = i + (size_t)u * 1024 < n4 ? ((const float4*)x)[i + (size_t)u * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+  }
+  if (threadIdx.x < (n & 3)) s += x[n4 * 4 + threadIdx.x];
+  __shared__ float red[16];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    *out = accumulate ? *out + t : t;
+  }
+}
 extern "C" int hamt_sumsq_partials(size_t n, const float* partials, float* out, int accumulate, void* stream) {
-  HAMT_CHECK_ARG(partials && out && n < (size_t)1 << 30, "hamt_sumsq_partials: bad argument");
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (int)n, partials, out, accumulate);
+  HAMT_CHECK_ARG(partials && out && n < (size_t)1 << 30 && ((uintptr_t)partials % 16) == 0, "hamt_sumsq_partials: bad argument");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, as_stream(stream), n, partials, out, accumulate);
   HAMT_CHECK_LAUNCH("hamt_sumsq_partials");
   return HAMT_OK;
 }

@@ -294,8 +294,19 @@ class AdamW(Optimizer):
             return self._gnorm
         if not torch.cuda.is_current_stream_capturing():
             self._ensure_table()            # (a captured step: the caller refreshes the table before every replay)
-        L.check(L.load().hamt_sumsq_table(0, self._n, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
-                                          _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
+        # two launches: the GEMM-weight region (mostly skipped when the tile sums exist: what is left -- weights written twice in
+        # the pass, ineligible shapes -- is scattered) and the fp32-read region (dense): each gets its own grid, else the few
+        # blocks that own the dense tail of ONE grid do all the reading (measured 102 us for 100 MB)
+        n_a = self._n_shadow_only
+        lib = L.load()
+        if 0 < n_a < self._n:
+            L.check(lib.hamt_sumsq_table(0, n_a, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
+                                         _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
+            L.check(lib.hamt_sumsq_table(n_a, self._n - n_a, _p(self._flat_g[n_a:]), _p(self._ends), _p(self._hyp), len(self._params),
+                                         _p(self._gnorm), 1, _p(self._ws), _stream()), "hamt_sumsq_table")
+        else:
+            L.check(lib.hamt_sumsq_table(0, self._n, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
+                                         _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
         if self._fused is not None:         # the table (flag 3) skipped these: their tiles' sums of squares
             ss = self._fused[0]
             L.check(L.load().hamt_sumsq_partials(ss.numel(), _p(ss), _p(self._gnorm), 1, _stream()), "hamt_sumsq_partials")
