@@ -344,7 +344,8 @@ def main():
                 n2 = args.steps if bsz <= 64 else max(12, args.steps // 2)
                 out["batch_sweep"].append({"per_gpu_batch": bsz, "value": round(smp2 / dt2, 2), "unit": "panorama-steps/s", "steps": n2,
                                            "ms_per_step": round(dt2 / n2 * 1e3, 3), "model_tflops_per_gpu": round(fl2 / dt2 / 1e12, 2),
-                                           "mfma_roofline_frac_end_to_end": round(fl2 / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4)})
+                                           "mfma_roofline_frac_end_to_end": round(fl2 / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                           "state_finite_after_timed_region": bool(torch.isfinite(opt._flat_p).all() and torch.isfinite(opt._flat_m).all())})
                 log(f"batch {bsz}: {dt2 / n2 * 1e3:.3f} ms/step")
                 for k in [k for k in batches if k[2] == bsz]:
                     del batches[k]
