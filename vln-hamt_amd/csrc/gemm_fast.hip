@@ -622,7 +622,7 @@ struct WgradProb {
 };
 static_assert(sizeof(WgradProb) == HAMT_WGRAD_TABLE_ENTRY, "HAMT_WGRAD_TABLE_ENTRY");
 struct WgradChunk { WgradProb p[WG_MAX]; };
-// The problem table lives in caller-provided device memory and is WRITTEN BY KERNELS whose kernargs carry it 60 entries
+// The problem table lives in caller-provided device memory and is WRITTEN BY KERNELS whose kernargs carry it WG_MAX entries
 // at a time: no host buffer has to outlive the call, so the whole sequence is hipGraph-capturable as is.
 __global__ void wgrad_table_write_kernel(WgradChunk c, WgradProb* tab, int off, int cnt) {
   if ((int)threadIdx.x < cnt) tab[off + threadIdx.x] = c.p[threadIdx.x];
