@@ -220,7 +220,9 @@ template <int W> __device__ __forceinline__ void st_f(float* p, const float* v) 
 }
 
 template <int EPI, int W>
-__device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, const float* acc, float* ssq = nullptr) {
+__device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, const float* acc, float* ssq = nullptr,
+                                          const uint4* pre_aux = nullptr, const f32x4* pre_c = nullptr, bool pre_ok = false) {
+  // pre_aux / pre_c (W = 8, pre_ok): this row piece's 8 bf16 of aux / 8 fp32 of C, loaded by the caller ahead of its LDS transpose
   if (row >= g.M || col >= g.N) return;
   const int epi = EPI >= 0 ? EPI : (EPI == -2 ? (g.epi & HAMT_EPI_ACCUM) : g.epi);   // -2: plain store or C += only
   float v[W];
@@ -262,7 +264,11 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
   }
   if (epi & (HAMT_EPI_MUL_AUX | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
     float h[W];
-    if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
+    if (W == 8 && pre_aux && pre_ok) {
+      const uint32_t w4[4] = {pre_aux->x, pre_aux->y, pre_aux->z, pre_aux->w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { h[2 * q] = __uint_as_float(w4[q] << 16); h[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u); }
+    } else if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
     else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
     for (int j = 0; j < W; ++j)
       v[j] *= (epi & HAMT_EPI_MUL_AUX) ? h[j] : ((epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h[j]) : (h[j] > 0.0f ? 1.0f : 0.0f));
@@ -284,7 +290,12 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
   } else {
     float* c = (float*)g.C + ic;
     if (vc) {
-      if (epi & HAMT_EPI_ACCUM) { float p[W]; ld_f<W>(c, p); for (int j = 0; j < W; ++j) v[j] += p[j]; }
+      if (epi & HAMT_EPI_ACCUM) {
+        float p[W];
+        if (W == 8 && pre_c && pre_ok) { for (int j = 0; j < 4; ++j) { p[j] = pre_c[0][j]; p[4 + j] = pre_c[1][j]; } }
+        else ld_f<W>(c, p);
+        for (int j = 0; j < W; ++j) v[j] += p[j];
+      }
       st_f<W>(c, v);
       if (ssq) for (int j = 0; j < W; ++j) *ssq += v[j] * v[j];
     } else for (int j = 0; j < W; ++j) if (col + j < g.N) {
@@ -916,8 +927,29 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   // epilogue: two passes (a0 rows, a1 rows) through this wave's own 16 KiB of LDS: [64][64] fp32, float4 slot ^= row & 7
   float tile_ssq = 0.f;
   float* ct = (float*)lds + w * 4096;
+  // An epilogue that READS (the saved gelu' of `mulaux`) issues the half's eight row-piece loads before
+  // the transpose: inside epi_store each load sits behind the previous piece's store and its latency is paid 16 times per thread.
+  constexpr bool PRE_AUX = EPI >= 0 && (EPI & HAMT_EPI_MUL_AUX) != 0;
+  constexpr bool PRE_C = false;   // the same for the fp32 C of `acc` (16 registers per piece) measured 1 us SLOWER per launch: off
+  const int c8 = lane & 7, col = n0 + p8_index<BGS>(32 * wc + (c8 & 3) * 8, c8 >> 2);
+  bool pre_ok = false;
+  if constexpr (PRE_AUX) pre_ok = col + 8 <= g.N && g.dtype_aux == HAMT_BF16 && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
+  if constexpr (PRE_C) pre_ok = col + 8 <= g.N && g.dtype_c == HAMT_F32 && (g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
+    uint4 pa[PRE_AUX ? 8 : 1];
+    f32x4 pc[PRE_C ? 16 : 2];
+    if constexpr (PRE_AUX || PRE_C) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = m0 + 128 * wr + 64 * h + it * 8 + (lane >> 3);
+        const int rr = row < g.M ? row : g.M - 1;            // (an out-of-range row's piece is loaded from the last row and never used)
+        if constexpr (PRE_AUX) { if (pre_ok) pa[it] = *(const uint4*)((const bf16_t*)g.aux + (size_t)rr * g.ldaux + col); }
+        if constexpr (PRE_C) {
+          if (pre_ok) { const f32x4* cp = (const f32x4*)((const float*)g.C + (size_t)rr * g.ldc + col); pc[2 * it] = cp[0]; pc[2 * it + 1] = cp[1]; }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -925,14 +957,15 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
         const int rl = i * 16 + (lane & 15), c4 = j * 4 + (lane >> 4);
         *(f32x4*)(ct + rl * 64 + ((c4 ^ (rl & 7)) << 2)) = acc[4 * h + i][j];
       }
-    const int c8 = lane & 7, col = n0 + p8_index<BGS>(32 * wc + (c8 & 3) * 8, c8 >> 2);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int rl = it * 8 + (lane >> 3), row = m0 + 128 * wr + 64 * h + rl;
       const f32x4 lo = *(const f32x4*)(ct + rl * 64 + (((2 * c8) ^ (rl & 7)) << 2));
       const f32x4 hi = *(const f32x4*)(ct + rl * 64 + (((2 * c8 + 1) ^ (rl & 7)) << 2));
       const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
+      if constexpr (PRE_AUX) epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr, &pa[it], nullptr, pre_ok);
+      else if constexpr (PRE_C) epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr, nullptr, &pc[2 * it], pre_ok);
+      else epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
     }
   }
   if constexpr (COLSUM) {
