@@ -462,6 +462,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     static_assert(BN == 128, "the staged epilogue is written for 128-column tiles");
     constexpr int RPP = NW * 4;                    // tile rows per pass: 16 threads per row
     float* ct = (float*)lds;
+    const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + RPP p
+    // mulaux reads the saved gelu': all of the thread's row pieces are requested here, ahead of the two barriers and the
+    // transpose (inside epi_store each load waits behind the previous piece's store): 7-8 % on the 64-row FFN-2 dgrads.
+    // (The same for the fp32 C of `acc` and for the bias, here and in the K-group kernel: no measurable difference, not kept.)
+    constexpr bool PRE_AUX = EPI >= 0 && (EPI & HAMT_EPI_MUL_AUX) != 0 && BM / RPP <= 8;
+    uint4 pa[PRE_AUX ? BM / RPP : 1];
+    bool pre_ok = false;
+    if constexpr (PRE_AUX) {
+      pre_ok = g.ksplit <= 1 && col + 8 <= g.N && g.dtype_aux == HAMT_BF16 && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
+#pragma unroll
+      for (int p = 0; p < BM / RPP; ++p) {
+        const int row = m0 + p * RPP + (t >> 4), rr = row < g.M ? row : g.M - 1;
+        if (pre_ok) pa[p] = *(const uint4*)((const bf16_t*)g.aux + (size_t)rr * g.ldaux + col);
+      }
+    }
     __syncthreads();                               // every wave is done reading the last operand tile
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -471,7 +486,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
         *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[i][j];
       }
     __syncthreads();
-    const int c8 = t & 15, col = n0 + c8 * 8;      // this thread's 8 columns; rows (t >> 4) + RPP p
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
       const int rl = p * RPP + (t >> 4), row = m0 + rl;
@@ -484,7 +498,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
           if (col + 8 <= g.N && (g.N & 3) == 0) st_f<8>(P + (size_t)row * g.N + col, v8);
           else for (int e = 0; e < 8; ++e) if (col + e < g.N) P[(size_t)row * g.N + col + e] = v8[e];
         }
-      } else epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
+      } else if constexpr (PRE_AUX) epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr, &pa[p], nullptr, pre_ok);
+      else epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
     }
     if constexpr (COLSUM) { if (g.ss) tile_sumsq_store(g, m0, n0, tile_ssq, (float*)lds); }
   }
