@@ -362,9 +362,16 @@ def main():
                                "traffic": traffic, "traffic_source": src, "kernel": dom["kernel"], "per_step_ms": dom["per_step_ms"],
                                "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                                "algorithmic_work_per_launch": dom["work_per_launch"],
-                               "how": "dominant kernel of the step = largest per-step total among the kernels of one task-mix cycle; its launches are "
-                                      "re-issued (same operands, same epilogues) as a captured hipGraph and timed with HIP events on the launch stream; "
-                                      "work = 2MNK per GEMM launch (30 B per parameter, + 4 where the gradient slot is zeroed, for the AdamW kernel)"}
+                               "how": "dominant kernel of the step = largest per-step total among the kernels of one task-mix cycle.  The grouped "
+                                      "weight-gradient kernel is timed where it runs: one eager forward + backward per task, HIP events recorded on the "
+                                      "launch stream right around each kernel launch (hamt_debug_wgrad_timing; avg_launch_us is per KERNEL launch, the "
+                                      "unit of the rocprofv3 summary in profiles/); back_to_back_ms_per_step = the same problems re-issued back to back "
+                                      "on fresh targets.  GEMM groups / AdamW: re-issued (same operands, same epilogues) as a captured hipGraph, HIP "
+                                      "events on the launch stream.  work = 2MNK per GEMM launch (30 B per parameter, + 4 where the gradient slot is "
+                                      "zeroed, for the AdamW kernel)"}
+            for k_ in ("back_to_back_ms_per_step", "back_to_back_achieved"):
+                if k_ in dom:
+                    out["roofline"][k_] = dom[k_]
             out["kernel_table"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in table[:12]]
             out["roofline_subblock_xattn"] = rp.subblock_xattn(model, args.batch, device)
             out["roofline_probe_xattn"] = time_xattn_probe(args.batch, device)

@@ -291,6 +291,12 @@ int hamt_fill_where_zero(size_t n, const int64_t* flag, float* x, float value, v
 int hamt_extend_mask(size_t n, const void* mask_u8, float* out, void* stream);
 /* test aid: fill the LDS of every CU with `pattern` (a kernel that reads LDS it has not written then shows it) */
 int hamt_debug_fill_lds(uint32_t pattern, void* stream);
+/* measurement aid (bench.py `roofline`): with on != 0 every grouped weight-gradient KERNEL launched eagerly by
+ * hamt_wgrad_grouped is bracketed by HIP events on its launch stream; hamt_debug_wgrad_times waits for them and returns
+ * their number, writing up to `cap` durations (us), tile heights (256 = wgrad_grouped_p8_kernel) and flops (2 M N K over the
+ * launch's table, K = the k-tiles actually multiplied).  Not for captures. */
+int hamt_debug_wgrad_timing(int on);
+int hamt_debug_wgrad_times(float* us, int* tile_rows, double* flops, int cap);
 /* dx = dy * act'(h): mode 1 erf-GELU (vilmodel.py:23-29), mode 2 ReLU (h may be the ReLU output) */
 int hamt_act_bwd(size_t n, const float* dy, const float* h, int mode, float* dx, void* stream);
 

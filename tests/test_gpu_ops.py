@@ -276,6 +276,41 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         L.check(lib.hamt_wgrad_grouped(1, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
 
 
+def test_wgrad_kernel_timing_aid():
+    """hamt_debug_wgrad_timing / _times (bench.py's `roofline`): one bracket per grouped KERNEL launch, positive durations, and
+    the library's own work count = sum 2 M N K over the k-tiles it multiplies (whole 64-row tiles up to K_valid)."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as L
+    ops = _ops()
+    lib = L.load()
+    specs = [(1024, 768, 768, 0), (1024, 768, 3072, 0), (512, 3072, 768, 200), (256, 768, 768, 0)]      # (K, M, N, K_valid)
+    descs = (L.WgradDesc * len(specs))()
+    keep, want = [], 0.0
+    for i, (K, M, N, kv) in enumerate(specs):
+        dy = rnd(K, M, seed=i).to(torch.bfloat16).to(DEV)
+        x = rnd(K, N, seed=10 + i).to(torch.bfloat16).to(DEV)
+        dw = torch.empty(M, N, device=DEV)
+        keep += [dy, x, dw]
+        d = descs[i]
+        d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None
+        d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db, d.K_valid = M, N, K, M, N, N, 0, 0, kv
+        want += 2.0 * M * N * (((kv + 63) // 64 * 64) if kv else K)
+    tab = torch.empty(sum((sp[1] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
+    assert lib.hamt_debug_wgrad_times(None, None, None, 0) == 0
+    L.check(lib.hamt_debug_wgrad_timing(1), "hamt_debug_wgrad_timing")
+    for _ in range(2):
+        L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
+    us, rows, fl = (C.c_float * 16)(), (C.c_int * 16)(), (C.c_double * 16)()
+    n = lib.hamt_debug_wgrad_times(us, rows, fl, 16)
+    assert n >= 2 and n % 2 == 0, n
+    assert all(0.0 < us[i] < 1e5 and rows[i] in (64, 128, 256) for i in range(n)), [(us[i], rows[i]) for i in range(n)]
+    assert abs(sum(fl[i] for i in range(n)) - 2 * want) <= 1e-9 * want, (sum(fl[i] for i in range(n)), 2 * want)
+    L.check(lib.hamt_debug_wgrad_timing(0), "hamt_debug_wgrad_timing")
+    L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
+    assert lib.hamt_debug_wgrad_times(us, rows, fl, 16) == 0          # off: nothing recorded
+    torch.cuda.synchronize()
+
+
 def test_deferred_wgrad_queue_semantics():
     """wgrad.py: queued gradients are published as .grad at the end of backward; a parameter used twice in one pass and
     gradient accumulation over two passes sum like autograd's AccumulateGrad; results equal the immediate path."""

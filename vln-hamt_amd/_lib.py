@@ -105,6 +105,8 @@ SIGNATURES = {
     "hamt_kl_bwd": [i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp],
     "hamt_extend_mask": [sz, vp, vp, vp],
     "hamt_debug_fill_lds": [u32, vp],
+    "hamt_debug_wgrad_timing": [C.c_int],
+    "hamt_debug_wgrad_times": [vp, vp, vp, C.c_int],
     "hamt_a2c_fwd": [i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp],
     "hamt_a2c_bwd": [i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "hamt_sumsq": [sz, vp, vp, i32, vp, vp],

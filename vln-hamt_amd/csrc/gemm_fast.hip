@@ -1230,6 +1230,30 @@ extern "C" int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dty
 static inline int kv_of(const hamt_wgrad_desc& d) { return (d.K_valid > 0 && d.K_valid < d.K) ? d.K_valid : d.K; }
 static inline int keff(const hamt_wgrad_desc& d) { return (kv_of(d) + 63) / 64 * 64; }   // reduction rows actually multiplied
 
+// Measurement aid for bench.py's `roofline` object: per-launch durations of the grouped weight-gradient kernels, taken with HIP
+// events recorded on the launch stream right around each kernel (not around the whole call: the table writes and the other tile
+// class are separate kernels in rocprofv3's summary too).  Eager launches only -- events cannot be read back from a capture.
+struct WgradTimed { hipEvent_t a, b; int bm; double flops; };
+static bool wgrad_timing_on = false;
+static std::vector<WgradTimed> wgrad_timing_ev;
+extern "C" int hamt_debug_wgrad_timing(int on) {
+  for (auto& t : wgrad_timing_ev) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  wgrad_timing_ev.clear();
+  wgrad_timing_on = on != 0;
+  return HAMT_OK;
+}
+// us[i], tile_rows[i], flops[i] (2 M N K over the launch's table, K = the k-tiles actually multiplied) of the launches since hamt_debug_wgrad_timing(1) (waits for them); returns their number (<= cap are written)
+extern "C" int hamt_debug_wgrad_times(float* us, int* tile_rows, double* flops, int cap) {
+  int n = 0;
+  for (auto& t : wgrad_timing_ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.b) != hipSuccess || hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) return -1;
+    if (n < cap) { if (us) us[n] = ms * 1e3f; if (tile_rows) tile_rows[n] = t.bm; if (flops) flops[n] = t.flops; }
+    ++n;
+  }
+  return n;
+}
+
 extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream) {
   HAMT_CHECK_ARG(n >= 0 && (n == 0 || probs), "hamt_wgrad_grouped: bad argument");
   std::vector<int> order;
@@ -1305,6 +1329,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     std::vector<WgradProb> flat;
     flat.reserve(cn);
     int max_tiles = 0;
+    double launch_flops = 0.0;
     for (int x = 0; x < 8; ++x) {
       xs.start[x] = (int)flat.size();
       std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return keff(probs[units[a].prob]) > keff(probs[units[b].prob]); });
@@ -1319,6 +1344,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
                                  un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
                                  (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, kv_of(d), 0});
         flat.back().K = keff(d);                        // whole k-tiles behind the last valid row are not multiplied at all
+        launch_flops += 2.0 * un.m_rows * d.N * keff(d);
       }
       max_tiles = std::max(max_tiles, tiles);
     }
@@ -1330,10 +1356,16 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
       hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, off + b0, cnt);
     }
     const dim3 grid(8 * max_tiles);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (wgrad_timing_on) {     // measurement aid (hamt_debug_wgrad_timing): HIP events around the kernel, on its own stream
+      hipEventCreate(&ev0); hipEventCreate(&ev1);
+      hipEventRecord(ev0, s);
+    }
     if (bm == 256 && use_p8) hipLaunchKernelGGL(wgrad_grouped_p8_kernel, grid, dim3(512), 0, s, tab + off, xs);
     else if (bm == 256) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, tab + off, xs);
     else if (bm == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, tab + off, xs);
     else hipLaunchKernelGGL((wgrad_grouped_kernel<64, 128, 2, 2>), grid, dim3(256), 0, s, tab + off, xs);
+    if (ev0) { hipEventRecord(ev1, s); wgrad_timing_ev.push_back(WgradTimed{ev0, ev1, bm, launch_flops}); }
     HAMT_CHECK_LAUNCH("hamt_wgrad_grouped");
     off += cn;
   }

@@ -235,12 +235,15 @@ class AdamW(Optimizer):
             if p.dim() >= 2:
                 p._hamt_arena16 = (self._flat_p16[o:o + p.numel()].view(p.shape), self._flat_p, ver, p._version)
 
-    def update_bytes(self) -> float:
-        """algorithmic HBM bytes of one update of every parameter: read p, g, m, v + write p, m, v + bf16 shadow = 30 per element,
-        + 4 where the gradient slot is zeroed as well"""
+    def update_bytes(self, active=None) -> float:
+        """algorithmic HBM bytes of one update of every parameter (or of those flagged in `active`, one bool per parameter): read
+        p, g, m, v + write p, m, v + bf16 shadow = 30 per element, + 4 where the gradient slot is zeroed as well"""
         self.materialize()
         sizes = np.diff(np.concatenate([[0], self._ends.cpu().numpy()])).astype(np.float64)
-        return float((sizes * np.where(self._keep == 2.0, 30.0, 34.0)).sum())
+        per = sizes * np.where(self._keep == 2.0, 30.0, 34.0)
+        if active is not None:
+            per = per * np.asarray(active, dtype=np.float64)
+        return float(per.sum())
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow arena from the fp32 masters (after loading / broadcasting parameters in place)."""
