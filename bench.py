@@ -353,9 +353,14 @@ def main():
             cycle = [get_batch(s_) for s_ in range(len(sched.cycle))]
         else:
             cycle = [get_batch(0)]
+        if dist_on:
+            # the probes below run model passes on THIS rank only: a gradient exchange they started would wait for ranks that sit
+            # in the final barrier.  (Found with a 2-rank run at the end of round 2: the bench hung here for any N > 1.)
+            from vln_hamt_amd import parallel as par
+            par.DRY[0] = True
         if not args.no_probes:
             from tools import roofline_probe as rp
-            table = rp.kernel_table(model, opt, cycle, device)
+            table = rp.kernel_table(model, opt, cycle, device, live=not dist_on)
             dom = dict(table[0])                            # the kernel with the largest share of a step
             traffic, src = rp.traffic_of(dom["kernel"], args.batch)
             out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],

@@ -359,3 +359,24 @@ def test_gradient_norm_tracks_gradients_changed_after_the_pass(tiny):
     m(b1, "sap", True).mean().backward()
     m.bert.encoder.layer[0].intermediate.dense.weight.grad = None      # dropped
     check("one gradient dropped")
+
+
+@pytest.mark.parametrize("sharded", ["1", "0"])
+def test_two_rank_bench_with_probes_finishes(tmp_path, sharded):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, default probes) must print its JSON line and exit:
+    rank 0 runs the roofline probes -- model passes of its own -- while the other ranks wait in the final barrier, so the probes
+    must not start a gradient exchange (round 2: they did, and every N > 1 run hung behind the timed region).  Two ranks on the
+    one GPU over gloo (RCCL refuses two ranks per device); the numbers mean nothing here, finishing does."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HAMT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", HAMT_SHARDED=sharded)   # reduce-scatter / all-reduce exchange
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["state_finite_after_timed_region"] is True, line[:600]

@@ -102,9 +102,11 @@ def _wgrad_launcher(items, device):
     return run, flops, n, keep
 
 
-def kernel_table(model, opt, cycle, device):
+def kernel_table(model, opt, cycle, device, live=True):
     """[{kernel, bound, per_step_ms, launches_per_step, avg_launch_us, achieved, unit, frac}] sorted by per-step time.
-    `cycle` = [(task, batch)] of one task-mix cycle (the batches of the timed region)."""
+    `cycle` = [(task, batch)] of one task-mix cycle (the batches of the timed region).  `live`: time the grouped weight-gradient
+    kernel and the update kernel inside one eager step per task (single-process runs only: with a gradient exchange installed a
+    step on ONE rank would start collectives nobody answers); else their back-to-back figures stand in."""
     from vln_hamt_amd import ops
     st = torch.cuda.Stream()
     freq = collections.Counter(t for t, _ in cycle)
@@ -154,6 +156,13 @@ def kernel_table(model, opt, cycle, device):
             # ... and the same kernel where it runs: one eager forward + backward of the task with the pass's own flush (gradient
             # arena targets, tile sums of squares, the pass's launch groups), bracketed the same way.  THIS is the row's time --
             # the launches rocprofv3 sees in the step; the back-to-back figure above is kept beside it.
+            a_ = acc["wgrad_grouped_p8_kernel" if os.environ.get("HAMT_WGRAD_P8", "1") != "0" else "wgrad_grouped_kernel<256, 256, 2, 4>"]
+            if not live:
+                a_["s"] += wt * sum(big) * 1e-6 / reps
+                a_["launches"] += wt * len(big) / reps
+                a_["work"] += wt * big_fl
+                del calls, items, groups, keep
+                continue
             lib.hamt_debug_wgrad_timing(1)
             model(b, task, True).mean().backward()
             torch.cuda.synchronize()
