@@ -177,7 +177,7 @@ def main():
     from vln_hamt_amd import ops
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
     from vln_hamt_amd.optim.misc import NO_DECAY
-    from vln_hamt_amd.parallel import (OverlappedGradSync, ShardedGradSync, TaskSchedule, allreduce_grads, barrier, broadcast_params, default_wire,
+    from vln_hamt_amd.parallel import (TaskSchedule, make_grad_sync, allreduce_grads, barrier, broadcast_params, default_wire,
                                        init_distributed, max_over_ranks, sum_over_ranks)
     from vln_hamt_amd.synth import make_batch, make_itm_rng
 
@@ -205,10 +205,9 @@ def main():
         ng = int(os.environ.get("HAMT_SYNC_GROUPS", 4))
         if os.environ.get("HAMT_NO_OVERLAP"):
             grad_sync = lambda o: allreduce_grads(o, wire)
-        elif os.environ.get("HAMT_SHARDED", "1") != "0" and args.prec == "bf16":
-            grad_sync = ShardedGradSync(opt, n_groups=ng, wire=wire)    # reduce-scatter -> owned-slice AdamW -> all-gather (default)
-        else:
-            grad_sync = OverlappedGradSync(opt, n_groups=ng, wire=wire)  # all-reduce, full AdamW on every rank
+        else:     # bf16 mode: reduce-scatter -> owned-slice AdamW -> all-gather (ShardedGradSync) when the arenas split evenly over the
+            # ranks; else / HAMT_SHARDED=0 / fp32 mode: all-reduce + full AdamW on every rank (OverlappedGradSync)
+            grad_sync = make_grad_sync(opt, args.prec, n_groups=ng, wire=wire)
     net = model
 
     sched = TaskSchedule(cyclic=True) if args.task == "mix" else None

@@ -14,6 +14,8 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
   tiny_finetune.npz   NavCMT language / history / visual modes (incl. no_lang_ca)
   vit.npz             ViT backbone features / gradients from the reference's VisionTransformer class
   collate.npz         outputs of the reference's six *_collate functions on seeded ragged samples
+  r2r_tiny/ + r2r_data.npz   a tiny R2R-style dataset (data files) and what the reference's MultiStepNavData reads / builds from it
+  loader.npz          (task, batch) sequences of the reference's MetaLoader and build_dataloader's loader attributes
 Weights always come from oracle.hamt_oracle.make_state_dict (numpy PCG64), never from random init.
 """
 import hashlib
@@ -504,8 +506,169 @@ def gen_collate():
     print("collate.npz:", len(store), "arrays; oracle restatement bit-exact on", len(COLLATE_CASES), "cases")
 
 
+# ------------------------------------------------------------------------------------------------ N4: readers + loaders
+R2R_TINY = os.path.join(OUT, "r2r_tiny")
+R2R_DIMS = dict(image_feat_size=16, image_prob_size=10, angle_feat_size=4)
+# get_input cases: (trajectory, instruction, t_cur, return_ob, return_hist_img_probs, return_ob_action, return_ob_progress, ob_cand_pano_view)
+R2R_CASES = [(0, 0, 0, True, False, True, True, False), (0, 1, 2, True, True, True, True, False), (0, 0, 3, True, False, True, True, True),
+             (1, 0, 1, False, True, False, False, None), (1, 0, 4, True, True, True, True, False), (1, 0, 4, True, False, True, True, True),
+             (2, 0, 2, True, False, True, True, True), (2, 1, 3, True, True, True, True, False), (3, 0, 1, True, False, True, True, False),
+             (3, 0, 0, True, False, True, False, True)]
+
+
+def make_r2r_tiny():
+    """Write the tiny R2R-style dataset (data, not code): two scans' connectivity files, candidate views per viewpoint, four
+    trajectories (one with a `guide_path`, one longer than max_act_len, one with an over-long instruction) and the view features
+    (float64 [36, feat + prob] per `scan_viewpoint`, the precompute script's dtype).  Deterministic (numpy PCG64)."""
+    import json
+    rng = np.random.Generator(np.random.PCG64(11))
+    os.makedirs(R2R_TINY, exist_ok=True)
+    scans = {"scanA": 7, "scanB": 5}
+    feats, cands, conn = {}, {}, {}
+    for scan, n in scans.items():
+        vps = [f"{scan[-1].lower()}{k:02d}" for k in range(n)]
+        xyz = rng.uniform(-6, 6, size=(n + 1, 3))
+        link = np.zeros((n + 1, n + 1), dtype=bool)
+        for k in range(n - 1):                       # a chain plus a few chords; the extra node is excluded from the graph
+            link[k, k + 1] = link[k + 1, k] = True
+        for a, b in ((0, 2), (1, 4), (2, n - 1)):
+            link[a, b] = link[b, a] = True
+        link[n, 0] = link[0, n] = True
+        nodes = []
+        for k in range(n + 1):
+            pose = [0.0] * 16
+            pose[3], pose[7], pose[11] = (float(v) for v in xyz[k])
+            nodes.append({"image_id": vps[k] if k < n else "excluded", "pose": pose, "included": k < n, "unobstructed": [bool(b) for b in link[k]]})
+        conn[scan] = nodes
+        for k, vp in enumerate(vps):
+            feats[f"{scan}_{vp}"] = rng.standard_normal((36, R2R_DIMS["image_feat_size"] + R2R_DIMS["image_prob_size"]))
+            nb = [j for j in range(n) if link[k, j]]
+            views = rng.choice(36, size=len(nb), replace=False)
+            cands[f"{scan}_{vp}"] = {vps[j]: [int(v), float(rng.uniform(1, 4)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2))]
+                                     for j, v in zip(nb, views)}
+    with open(os.path.join(R2R_TINY, "scans.txt"), "w") as f:
+        f.write("\n".join(scans) + "\n")
+    for scan, nodes in conn.items():
+        with open(os.path.join(R2R_TINY, f"{scan}_connectivity.json"), "w") as f:
+            json.dump(nodes, f)
+    with open(os.path.join(R2R_TINY, "scanvp_cands.json"), "w") as f:
+        json.dump(cands, f)
+    np.savez_compressed(os.path.join(R2R_TINY, "img_fts.npz"), **feats)
+
+    def traj(scan, idxs, n_instr, long_instr=False, guide=None):
+        vps = [f"{scan[-1].lower()}{k:02d}" for k in idxs]
+        act = [cands[f"{scan}_{a}"][b][0] for a, b in zip(vps[:-1], vps[1:])] + [-1]
+        item = {"scan": scan, "path": vps, "path_viewindex": [int(v) for v in rng.integers(0, 36, len(vps))], "action_viewindex": act,
+                "abs_pos_angles": [[float(a), float(b)] for a, b in rng.uniform(-3, 3, (len(vps), 2))],
+                "rel_act_angles": [[float(a), float(b)] for a, b in rng.uniform(-1.5, 1.5, (len(vps), 2))],
+                "instr_ids": [f"{scan}_{idxs[0]}_{j}" for j in range(n_instr)],
+                "instr_encodings": [[101] + [int(t) for t in rng.integers(1996, 29611, (14 if long_instr else 5) + j)] + [102] for j in range(n_instr)]}
+        if guide is not None:
+            item["guide_path"] = [f"{scan[-1].lower()}{k:02d}" for k in guide]
+        return item
+
+    trajs = [traj("scanA", [0, 1, 2, 3], 2), traj("scanA", [0, 2, 6, 5, 4, 3], 1), traj("scanB", [0, 1, 4, 3], 2, long_instr=True),
+             traj("scanB", [1, 2, 3], 1, guide=[1, 4])]
+    with open(os.path.join(R2R_TINY, "traj.jsonl"), "w") as f:
+        for t in trajs[:3]:
+            f.write(json.dumps(t) + "\n")
+    with open(os.path.join(R2R_TINY, "traj2.jsonl"), "w") as f:
+        f.write(json.dumps(trajs[3]) + "\n\n")          # (a blank line at the end: skipped by both readers)
+
+
+def r2r_tiny_kwargs():
+    return dict(traj_files=[os.path.join(R2R_TINY, "traj.jsonl"), os.path.join(R2R_TINY, "traj2.jsonl")], img_ft_file=os.path.join(R2R_TINY, "img_fts.npz"),
+                scanvp_cands_file=os.path.join(R2R_TINY, "scanvp_cands.json"), connectivity_dir=R2R_TINY, max_txt_len=12, max_act_len=6, **R2R_DIMS)
+
+
+def flatten_sample(prefix, out, store):
+    for k, v in out.items():
+        if isinstance(v, list) and len(v) == 0:
+            store[f"{prefix}/{k}/emptylist"] = np.zeros(0)
+        elif isinstance(v, str):
+            store[f"{prefix}/{k}/str"] = np.asarray(v)
+        else:
+            store[f"{prefix}/{k}"] = np.asarray(v)
+
+
+def gen_r2r_data():
+    """Row N4 (readers): the reference's own MultiStepNavData (r2r_data.py) on the tiny dataset -- trajectory index lists, angle
+    tables, shortest distances, `get_input` over R2R_CASES (both observation layouts, history soft labels, progress, truncation
+    by max_act_len / max_txt_len, the STOP step) and the `val_sample_num` subsampling under a fixed numpy seed."""
+    make_r2r_tiny()
+    ref = ref_shim.import_r2r_data(os.path.join(R2R_TINY, "img_fts.npz"))
+    kw = r2r_tiny_kwargs()
+    store = {}
+    for pano in (True, False):
+        db = ref.MultiStepNavData(hist_enc_pano=pano, **kw)
+        tag = "pano" if pano else "nopano"
+        store[f"{tag}/traj_refer"] = np.asarray(db.traj_refer)
+        store[f"{tag}/traj_step_refer"] = np.asarray(db.traj_step_refer)
+        for c, case in enumerate(R2R_CASES):
+            i, j, t, ob, probs, act, prog, cand = case
+            out = db.get_input(i, j, t, return_ob=ob, return_hist_img_probs=probs, return_ob_action=act, return_ob_progress=prog, ob_cand_pano_view=cand)
+            flatten_sample(f"{tag}/case{c}", out, store)
+    store["angle_features"] = np.stack(db.angle_features, 0)
+    store["rel_angles"] = np.stack(db.rel_angles, 0)
+    for scan, d in db.shortest_distances.items():
+        vps = sorted(d)
+        store[f"dist/{scan}"] = np.asarray([[d[a][b] for b in vps] for a in vps])
+    np.random.seed(5)
+    dbv = ref.MultiStepNavData(val_sample_num=4, **kw)
+    store["val/traj_refer"], store["val/traj_step_refer"] = np.asarray(dbv.traj_refer), np.asarray(dbv.traj_step_refer)
+    np.savez_compressed(os.path.join(OUT, "r2r_data.npz"), **store)
+    print("r2r_data.npz:", len(store), "arrays from the reference's MultiStepNavData on tests/golden/r2r_tiny")
+
+
+LOADER_RATIOS = {"mlm": 5, "sap": 1, "itm": 2}
+
+
+def loader_sets():
+    """three tiny index datasets of different lengths: a batch is the list of sample ids it holds"""
+    from torch.utils.data import TensorDataset
+    return {"mlm": TensorDataset(torch.arange(0, 23)), "sap": TensorDataset(torch.arange(100, 107)), "itm": TensorDataset(torch.arange(200, 210))}
+
+
+def loader_opts(**kw):
+    import types
+    d = dict(train_batch_size=4, val_batch_size=3, local_rank=-1, n_workers=0, pin_mem=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def gen_loader():
+    """Row N4 (task-mixing loader): the reference's own MetaLoader / build_dataloader (data/loader.py) under fixed torch seeds:
+    the (task, batch) sequence of 60 steps for accum_steps 1 and 2 (task draws, per-task epoch restarts and reshuffles included)
+    and the attributes of the DataLoaders build_dataloader returns."""
+    ref = ref_shim.import_loader()
+    col = lambda items: torch.stack([it[0] for it in items])
+    store = {}
+    for accum in (1, 2):
+        torch.manual_seed(100 + accum)
+        sets = loader_sets()
+        loaders = {n: (ref.build_dataloader(n, sets[n], col, True, loader_opts())[0], r, (lambda e: None)) for n, r in LOADER_RATIOS.items()}
+        ml = ref.MetaLoader(loaders, accum_steps=accum, distributed=False, device=None)
+        names, flat, lens = [], [], []
+        for step, (task, batch) in enumerate(ml):
+            if step == 60:
+                break
+            names.append(list(LOADER_RATIOS).index(task))
+            flat += batch.tolist()
+            lens.append(len(batch))
+        store[f"accum{accum}/task"], store[f"accum{accum}/ids"], store[f"accum{accum}/lens"] = np.asarray(names), np.asarray(flat), np.asarray(lens)
+    attrs = []
+    for task in ("mlm", "itm"):
+        for train in (True, False):
+            ld, _ = ref.build_dataloader(task, loader_sets()["mlm"], col, train, loader_opts())
+            attrs.append([ld.batch_size, int(type(ld.sampler).__name__ == "RandomSampler"), int(ld.drop_last), ld.num_workers, int(ld.pin_memory)])
+    store["attrs"] = np.asarray(attrs)
+    np.savez_compressed(os.path.join(OUT, "loader.npz"), **store)
+    print("loader.npz:", len(store), "arrays from the reference's MetaLoader / build_dataloader")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "loader"]
     for w in which:
-        {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate}[w]()
+        {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
+         "r2r_data": gen_r2r_data, "loader": gen_loader}[w]()

@@ -179,3 +179,66 @@ def import_collate():
         spec.loader.exec_module(mod)
         out = mod
     return out
+
+
+def import_loader():
+    """-> the reference's pretrain_src/data/loader.py module (MetaLoader, PrefetchLoader, build_dataloader): it imports only torch."""
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location("_ref_loader", os.path.join(REF, "pretrain_src", "data", "loader.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_r2r_data(feature_npz):
+    """-> the reference's pretrain_src/data/r2r_data.py module.  It imports `jsonlines` and `h5py` at module level, neither of
+    which is in this image; two I/O stand-ins are installed for exactly the calls the module makes -- `jsonlines.Reader(f)`
+    (iterate the JSON objects of an open text file) and `h5py.File(path, 'r')` used as a context manager whose items support
+    `[...]` -- the latter served from the numpy archive `feature_npz` (the same arrays the product's reader is given).  No
+    arithmetic of the reference is replaced.  numpy >= 1.24 removed the `np.bool` alias r2r_data.py:232 still uses: restored."""
+    import json
+    import numpy as np
+    sys.dont_write_bytecode = True
+    if not hasattr(np, "bool"):
+        np.bool = np.bool_
+    jl = types.ModuleType("jsonlines")
+
+    class Reader:
+        def __init__(self, f):
+            self.f = f
+
+        def __iter__(self):
+            for ln in self.f:
+                if ln.strip():
+                    yield json.loads(ln)
+
+    jl.Reader = Reader
+    h5 = types.ModuleType("h5py")
+    arrays = dict(np.load(feature_npz))
+
+    class _Item:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, idx):
+            return self.a[idx]
+
+    class File:
+        def __init__(self, path, mode="r"):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def __getitem__(self, key):
+            return _Item(arrays[key])
+
+    h5.File = File
+    sys.modules["jsonlines"], sys.modules["h5py"] = jl, h5
+    spec = importlib.util.spec_from_file_location("_ref_r2r_data", os.path.join(REF, "pretrain_src", "data", "r2r_data.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

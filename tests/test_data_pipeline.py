@@ -1,0 +1,189 @@
+"""Row N4 (input pipeline), CPU: the product's trajectory / view-feature readers, per-sample input builder and task-mixing loader
+against goldens produced by the REFERENCE's own classes (oracle/gen_goldens.py r2r_data / loader: pretrain_src/data/r2r_data.py
+`MultiStepNavData`, data/loader.py `MetaLoader` / `build_dataloader`) on the committed tiny dataset tests/golden/r2r_tiny/."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+TINY = os.path.join(GOLD, "r2r_tiny")
+DIMS = dict(image_feat_size=16, image_prob_size=10, angle_feat_size=4)
+CASES = [(0, 0, 0, True, False, True, True, False), (0, 1, 2, True, True, True, True, False), (0, 0, 3, True, False, True, True, True),
+         (1, 0, 1, False, True, False, False, None), (1, 0, 4, True, True, True, True, False), (1, 0, 4, True, False, True, True, True),
+         (2, 0, 2, True, False, True, True, True), (2, 1, 3, True, True, True, True, False), (3, 0, 1, True, False, True, True, False),
+         (3, 0, 0, True, False, True, False, True)]
+
+
+def _kw(**extra):
+    d = dict(traj_files=[os.path.join(TINY, "traj.jsonl"), os.path.join(TINY, "traj2.jsonl")], img_ft_file=os.path.join(TINY, "img_fts.npz"),
+             scanvp_cands_file=os.path.join(TINY, "scanvp_cands.json"), connectivity_dir=TINY, max_txt_len=12, max_act_len=6, **DIMS)
+    d.update(extra)
+    return d
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(GOLD, "r2r_data.npz")))
+
+
+def _same(got, want, what):
+    want = np.asarray(want)
+    got = np.asarray(got)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if want.dtype.kind in "iub":
+        assert got.dtype.kind in "iub" and np.array_equal(got, want), what                    # index work: bit exact
+    elif want.dtype.kind == "U":
+        assert str(got) == str(want), what
+    else:
+        assert got.dtype == want.dtype or got.ndim == 0, (what, got.dtype, want.dtype)
+        assert np.array_equal(got, want), (what, float(np.abs(got.astype(np.float64) - want).max()))     # same arithmetic: bit exact
+
+
+@pytest.mark.parametrize("pano", [True, False])
+def test_multistep_nav_data_matches_the_reference_class(gold, pano):
+    from vln_hamt_amd.data.r2r_data import MultiStepNavData
+    db = MultiStepNavData(hist_enc_pano=pano, **_kw())
+    tag = "pano" if pano else "nopano"
+    _same(db.traj_refer, gold[f"{tag}/traj_refer"], "traj_refer")
+    _same(db.traj_step_refer, gold[f"{tag}/traj_step_refer"], "traj_step_refer")
+    for c, (i, j, t, ob, probs, act, prog, cand) in enumerate(CASES):
+        out = db.get_input(i, j, t, return_ob=ob, return_hist_img_probs=probs, return_ob_action=act, return_ob_progress=prog, ob_cand_pano_view=cand)
+        keys = {k.split("/")[2] for k in gold if k.startswith(f"{tag}/case{c}/")}
+        assert keys == set(out), (c, keys ^ set(out))
+        for k, v in out.items():
+            base = f"{tag}/case{c}/{k}"
+            if base + "/emptylist" in gold:
+                assert isinstance(v, list) and len(v) == 0, base
+            elif base + "/str" in gold:
+                assert v == str(gold[base + "/str"]), base
+            elif k == "ob_progress":            # distances are sums of float64 edge lengths: equal up to the order of tie-breaking
+                assert abs(float(v) - float(gold[base])) < 1e-9, base
+            else:
+                _same(v, gold[base], base)
+
+
+def test_angle_tables_and_graph_distances(gold):
+    from vln_hamt_amd.data import r2r_data as rd
+    _same(np.stack(rd.get_all_point_angle_feature(4), 0), gold["angle_features"], "angle features")
+    _same(np.stack(rd.get_all_point_rel_angles(), 0), gold["rel_angles"], "relative angles")
+    graphs, dist = rd.load_nav_graphs(TINY)
+    for scan, d in dist.items():
+        vps = sorted(d)
+        assert "excluded" not in d
+        got = np.asarray([[d[a][b] for b in vps] for a in vps])
+        assert np.abs(got - gold[f"dist/{scan}"]).max() < 1e-9, scan
+    assert rd.softmax(np.array([[0.0, 0.0]]))[0, 0] == 0.5
+
+
+def test_validation_subsample_uses_the_global_numpy_stream(gold):
+    from vln_hamt_amd.data.r2r_data import MultiStepNavData
+    np.random.seed(5)
+    db = MultiStepNavData(val_sample_num=4, **_kw())
+    _same(db.traj_refer, gold["val/traj_refer"], "val traj_refer")
+    _same(db.traj_step_refer, gold["val/traj_step_refer"], "val traj_step_refer")
+
+
+def test_view_feature_store_backends(tmp_path):
+    from vln_hamt_amd.data.r2r_data import ViewFeatureStore, read_jsonl
+    arrays = dict(np.load(os.path.join(TINY, "img_fts.npz")))
+    key = sorted(arrays)[3]
+    for k, a in arrays.items():
+        np.save(os.path.join(str(tmp_path), k + ".npy"), a)
+    for store in (ViewFeatureStore(os.path.join(TINY, "img_fts.npz")), ViewFeatureStore(str(tmp_path), in_memory=True)):
+        got = store.get(key)
+        assert got.dtype == np.float32 and np.array_equal(got, arrays[key].astype(np.float32)) and key in store and "nope" not in store
+    assert store.get(key) is store.get(key)                                      # in_memory: cached block
+    # HDF5 is read through h5py, which this image does not ship: the reader must say so, not substitute anything
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            ViewFeatureStore(os.path.join(str(tmp_path), "features.hdf5")).get(key)
+    items = list(read_jsonl(os.path.join(TINY, "traj2.jsonl")))                  # trailing blank line skipped
+    assert len(items) == 1 and items[0]["scan"] == "scanB" and "guide_path" in items[0]
+
+
+# ------------------------------------------------------------------------------------------------ MetaLoader / build_dataloader
+RATIOS = {"mlm": 5, "sap": 1, "itm": 2}
+
+
+def _sets():
+    from torch.utils.data import TensorDataset
+    return {"mlm": TensorDataset(torch.arange(0, 23)), "sap": TensorDataset(torch.arange(100, 107)), "itm": TensorDataset(torch.arange(200, 210))}
+
+
+def _opts(**kw):
+    d = dict(train_batch_size=4, val_batch_size=3, local_rank=-1, n_workers=0, pin_mem=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _col(items):
+    return torch.stack([it[0] for it in items])
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_metaloader_reference_sampling_reproduces_the_reference_sequence(accum):
+    """same torch seed -> the same task draws, batches, epoch restarts and reshuffles as data/loader.py's MetaLoader"""
+    from vln_hamt_amd.data.loader import MetaLoader, build_dataloader
+    g = np.load(os.path.join(GOLD, "loader.npz"))
+    torch.manual_seed(100 + accum)
+    sets = _sets()
+    loaders = {n: (build_dataloader(n, sets[n], _col, True, _opts())[0], r, (lambda e: None)) for n, r in RATIOS.items()}
+    ml = MetaLoader(loaders, accum_steps=accum, distributed=False, device=None)
+    assert ml.sampling == "reference"
+    names, flat, lens = [], [], []
+    for step, (task, batch) in enumerate(ml):
+        if step == 60:
+            break
+        names.append(list(RATIOS).index(task))
+        flat += batch.tolist()
+        lens.append(len(batch))
+    assert names == g[f"accum{accum}/task"].tolist()
+    assert lens == g[f"accum{accum}/lens"].tolist() and flat == g[f"accum{accum}/ids"].tolist()
+
+
+def test_build_dataloader_attributes_match_the_reference():
+    from vln_hamt_amd.data.loader import build_dataloader
+    g = np.load(os.path.join(GOLD, "loader.npz"))
+    attrs = []
+    for task in ("mlm", "itm"):
+        for train in (True, False):
+            ld, pre = build_dataloader(task, _sets()["mlm"], _col, train, _opts())
+            assert pre(3) is None
+            attrs.append([ld.batch_size, int(type(ld.sampler).__name__ == "RandomSampler"), int(ld.drop_last), ld.num_workers, int(ld.pin_memory)])
+    assert attrs == g["attrs"].tolist()
+
+
+def test_metaloader_shared_seed_schedule_needs_no_collective():
+    """distributed default: the task of draw k is a pure function of (seed, k) -- two 'ranks' built independently agree on 400
+    draws without talking, accum_steps repeats a draw, and the mix follows the ratios."""
+    from vln_hamt_amd.data.loader import MetaLoader, build_dataloader
+
+    def tasks(seed, accum, n):
+        sets = _sets()
+        loaders = {k: (build_dataloader(k, sets[k], _col, True, _opts())[0], r, (lambda e: None)) for k, r in RATIOS.items()}
+        ml = MetaLoader(loaders, accum_steps=accum, distributed=True, device=None, seed=seed)      # (no process group: nothing is broadcast)
+        assert ml.sampling == "shared_seed"
+        out = []
+        for step, (task, batch) in enumerate(ml):
+            if step == n:
+                break
+            out.append(task)
+        return out
+
+    torch.manual_seed(1)
+    a = tasks(7, 1, 400)
+    torch.manual_seed(2)            # a different torch stream on the "other rank": irrelevant to the schedule
+    b = tasks(7, 1, 400)
+    assert a == b and tasks(8, 1, 50) != a[:50]
+    frac = a.count("mlm") / len(a)
+    assert abs(frac - 5 / 8) < 0.08, frac
+    c = tasks(7, 2, 40)
+    assert c[0::2] == c[1::2] and c[0::2] == a[:20]

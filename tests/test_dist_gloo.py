@@ -177,9 +177,10 @@ def test_wgrad_plan_invariants_cpu():
 
 
 def test_shard_cuts_invariants():
-    """parallel.shard_cuts: ranges tile the arena, end on 8 * world granules, never move a cut towards an EARLIER-final range,
-    and the bf16- / fp32-gathered region boundary is always a cut."""
-    from vln_hamt_amd.parallel import shard_cuts
+    """parallel.shard_cuts / range_finality: the STATIC ranges tile the arena, end on 8 * world granules, contain the bf16- / fp32-
+    gathered region boundary, depend on nothing but (arena layout, world size) -- so the owner of an element never changes between
+    steps -- and a static range is exchanged no earlier than every weight-gradient launch group that writes into it."""
+    from vln_hamt_amd.parallel import range_finality, shard_cuts
     import random
     rnd = random.Random(0)
     for world in (1, 2, 4, 8):
@@ -187,11 +188,20 @@ def test_shard_cuts_invariants():
         for _ in range(50):
             n = q * rnd.randint(4, 400)
             n_a = q * rnd.randint(0, n // q)
-            bounds = sorted(rnd.sample(range(8, n, 8), min(5, n // 8 - 1)))
-            cuts = shard_cuts(n, n_a, world, bounds)
+            parts = rnd.randint(1, 9)
+            cuts = shard_cuts(n, n_a, world, parts)
+            assert cuts == shard_cuts(n, n_a, world, parts)
             assert cuts[0] == 0 and cuts[-1] == n and n_a in cuts and cuts == sorted(set(cuts))
-            assert all(c % q == 0 for c in cuts)
-            for b in bounds:                                  # the cut that stands for b is the granule boundary at or below it
-                assert (b // q * q) in cuts
-            owned = sum((hi - lo) // world for lo, hi in zip(cuts[:-1], cuts[1:]))
+            assert all(c % q == 0 for c in cuts) and len(cuts) <= parts + 2
+            ranges = list(zip(cuts[:-1], cuts[1:]))
+            owned = sum((hi - lo) // world for lo, hi in ranges)
             assert owned * world == n                          # every element has exactly one owner
+            # a step's plan: arbitrary cut points (they differ from task to task), each plan range final after some launch group
+            pb = [0] + sorted(rnd.sample(range(1, n), min(4, n - 1))) + [n]
+            plan = [(lo, hi, rnd.randint(-1, 3), frozenset(rnd.sample(range(4), rnd.randint(0, 3)))) for lo, hi in zip(pb[:-1], pb[1:])]
+            fin = range_finality(ranges, plan)
+            assert [(lo, hi) for lo, hi, _, _ in fin] == ranges          # ownership is the plan's business in no way
+            for lo, hi, after, touched in fin:
+                for plo, phi, paf, pt in plan:
+                    if plo < hi and phi > lo:
+                        assert after >= paf and set(pt) <= touched

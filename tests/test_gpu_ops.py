@@ -186,6 +186,209 @@ def test_gemm_k_groups(layout, shape, variant):
         close(out, bf16_round(Az).double() @ bf16_round(B).double(), tol, "kg nn ragged K")
 
 
+# The step's own GEMM shapes at the benchmarked per-GPU batch (B = 64: text 5120 rows, panorama 11520, text + vision 7872 ...),
+# each on the kernel the launcher picks for it there, against fp64 products of the same bf16-rounded operands.  The smaller
+# SHAPES above never reach the 256-square two-phase tile (gemm_p8_kernel needs >= ~200 tiles and K >= 128) nor the 128-row plain
+# tile; round 2 shipped a NaN in exactly that family which only a training soak saw.
+BENCH_GEMMS = [   # (layout, M, N, K, epilogue, C dtype, kernel the launcher must pick)
+    ("nt", 5120, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),          # text QKV
+    ("nt", 7872, 2304, 768, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),   # packed QKV over text + vision rows: 279 256-square tiles = two rounds -> plain 128-row tiles
+    ("nt", 11520, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),         # panorama QKV
+    ("nt", 5120, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false>"),    # text FFN-1 (+ saved gelu')
+    ("nt", 11520, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false>"),   # panorama FFN-1
+    ("nt", 5003, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),          # ragged last tile row
+    ("nt", 5120, 2318, 768, "bias", "f32", "gemm_p8_kernel<1, false, false>"),           # ragged last tile column, fp32 C
+    ("nt", 11520, 768, 3072, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),         # panorama FFN-2
+    ("nt", 11520, 768, 3072, "drop_res", "f32", "gemm_p8_kernel<1537, false, false>"),   # bias + dropout + residual (pre-LN ViT form)
+    ("nn", 5120, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),       # dgrad of FFN-2 x gelu'
+    ("nn", 11520, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),
+    ("nn", 11520, 768, 3072, "acc", "f32", "gemm_p8_kernel<8, false, true>"),            # dgrad of FFN-1 into the residual gradient
+    ("nn", 11520, 768, 2304, "acc", "f32", "gemm_p8_kernel<8, false, true>"),            # dgrad of QKV into the residual gradient
+    ("nn", 5120, 2304, 768, "none", "bf16", "gemm_p8_kernel<0, false, true>"),
+    ("nn", 5009, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),       # ragged rows
+    ("nt", 5120, 768, 768, "bias", "bf16", "gemm_fast_kernel<64, 1, false, false>"),     # attention output projection
+    ("nn", 5120, 768, 768, "none", "bf16", "gemm_fast_kernel<64, 0, false, true>"),      # its dgrad
+    ("nt", 2752, 768, 768, "bias", "f32", "gemm_fast_kernel<64, 1, false, false>"),      # vision stream
+    ("nt", 4096, 4096, 64, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),    # 128-row plain tile
+    ("nn", 4096, 4096, 64, "acc", "f32", "gemm_fast_kernel<128, 8, false, true>"),
+    ("nt", 5120, 768, 3072, "bias", "bf16", "gemm_kg_kernel<128, 2, 2, false>"),         # text FFN-2 (K groups)
+    ("nn", 5120, 768, 3072, "acc", "f32", "gemm_kg_kernel<128, 2, 2, true>"),
+]
+
+
+@pytest.mark.parametrize("layout,M,N,K,epi,cdt,kernel", BENCH_GEMMS, ids=[f"{s[0]}-{s[1]}x{s[2]}x{s[3]}-{s[4]}-{s[5]}" for s in BENCH_GEMMS])
+def test_gemm_bench_shapes_vs_fp64(layout, M, N, K, epi, cdt, kernel):
+    ops = _ops()
+    from vln_hamt_amd import _lib as L
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)         # logical [N][K]
+    ref = A.double() @ W.double().t()
+    b = W if layout == "nt" else W.t().contiguous()
+    cd = torch.float32 if cdt == "f32" else torch.bfloat16
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=cd)                          # an unwritten element shows
+    kw = dict(b_kmajor=layout == "nn", prec="bf16")
+    aux = dref = keep_frac = None
+    if epi in ("bias", "gelugrad", "drop_res"):
+        bias = torch.randn(N, device=DEV, generator=g)
+        kw["bias"] = bias
+        ref = ref + bias.double()
+    if epi == "acc":
+        kw["epilogue"] = L.EPI_ACCUM
+        base = torch.randn(M, N, device=DEV, generator=g)
+        out = base.clone() if cdt == "f32" else base.to(torch.bfloat16)
+        ref = ref + out.double()
+    elif epi == "mulaux":
+        aux = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+        kw.update(epilogue=L.EPI_MUL_AUX, aux=aux)
+        ref = ref * aux.double()
+    elif epi == "gelugrad":
+        aux = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        kw.update(epilogue=L.EPI_GELU_GRAD, aux=aux)
+        pre = ref
+        phi = 0.5 * (1 + torch.erf(pre / 2 ** 0.5))
+        ref = pre * phi
+        dref = phi + pre * torch.exp(-0.5 * pre * pre) / (2 * math.pi) ** 0.5
+    elif epi == "drop_res":
+        res = torch.randn(M, N, device=DEV, generator=g)
+        kw.update(epilogue=L.EPI_ADD_AUX, aux=res, drop=(0.1, 4242))
+    ops.gemm(A, b, out, **kw)
+    assert L.last_kernel() == kernel, L.last_kernel()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()), "non-finite / unwritten output elements"
+    # fp32 accumulation of K bf16 products: 2e-5 sqrt(K)/4 of the scale (as the small-shape tests); + bf16 rounding of a bf16 C
+    tol = 2e-5 * math.sqrt(K) / 4 + (2 ** -8 if cdt == "bf16" else 0.0)
+    if epi == "drop_res":
+        y = out.double() - res.double()
+        kept = y != 0
+        keep_frac = float(kept.double().mean())
+        assert abs(keep_frac - 0.9) < 2e-3, keep_frac
+        close(torch.where(kept, y, torch.zeros_like(y)), torch.where(kept, ref / 0.9, torch.zeros_like(ref)), 3 * tol, f"{kernel} dropout + residual")
+    else:
+        close(out, ref, tol, f"{kernel} {layout} {M}x{N}x{K} {epi}")
+    if dref is not None:
+        assert bool(torch.isfinite(aux).all())
+        close(aux, dref, 2 ** -7, f"{kernel} saved gelu'")
+
+
+def _ref_ln(x, g, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def _ref_attn(q, k, v, add_mask, heads):
+    B, Sq, H = q.shape
+    Sk, dh = k.shape[1], H // heads
+    qh, kh, vh = (t.view(B, -1, heads, dh).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if add_mask is not None:
+        s = s + add_mask.view(B, 1, 1, Sk)
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Sq, H)
+
+
+def _grad_report(named, ref_grads, what, cos_min, probe_tol):
+    """bf16 block gradients against fp64 autograd: global cosine over all parameters + per-tensor relative error."""
+    num = den_a = den_b = 0.0
+    # (a key bias has NO gradient mathematically -- softmax is invariant to a per-query shift of the scores -- so errors are taken
+    # relative to max(||ref||, 5 % of the largest gradient norm among tensors of the same rank))
+    gmax = {d: max(float(rg.norm()) for (_, p), rg in zip(named, ref_grads) if p.dim() == d) for d in {p.dim() for _, p in named}}
+    for (name, p), rg in zip(named, ref_grads):
+        assert p.grad is not None, f"{what}: {name} has no gradient"
+        g = p.grad.double()
+        assert bool(torch.isfinite(g).all()), f"{what}: {name} gradient not finite"
+        num += float((g * rg).sum()); den_a += float((g * g).sum()); den_b += float((rg * rg).sum())
+        rel = float((g - rg).norm()) / max(float(rg.norm()), 0.05 * gmax[p.dim()])
+        assert rel <= probe_tol, f"{what}: {name} ||g - ref|| / ||ref|| = {rel:.3e}"
+    cos = num / math.sqrt(den_a * den_b)
+    assert cos >= cos_min, f"{what}: gradient cosine {cos:.6f}"
+
+
+@pytest.mark.parametrize("B,S", [(64, 80), (320, 36)])       # the step's text stream (5120 rows) and its panorama encoder (64 x 5 panoramas x 36 views = 11520 rows)
+def test_bert_layer_block_at_bench_rows_vs_fp64(B, S):
+    """SelfAttnBlockFn + FfnBlockFn (BertLayer, vilmodel.py:188-201) forward + backward at the bench's row counts -- the shapes
+    whose GEMMs run on gemm_p8_kernel / gemm_kg_kernel<128, ...> / gemm_fast_kernel<64, ...> and whose weight gradients run on
+    the grouped 256-square tile -- against an fp64 torch restatement with the same (bf16-rounded) weights."""
+    from vln_hamt_amd.model import vilmodel
+    from vln_hamt_amd.modeling import HamtConfig
+    from vln_hamt_amd import _lib as L
+    H = 768
+    torch.manual_seed(7)
+    layer = vilmodel.BertLayer(HamtConfig(hamt_precision="bf16")).to(DEV).eval()       # eval: dropout off, same kernels
+    for n, p in layer.named_parameters():
+        with torch.no_grad():
+            p.copy_(torch.randn_like(p) * (0.03 if p.dim() == 2 else 0.1) + (1.0 if "LayerNorm.weight" in n else 0.0))
+            if p.dim() == 2:
+                p.copy_(p.to(torch.bfloat16).float())        # weights exactly representable: the comparison isolates the kernels
+    x = torch.randn(B, S, H, device=DEV).requires_grad_()
+    lens = torch.randint(S // 2, S + 1, (B,), device=DEV)
+    add_mask = ((torch.arange(S, device=DEV)[None] >= lens[:, None]).float() * -10000.0).view(B, 1, 1, S)
+    dy = torch.randn(B, S, H, device=DEV)
+    (y,) = layer(x, add_mask)
+    (y * dy).sum().backward()
+    torch.cuda.synchronize()
+
+    P = {n: p.detach().double().requires_grad_() for n, p in layer.named_parameters()}
+    xd = x.detach().double().requires_grad_()
+    lin = lambda t, n: t @ P[n + ".weight"].t() + P[n + ".bias"]
+    q, k, v = (lin(xd, "attention.self." + n) for n in ("query", "key", "value"))
+    a = _ref_attn(q, k, v, add_mask.double(), 12)
+    h1 = _ref_ln(lin(a, "attention.output.dense") + xd, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], 1e-12)
+    f = F.gelu(lin(h1, "intermediate.dense"))
+    yr = _ref_ln(lin(f, "output.dense") + h1, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], 1e-12)
+    (yr * dy.double()).sum().backward()
+    close(y, yr, 1e-2, f"BertLayer forward B={B} S={S}")            # north_star: <= 1e-2 for bf16 activations
+    assert bool(torch.isfinite(x.grad).all())
+    rel = float((x.grad.double() - xd.grad).norm() / xd.grad.norm())
+    assert rel <= 2e-2, f"dx relative error {rel:.3e}"
+    named = list(layer.named_parameters())
+    _grad_report(named, [P[n].grad for n, _ in named], f"BertLayer B={B} S={S}", 0.9995, 3e-2)
+
+
+def test_cross_attention_block_at_bench_rows_vs_fp64():
+    """CrossAttnBlockFn + KvProjFn (BertXAttention, vilmodel.py:351-360) in both directions with the SHARED weights, at the
+    x-layers' own shapes (80 text tokens x 43 history + observation tokens, B = 64), forward + backward against fp64."""
+    from vln_hamt_amd.model import vilmodel
+    from vln_hamt_amd.modeling import HamtConfig
+    B, Sl, Sv, H = 64, 80, 43, 768
+    torch.manual_seed(11)
+    xa = vilmodel.BertXAttention(HamtConfig(hamt_precision="bf16")).to(DEV).eval()
+    for n, p in xa.named_parameters():
+        with torch.no_grad():
+            p.copy_(torch.randn_like(p) * (0.03 if p.dim() == 2 else 0.1) + (1.0 if "LayerNorm.weight" in n else 0.0))
+            if p.dim() == 2:
+                p.copy_(p.to(torch.bfloat16).float())
+    xl = torch.randn(B, Sl, H, device=DEV).requires_grad_()
+    xv = torch.randn(B, Sv, H, device=DEV).requires_grad_()
+    ll = torch.randint(Sl // 2, Sl + 1, (B,), device=DEV)
+    lv = torch.randint(7, Sv + 1, (B,), device=DEV)
+    ml = ((torch.arange(Sl, device=DEV)[None] >= ll[:, None]).float() * -10000.0).view(B, 1, 1, Sl)
+    mv = ((torch.arange(Sv, device=DEV)[None] >= lv[:, None]).float() * -10000.0).view(B, 1, 1, Sv)
+    dl, dv = torch.randn(B, Sl, H, device=DEV), torch.randn(B, Sv, H, device=DEV)
+    yl = xa(xl, xv, ctx_att_mask=mv)
+    yv = xa(xv, xl, ctx_att_mask=ml)
+    ((yl * dl).sum() + (yv * dv).sum()).backward()
+    torch.cuda.synchronize()
+
+    P = {n: p.detach().double().requires_grad_() for n, p in xa.named_parameters()}
+    xld, xvd = xl.detach().double().requires_grad_(), xv.detach().double().requires_grad_()
+    lin = lambda t, n: t @ P[n + ".weight"].t() + P[n + ".bias"]
+
+    def ref(x, c, m):
+        a = _ref_attn(lin(x, "att.query"), lin(c, "att.key"), lin(c, "att.value"), m.double(), 12)
+        return _ref_ln(lin(a, "output.dense") + x, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], 1e-12)
+
+    rl, rv = ref(xld, xvd, mv), ref(xvd, xld, ml)
+    ((rl * dl.double()).sum() + (rv * dv.double()).sum()).backward()
+    close(yl, rl, 1e-2, "cross attention lang <- vis")
+    close(yv, rv, 1e-2, "cross attention vis <- lang")
+    for got, want, nm in ((xl.grad, xld.grad, "dlang"), (xv.grad, xvd.grad, "dvis")):
+        rel = float((got.double() - want).norm() / want.norm())
+        assert rel <= 2e-2, f"{nm} relative error {rel:.3e}"
+    named = list(xa.named_parameters())
+    _grad_report(named, [P[n].grad for n, _ in named], "BertXAttention both directions", 0.9995, 3e-2)
+
+
 def test_gemm_tr_read_matches_scalar_fallback():
     """ds_read_b64_tr_b16 fragment path == scalar LDS gather path (HAMT_NO_TR=1), bit for bit."""
     code = r"""

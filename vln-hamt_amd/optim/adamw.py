@@ -157,6 +157,8 @@ class AdamW(Optimizer):
         self._table_ready = False   # the device table already describes the step whose gradients are packed now
         self._table_lrs = None
         self._fused = None          # (partial sums tensor, parameter index array): gradients whose sum of squares wgrad.py already has
+        self._sharded_sync = None   # parallel.ShardedGradSync attached to this optimizer (state lives sharded over the ranks)
+        self._shard_stale = False
 
     # ---------------------------------------------------------------- arenas
     def _build(self):
@@ -506,6 +508,10 @@ class AdamW(Optimizer):
         (copies of the arena slots), plus param_groups -- what ModelSaver writes to train_state_*.pt."""
         if not self._built:
             return super().state_dict()
+        if getattr(self, "_shard_stale", False):
+            raise RuntimeError("AdamW.state_dict(): the optimizer state is sharded over the ranks (parallel.ShardedGradSync) and this rank's "
+                               "copy of the other ranks' exp_avg / exp_avg_sq / fp32 masters is out of date: call grad_sync.gather_state() "
+                               "on EVERY rank first")
         self.wait_update()
         self.state.clear()
         for i, (p, o) in enumerate(zip(self._params, self._offs)):

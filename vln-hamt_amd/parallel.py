@@ -154,6 +154,9 @@ def allreduce_grads(optimizer, wire: str | None = None) -> None:
     (the grouped weight gradients are already there) and all-reduce the arena.  Call between backward and clip/step."""
     if not optimizer._packed:
         optimizer._pack_grads()
+    # the per-tile sums of squares the weight-gradient launch left (optim.AdamW.note_fused_sumsq) describe THIS rank's gradients
+    # before the average; the collective rewrites the arena through raw pointers, which no version counter sees
+    optimizer.clear_fused_sumsq()
     allreduce_mean_(optimizer._flat_g, wire=wire or default_wire("fp32"))
 
 
@@ -266,17 +269,56 @@ class OverlappedGradSync:
         allreduce_grads(optimizer, self.wire)
 
 
-def shard_cuts(n: int, n_a: int, world: int, bounds):
-    """Range boundaries for the sharded exchange: the plan's arena cut points `bounds` (ascending, inside (0, n)) rounded DOWN to
-    multiples of 8 * world (a cut may only move towards the range that becomes final LATER), plus the region boundary `n_a`
-    (bf16-gathered | fp32-gathered).  Returns sorted unique cut points including 0 and n; every range then splits into `world`
-    equal chunks of whole 8-element granules."""
+def shard_cuts(n: int, n_a: int, world: int, parts: int = 8):
+    """STATIC range boundaries of the sharded exchange: the GEMM-weight region [0, n_a) (all-gathered as bf16) in `parts` ranges of
+    equal size rounded down to multiples of 8 * world, the fp32-read region [n_a, n) as one range.  Returns sorted unique cut
+    points including 0 and n; every range splits into `world` equal chunks of whole 8-element granules, rank r owns chunk r.
+    The cuts depend on nothing but the arena layout and the world size: ownership of an element -- and with it the only valid
+    copy of its exp_avg / exp_avg_sq / fp32 master -- never moves between steps, tasks or batch shapes (a first version cut at
+    each step's weight-gradient group boundaries, which differ from task to task: elements changed owner and the new owner
+    applied AdamW to stale moments)."""
     q = 8 * world
     assert n % q == 0 and n_a % q == 0, (n, n_a, world)
     cuts = {0, n, n_a}
-    for b in bounds:
-        cuts.add(b // q * q)
+    for k in range(1, max(1, parts)):
+        cuts.add((n_a * k // parts) // q * q)
     return sorted(c for c in cuts if 0 <= c <= n)
+
+
+def range_finality(static_ranges, plan_ranges):
+    """[(lo, hi, after_group, groups)] for the static ranges of the sharded exchange under one step's weight-gradient plan
+    (`wgrad.Plan.ranges`, same tuple layout): a static range is final once every plan range that overlaps it is."""
+    out = []
+    for lo, hi in static_ranges:
+        touched, after = set(), -1
+        for (plo, phi, paf, pt) in plan_ranges:
+            if plo < hi and phi > lo:
+                touched |= set(pt)
+                after = max(after, paf)
+        out.append((lo, hi, after, touched))
+    return out
+
+
+def shardable(optimizer, world: int) -> bool:
+    """Can the arenas be split into 8-element granules over `world` ranks?  (Region ends are multiples of optim.adamw.REGION_ALIGN =
+    512 elements: true whenever 8 * world divides 512, i.e. world in {1, 2, 4, 8, 16, 32, 64}.)"""
+    o = optimizer.materialize()
+    return o._n % (8 * world) == 0 and o._n_shadow_only % (8 * world) == 0
+
+
+def make_grad_sync(optimizer, prec: str = "bf16", n_groups: int = 4, wire: str | None = None, sharded: bool | None = None):
+    """The gradient exchange for this process group: ShardedGradSync (reduce-scatter, owned-slice AdamW, all-gather) in bf16 mode
+    when the arenas split evenly over the ranks, else OverlappedGradSync (all-reduce, full AdamW on every rank)."""
+    wire = wire or default_wire(prec)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if sharded is None:
+        sharded = os.environ.get("HAMT_SHARDED", "1") != "0" and prec == "bf16"
+    if sharded and not shardable(optimizer, world):
+        import warnings
+        warnings.warn(f"vln_hamt_amd.parallel: 8 x world size ({world}) does not divide the arena regions (multiples of 512 elements); "
+                      "using the all-reduce exchange (OverlappedGradSync) instead of the sharded one")
+        sharded = False
+    return (ShardedGradSync if sharded else OverlappedGradSync)(optimizer, n_groups=n_groups, wire=wire)
 
 
 class ShardedGradSync(OverlappedGradSync):
@@ -288,12 +330,15 @@ class ShardedGradSync(OverlappedGradSync):
         -> clip + AdamW over the owned slices only (1/world of the update traffic)
         -> all-gather: the bf16 shadow for the GEMM-weight region (what forward / backward read), fp32 for the rest
 
-    Rank r owns chunk r of every range (ranges end on multiples of 8 * world elements, optim.adamw.REGION_ALIGN).  Bytes per GPU on
+    Rank r owns chunk r of every range of a STATIC partition of the arena (`shard_cuts`: fixed at construction, the same for every
+    task / batch shape / step, so exp_avg, exp_avg_sq and the fp32 master of an element live on one rank for the whole run; a
+    range is exchanged as soon as every weight-gradient launch group of the step that writes into it is done).  Bytes per GPU on
     the wire with the bf16 format: (world-1)/world x (2 B/param reduce-scatter + 2 B/param all-gather of the weights + 4 B/param
     of the ~14 % fp32-read parameters) -- about the bf16 all-reduce's -- while the update's HBM traffic drops by `world`.
     Gradient slots of parameters without a gradient hold zeros on every rank (DDP find_unused_parameters=True semantics,
     utils/misc.py:57-58): a range is zeroed right after its reduce-scatter and only the owned, reduced chunk is written back.
-    fp32 masters of GEMM weights this rank does not own are NOT kept current (nobody reads them: `gather_masters()` before saving)."""
+    fp32 masters of GEMM weights and the moments of everything this rank does not own are NOT kept current (nobody reads them):
+    `gather_state()` on EVERY rank before `state_dict()` / checkpointing (the optimizer's state_dict refuses otherwise)."""
 
     sharded = True
 
@@ -303,12 +348,22 @@ class ShardedGradSync(OverlappedGradSync):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.gloo = dist.is_initialized() and dist.get_backend() != "nccl"
         o = optimizer.materialize()
-        assert o._n % (8 * self.world) == 0 and o._n_shadow_only % (8 * self.world) == 0
+        if not shardable(o, self.world):
+            raise ValueError(f"ShardedGradSync: 8 x world size ({self.world}) must divide the arena regions ({o._n_shadow_only}, {o._n} elements); "
+                             "use parallel.make_grad_sync, which falls back to OverlappedGradSync")
+        cuts = shard_cuts(o._n, o._n_shadow_only, self.world, int(os.environ.get("HAMT_SHARD_PARTS", 8)))
+        self._ranges = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]      # static: see shard_cuts
+        o._sharded_sync = self
+        o._shard_stale = False             # True: moments / masters of foreign chunks are out of date (gather_state() clears)
         self._stage = torch.empty(o._n, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
         self._own16 = torch.empty(o._n // self.world + 8, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
         self._own32 = torch.empty(o._n // self.world + 8, dtype=torch.float32, device=o._flat_g.device)
         self._gsq = torch.zeros(1, dtype=torch.float32, device=o._flat_g.device)
-        self._ranges = None                # [(lo, hi)] of the last exchange
+
+    def close(self):
+        super().close()
+        if getattr(self.opt, "_sharded_sync", None) is self:
+            self.opt._sharded_sync = None
 
     # ---- collectives (gloo has neither reduce_scatter nor all_gather_into_tensor: same arithmetic through all_reduce / all_gather)
     def _reduce_scatter(self, out, inp):
@@ -357,19 +412,10 @@ class ShardedGradSync(OverlappedGradSync):
     def run(self, plan):
         """The plan's groups with the reduce-scatters on the communication stream (same overlap structure as the parent)."""
         from . import wgrad
-        o = self.opt
         main = torch.cuda.current_stream()
-        cuts = shard_cuts(o._n, o._n_shadow_only, self.world, [r[0] for r in plan.ranges if r[0] > 0])
-        # a (cut) range is final once every plan range that overlaps it is
-        rng = []
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            touched, after = set(), -1
-            for (plo, phi, paf, pt) in plan.ranges:
-                if plo < hi and phi > lo:
-                    touched |= set(pt)
-                    after = max(after, paf)
-            rng.append((lo, hi, after, touched))
-        self._ranges = [(lo, hi) for lo, hi, _, _ in rng]
+        rng = getattr(plan, "_shard_rng", None)
+        if rng is None:
+            rng = plan._shard_rng = range_finality(self._ranges, plan.ranges)
         pending = sorted(rng, key=lambda r: r[2])
         k, done = 0, []
 
@@ -408,11 +454,9 @@ class ShardedGradSync(OverlappedGradSync):
         if self.done:
             self.done = False
             return
-        # no queued GEMM gradients in this pass (fp32 mode / nothing deferred): exchange the whole arena as one range per region
+        # no queued GEMM gradients in this pass (fp32 mode / nothing deferred): exchange the arena range by range, same ownership
         if not optimizer._packed:
             optimizer._pack_grads()
-        o = self.opt
-        self._ranges = [(lo, hi) for lo, hi in zip(*(lambda c: (c[:-1], c[1:]))(shard_cuts(o._n, o._n_shadow_only, self.world, [])))]
         for lo, hi in self._ranges:
             self._exchange_range(lo, hi)
 
@@ -452,14 +496,22 @@ class ShardedGradSync(OverlappedGradSync):
         if o._n > n_a:                                                # bf16 images of the >= 2-D fp32-read parameters (tied MLM decoder ...)
             L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
         o.mark_updated()
+        o._shard_stale = self.world > 1
 
     @torch.no_grad()
-    def gather_masters(self):
-        """Make every rank's fp32 masters of the GEMM-weight region current (before state_dict() / checkpointing)."""
+    def gather_state(self):
+        """Collective (call on EVERY rank, e.g. right before rank 0 saves -- utils/save.py:42-45 writes model and
+        optimizer.state_dict() from one rank): make the fp32 masters of the GEMM-weight region and exp_avg / exp_avg_sq of the
+        whole arena current on every rank."""
         o = self.opt
-        for lo, hi in (self._ranges or []):
+        for lo, hi in self._ranges:
             if hi <= o._n_shadow_only:
                 self._all_gather_inplace(o._flat_p[lo:hi])
+            self._all_gather_inplace(o._flat_m[lo:hi])
+            self._all_gather_inplace(o._flat_v[lo:hi])
+        o._shard_stale = False
+
+    gather_masters = gather_state          # (round-2 name)
 
 
 def broadcast_params(optimizer, src: int = 0) -> None:
