@@ -170,6 +170,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-probes", action="store_true", help="only the timed steps (for rocprofv3 runs: no probe launches in the kernel statistics)")
+    ap.add_argument("--ragged", action="store_true", help="headline run on ragged batches (SURVEY 8d: L ~ U[20, 80], T ~ U[0, 7] per sample, padded to the "
+                    "batch maximum as the reference's collate does) instead of full-length ones; without the flag the ragged variant is reported "
+                    "next to `batch_sweep` as `ragged`")
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each: the first is `value` (the contract's K steps), all of "
+                    "them are reported in `regions_ms_per_step` with their min / median")
     ap.add_argument("--also-batch", type=int, default=-1, help="another per-GPU batch reported in `batch_sweep` (default: 16 -- the reference's "
                     "per-GPU batch -- and 256 when --batch is left at 64 on one GPU; 0 = none)")
     args = ap.parse_args()
@@ -214,17 +219,29 @@ def main():
     n_distinct = 12
     batches = {}
 
+    ragged_mode = [bool(args.ragged)]
+    sample_flops = {}                                   # batch key -> 3 x forward FLOPs summed over the batch's samples at THEIR lengths
+
     def get_batch(step, bsz=None):
         bsz = bsz or args.batch
         task = sched.task_at(step) if sched else args.task
-        key = (task, step % n_distinct, bsz)
+        rg = ragged_mode[0]
+        key = (task, step % n_distinct, bsz) + (("ragged",) if rg else ())
         if key not in batches:                          # synthetic inputs resident in HBM before the timed region
             b = make_batch(task, bsz, cfg, seed=1234 + rank + 7919 * (step % n_distinct), txt_len=L_TXT,
-                           hist_len=T_HIST, mlm_exact=12 if task == "mlm" else None, device=device)
+                           hist_len=7 if rg else T_HIST, ragged=rg, mlm_exact=12 if (task == "mlm" and not rg) else None, device=device)
             if task == "itm":
                 r = make_itm_rng(b, seed=step)
                 b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
             batches[key] = b
+            if rg:      # algorithmic work of a ragged batch: every sample at its own instruction / history length
+                ls = b["txt_masks"].sum(1).tolist()
+                ts = (b["hist_masks"].sum(1) - 1).tolist() if b.get("hist_masks") is not None else [0] * len(ls)
+                nm = int(b["txt_label_idx"].numel()) if task == "mlm" else 0
+                sample_flops[key] = 3.0 * (sum(trunk_fwd_flops(task, int(l), int(t)) - (2 * 12 * H * 30522 + 2 * 12 * H * H if task == "mlm" else 0)
+                                               for l, t in zip(ls, ts)) + 2 * nm * H * (30522 + H))
+            else:
+                sample_flops[key] = 3.0 * trunk_fwd_flops(task) * b["txt_ids"].shape[0]
         return task, batches[key]
 
     log("generating synthetic batches")
@@ -246,7 +263,7 @@ def main():
             lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
             for g in opt.param_groups:
                 g["lr"] = lr
-            key = (task, step % n_distinct, bsz)
+            key = (task, step % n_distinct, bsz) + (("ragged",) if ragged_mode[0] else ())
             graphed.step(key, b, task)
             # the bench's inputs are resident in HBM: keep working on the captured step's own static input tensors (a
             # loader would write each new batch into them; GraphedTrainStep.step copies any other batch in)
@@ -289,7 +306,7 @@ def main():
         for s in range(warmup, warmup + steps):
             task, n = train_step(s, bsz)
             samples += n
-            flops += 3.0 * trunk_fwd_flops(task) * n
+            flops += sample_flops[(task, s % n_distinct, bsz) + (("ragged",) if ragged_mode[0] else ())]
         if graphed is not None:
             graphed.finish()                 # the last step's parameter update (overlap_update: a replay applies the previous step's)
         torch.cuda.synchronize()
@@ -299,6 +316,11 @@ def main():
 
     dt, samples, flops = timed_region(args.batch, args.warmup, args.steps)
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
+    # the driver's K may be small (20 steps = 0.2 s): repeat the region so that box-to-box / run-to-run spread is visible
+    regions = [dt / args.steps * 1e3]
+    for _ in range(max(0, args.regions - 1)):
+        dt_r, _, _ = timed_region(args.batch, 0, args.steps, verbose=False)
+        regions.append(dt_r / args.steps * 1e3)
     exposed_comm_ms = None
     if dist_on and not args.no_probes:
         # the same steps with the collectives themselves skipped (every rank keeps its own values: timing only, after the measurement):
@@ -320,7 +342,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "R2R 6-proxy-task pretrain step (fwd+bwd+clip+AdamW, dropout 0.1), fixed ViT features, "
                                    "R2R-canon model 174.8M params" if args.task == "mix" else f"R2R {args.task} pretrain step",
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": L_TXT, "hist_len": T_HIST,
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "txt_len": "U[20,80]" if args.ragged else L_TXT,
+                       "hist_len": "U[0,7]" if args.ragged else T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
                        "parallelism": f"dp{world}" + (f" (flat-arena {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} " + ("reduce-scatter + owned-slice AdamW + all-gather" if getattr(grad_sync, "sharded", False) else "all-reduce") + f", {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
                        "launch": "hipGraph replay" if graphed is not None else "eager"},
@@ -329,6 +352,8 @@ def main():
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
             "exposed_comm_ms_per_step": exposed_comm_ms,
+            "regions_ms_per_step": [round(r, 3) for r in regions], "regions_min_ms": round(min(regions), 3),
+            "regions_median_ms": round(sorted(regions)[len(regions) // 2], 3),
             # the timed steps trained a real model: every master parameter and both moments are finite afterwards (a NaN anywhere
             # spreads within a few steps; NaN-filled operands also run at other clocks than real data, see DESIGN 4 on DVFS)
             "state_finite_after_timed_region": bool(torch.isfinite(opt._flat_p).all() and torch.isfinite(opt._flat_m).all() and torch.isfinite(opt._flat_v).all()),
@@ -348,6 +373,19 @@ def main():
                 log(f"batch {bsz}: {dt2 / n2 * 1e3:.3f} ms/step")
                 for k in [k for k in batches if k[2] == bsz]:
                     del batches[k]
+        if not args.ragged and not args.no_probes and args.task == "mix" and world == 1:
+            # SURVEY 8d's ragged variant: per-sample L ~ U[20, 80], T ~ U[0, 7], padded to the batch maximum (the reference's collate);
+            # throughput in samples/s, FLOPs counted at every sample's OWN lengths (padding is work the path does, not work it is credited for)
+            ragged_mode[0] = True
+            dt3, smp3, fl3 = timed_region(args.batch, n_distinct, args.steps, verbose=False)
+            s3, f3 = float(smp3), fl3
+            out["ragged"] = {"per_gpu_batch": args.batch, "txt_len": "U[20,80]", "hist_len": "U[0,7]", "value": round(s3 / dt3, 2), "unit": "panorama-steps/s",
+                             "steps": args.steps, "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                             "model_tflops_per_gpu_at_sample_lengths": round(f3 / dt3 / world / 1e12, 2)}
+            log(f"ragged batches: {dt3 / args.steps * 1e3:.3f} ms/step")
+            ragged_mode[0] = False
+            for k in [k for k in batches if k[-1] == "ragged"]:
+                del batches[k]
         if args.task == "mix":
             cycle = [get_batch(s_) for s_ in range(len(sched.cycle))]
         else:

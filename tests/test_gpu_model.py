@@ -1196,7 +1196,10 @@ def _two_rank_schedule(long_run):
         return ["sap", "mlm", "sap", "mrc", "mlm", "sap"], {}, dict(lr=1e-3, eps=1.0)
     seq = ["sap", "mlm", "sar", "mrc", "mlm", "sap", "mrc", "sar"] * 3
     shapes = {"sap": dict(txt_len=20, hist_len=4), "mlm": dict(txt_len=28, hist_len=2), "sar": dict(txt_len=12, hist_len=5), "mrc": dict(txt_len=16, hist_len=3)}
-    return seq, shapes, dict(lr=2e-4, eps=1e-6)
+    # lr = 1e-6: with sign-like Adam steps (eps = 1e-6 is far below every gradient) training is chaotic -- at lr = 2e-4 fp32
+    # summation-order noise grew to 1e-3 of parameter difference within 24 steps in the UNSHARDED exchange too; tiny steps keep the
+    # gradients of the compared runs equal, so that a parameter difference counts wrong updates in units of lr
+    return seq, shapes, dict(lr=1e-6, eps=1e-6)
 
 
 def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False, long_run=False):
@@ -1269,7 +1272,7 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
 @pytest.mark.parametrize("wire,use_graph,sharded,long_run", [("fp32", False, False, False), ("fp32", True, False, False), ("bf16", False, False, False),
                                                              ("fp32", False, True, False), ("fp32", True, True, False), ("bf16", True, True, False),
                                                              ("fp32", True, True, True), ("fp32", False, True, True), ("bf16", True, True, True),
-                                                             ("fp32", True, False, True)])
+                                                             ("fp32", True, False, True), ("bf16", True, False, True)])
 def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph, sharded, long_run):
     """world_size = 2 for real: two processes, different batches, the product's overlapped exchange (gloo moves the
     CUDA tensors) -- against one process that computes both ranks' gradients on the same weights, averages them,
@@ -1317,7 +1320,14 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
         o.zero_grad()
         m(bs[1][t], t, True).mean().backward()
         o._pack_grads()
-        o._flat_g.add_(g0).mul_(0.5)
+        if long_run and wire == "bf16":
+            # the wire's own arithmetic (DDP bf16_compress_hook: halve, round to bf16, sum in bf16): where the two ranks' gradients
+            # nearly cancel, the rounded average differs from the fp32 one by 100 % or changes sign, and a sign-like Adam step
+            # (eps = 1e-6) then differs by a whole lr -- 312 of 1.35 M elements against the fp32 average; that is the wire format,
+            # not the exchange, so the reference rounds the same way
+            o._flat_g.copy_(((g0 * 0.5).to(torch.bfloat16) + (o._flat_g * 0.5).to(torch.bfloat16)).float())
+        else:
+            o._flat_g.add_(g0).mul_(0.5)
         clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
         o.step()
         o.zero_grad()
@@ -1334,15 +1344,16 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     at = int(diff.argmax())
     who = next((n for (n, p_), off in zip(named, [o._offs[o._index_of[id(p_)]] for _, p_ in named]) if off <= at < off + p_.numel()), "?")
     print(f"[two ranks, wire={wire}, graph={use_graph}, sharded={sharded}] worst parameter difference after {len(seq)} steps: {worst:.2e} ({who})")
-    # (the long run's bound is wider only because 24 Adam steps at eps = 1e-6 amplify the summation-order / wire-rounding
-    # differences of small gradients; an element that met stale moments is off by ~lr per step, i.e. by 1e-3 and more)
-    assert worst < ((1e-4 if wire == "fp32" else 6e-4) if long_run else (2e-5 if wire == "fp32" else 2e-4)), (worst, who)
     m0, v0 = torch.load(os.path.join(str(tmp_path), "moments0.pt"))
     m1, v1 = torch.load(os.path.join(str(tmp_path), "moments1.pt"))
-    if sharded:
-        assert torch.equal(m0, m1) and torch.equal(v0, v1), "gather_state left the ranks with different moments"
-    tol = 2e-3 if wire == "fp32" else 3e-2
+    tol = 2e-3 if (wire == "fp32" or long_run) else 3e-2
     em = float((m0 - mr).abs().max()) / float(mr.abs().max())
     ev = float((v0 - vr).abs().max()) / float(vr.abs().max())
+    n_off = int((diff > 0.5 * hyp["lr"]).sum())
+    print(f"    elements off by more than half a step: {n_off} of {diff.numel()}")
     print(f"    exp_avg / exp_avg_sq max difference relative to their scale: {em:.2e} / {ev:.2e}")
+    # (long run: in units of the learning rate -- an element that met stale or missing moments is off by about lr per step)
+    assert worst < (0.3e-6 if long_run else (2e-5 if wire == "fp32" else 2e-4)), (worst, who)
+    if sharded:
+        assert torch.equal(m0, m1) and torch.equal(v0, v1), "gather_state left the ranks with different moments"
     assert em < tol and ev < tol, (em, ev)
