@@ -209,6 +209,22 @@ int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* residual, con
 int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                 const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                 float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);
+/* Dense layer + bias + dropout + residual + LayerNorm in one launch (forward; bf16 operands, fp32 accumulate and statistics):
+ *   z = dropout_pre(a16[M,K] w16[H,K]^T + bias) + residual ;  y = LN(z) gamma + beta
+ * -- BertSelfOutput / BertOutput / the output half of BertXAttention (vilmodel.py:139-143, 181-185, 351-360) without the HBM
+ * round trip of the dense output and the second launch.  Outputs as hamt_ln_fwd with io16 = HAMT_LN_Z_BF16: z16 [M,H] bf16
+ * (saved for hamt_ln_bwd, same dropout stream: call_id), y fp32, y16 [Mpad16,H] bf16 (rows >= M zero), mean, rstd.
+ * H must be 768 (the R2R / RxR model width); K % 64 == 0; tile_rows: 0 = automatic, 32 or 64 = rows per workgroup. */
+typedef struct {
+  int M, K, H, lda;
+  float eps, p_pre;
+  uint32_t call_id;
+  int Mpad16;
+  int tile_rows;
+} hamt_gemm_ln_desc;
+int hamt_gemm_ln_fwd(const hamt_gemm_ln_desc* d, const void* a16, const void* w16, const float* bias,
+                     const float* residual, const float* gamma, const float* beta, void* z16, float* y, void* y16,
+                     float* mean, float* rstd, const uint64_t* rng, void* stream);
 /* pre-LN blocks (x + f(LN(x)), vision_transformer.py:196-197): dz = LayerNorm-backward(dy) + add, where `add` is the
  * gradient that reaches x through the residual path -- one pass instead of a LayerNorm backward and an add. */
 int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean, const float* rstd,

@@ -47,6 +47,10 @@ class LnDesc(C.Structure):
     _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32), ("Mpad16", i32), ("io16", i32)]
 
 
+class GemmLnDesc(C.Structure):
+    _fields_ = [("M", i32), ("K", i32), ("H", i32), ("lda", i32), ("eps", f32), ("p_pre", f32), ("call_id", u32), ("Mpad16", i32), ("tile_rows", i32)]
+
+
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
 WGRAD_TABLE_ENTRY = 80      # HAMT_WGRAD_TABLE_ENTRY
 
@@ -74,6 +78,7 @@ SIGNATURES = {
     "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_attn_small_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_gemm_ln_fwd": [C.POINTER(GemmLnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd_add": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd_reduce": [i32, i32, vp, vp, vp, vp, vp],

@@ -111,6 +111,7 @@ __device__ __forceinline__ bf16x8 mask_k_tail(bf16x8 v, int kbase, int lane, int
   return f.v;
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt();
 template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }

@@ -41,7 +41,7 @@ constexpr int LN_H = 768, LN_CB = 3, LN_BN = 256;
 
 template <int BM>
 __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs g) {
-  constexpr int NW = 8, WM = BM / 32, WN = NW / WM, TN = LN_BN / WN, FM = 2, FN = TN / 16, NST = 3;
+  constexpr int NW = 8, WM = BM / 32, WN = NW / WM, TN = LN_BN / WN, FM = 2, FN = TN / 16, NST = BM == 32 ? 4 : 3;
   constexpr int A_ELEMS = BM * BK, B_ELEMS = LN_BN * BK, STAGE = A_ELEMS + B_ELEMS;
   constexpr int NWA = BM / 8 >= NW ? NW : BM / 8;          // waves that carry A pieces (8 rows per 1 KiB piece)
   constexpr int NLD_B = LN_BN / (8 * NW), NLD_A = BM / (8 * NWA);
@@ -51,6 +51,12 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs g) {
   const int m0 = blockIdx.x * BM;
   const int nk = g.K / BK, IT = LN_CB * nk;
   const bool has_a = w < NWA;                                // wave-uniform
+  // Every workgroup reads the SAME weight tiles; marching through them in the same order, the workgroups of an XCD would all ask
+  // its L2 for the same lines at the same moment (measured: 17 B/clk/CU).  So each workgroup starts somewhere else: its k-tiles
+  // rotated by `krot`, its three column blocks by `crot` (accumulator slot c holds column block (c + crot) % 3) -- fp32 summation
+  // order then depends on the row's workgroup, i.e. on the row index only: still deterministic.
+  const int xi = blockIdx.x >> 3;                            // index within the XCD (blocks are dealt round-robin to the 8 XCDs)
+  const int krot = xi % nk, crot = (xi / nk) % LN_CB;
 
   f32x4 acc[LN_CB][FM][FN];
 #pragma unroll
@@ -66,9 +72,13 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs g) {
   if (has_a) src_a.init(g.lda, m0, g.M - 1, w, lane);
 #pragma unroll
   for (int c = 0; c < LN_CB; ++c) src_b[c].init(g.K, c * LN_BN, LN_H - 1, w, lane);
-  auto stage = [&](int it) {       // it = cb * nk + kt
+  auto stage = [&](int it) {       // it = slot * nk + step: accumulator slot `slot`, the step-th k-tile of its rotated order
     const unsigned dst = lds0 + (unsigned)((it % NST) * STAGE * 2);
-    const int cb = it / nk, kt = it - cb * nk;
+    const int slot = it / nk;
+    int kt = it - slot * nk + krot;
+    kt = kt >= nk ? kt - nk : kt;
+    int cb = slot + crot;
+    cb = cb >= LN_CB ? cb - LN_CB : cb;
     if (has_a) src_a.issue(g.A, g.lda, kt * BK, 0, dst, w);
     if (cb == 0) src_b[0].issue(g.W, g.K, kt * BK, 0, dst + (unsigned)(A_ELEMS * 2), w);
     else if (cb == 1) src_b[1].issue(g.W, g.K, kt * BK, 0, dst + (unsigned)(A_ELEMS * 2), w);
@@ -82,8 +92,10 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs g) {
 #pragma unroll
   for (int cb = 0; cb < LN_CB; ++cb) {
     for (int kt = 0; kt < nk; ++kt, ++it) {
-      // tile `it` has landed when at most the pieces of the one younger tile are outstanding
-      if (it + 1 < IT) { if (has_a) wait_vmcnt_c<NLD_B + NLD_A>(); else wait_vmcnt_c<NLD_B>(); }
+      // tile `it` has landed when at most the pieces of the NST - 2 younger tiles are outstanding
+      const int younger = min(NST - 2, IT - 1 - it);
+      if (younger >= 2) { if (has_a) wait_vmcnt_c<2 * (NLD_B + NLD_A)>(); else wait_vmcnt_c<2 * NLD_B>(); }
+      else if (younger == 1) { if (has_a) wait_vmcnt_c<NLD_B + NLD_A>(); else wait_vmcnt_c<NLD_B>(); }
       else wait_vmcnt_c<0>();
       __builtin_amdgcn_s_barrier();             // everyone's share of tile `it` is in LDS; everyone is done with tile it - 1
       if (it + NST - 1 < IT) stage(it + NST - 1);
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs g) {
     for (int c = 0; c < LN_CB; ++c)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int col = c * LN_BN + wn * TN + j * 16 + lg * 4;
+        const int col = ((c + crot) % LN_CB) * LN_BN + wn * TN + j * 16 + lg * 4;
         const float4 b = *(const float4*)(g.bias + col);
         f32x4 v = acc[c][i][j];
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs g) {
       for (int c = 0; c < LN_CB; ++c)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          const int col = c * LN_BN + wn * TN + j * 16 + lg * 4;
+          const int col = ((c + crot) % LN_CB) * LN_BN + wn * TN + j * 16 + lg * 4;
           const size_t o = (size_t)row * LN_H + col;
           const f32x4 v = acc[c][i][j];
           const float4 ga = *(const float4*)(g.gamma + col), be = *(const float4*)(g.beta + col);

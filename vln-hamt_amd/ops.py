@@ -535,6 +535,52 @@ def _ln_fwd(x2, r2, gamma, beta, eps, p_pre, p_post, want16):
     return y, y16, z, mean, rstd, cid
 
 
+# Dense layer + LayerNorm as one launch (csrc/gemm_ln.hip): HAMT_GEMM_LN = 0 never, 1 whenever the kernel is built for the shape,
+# unset: where it measured faster than hamt_gemm + hamt_ln_fwd on MI355X (`gemm_ln_wins`).
+GEMM_LN = os.environ.get("HAMT_GEMM_LN", "auto")
+
+
+def gemm_ln_wins(M: int, K: int, H: int) -> bool:
+    """Every workgroup of the fused kernel streams the whole [H, K] weight through its CU (LayerNorm needs whole rows, so the grid is
+    M / 32 or M / 64 workgroups of H columns): it is bound by the CU's L2 -> LDS path, about 1.5 us per 64 of K whatever M is, while
+    the two-launch path pays a GEMM that grows with M plus 14 B per element of LayerNorm traffic.  Measured (tools/gemm_ln_bench.py,
+    profiles/r03_gemm_ln_bench.txt)."""
+    if GEMM_LN == "0" or H != 768 or K % 64 != 0:
+        return False
+    if GEMM_LN == "1":
+        return True
+    return _GEMM_LN_RULE(M, K)
+
+
+# Measured on MI355X (profiles/r03_gemm_ln_bench.txt): the fused kernel takes 37-40 us at K = 768 whatever M <= 8192 (58 us with 64-row
+# tiles up to M = 16384) and 95-130 us at K = 3072, against 20-46 us / 37-88 us for hamt_gemm + hamt_ln_fwd at the step's row counts:
+# it wins nowhere on this chip (DESIGN: every workgroup of a full-row tile streams the whole weight through its own LDS-DMA path,
+# ~1000 cycles of piece issue per 36 KB k-step, 36 - 144 steps).  Kept behind HAMT_GEMM_LN=1, tested, profiled; off by default.
+_GEMM_LN_RULE = lambda M, K: False
+
+
+def gemm_ln_fwd(a16, w16, bias, r2, gamma, beta, eps, p_pre, tile_rows=0):
+    """(y, y16, z16, mean, rstd, call_id) = LN(dropout(a16 @ w16^T + bias) + r2): the outputs of `_ln_fwd` behind a bf16 dense layer,
+    from ONE kernel.  a16 [M, K] bf16 (row stride >= K), w16 [H, K] bf16, r2 [M, H] fp32 contiguous."""
+    _chk(a16, "gemm_ln_fwd")
+    M, K = a16.shape
+    H = w16.shape[0]
+    dev = a16.device
+    assert a16.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.shape == (H, K) and w16.is_contiguous()
+    assert r2.shape == (M, H) and r2.dtype == torch.float32 and r2.is_contiguous() and a16.stride(1) == 1
+    z = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(M, H, dtype=torch.float32, device=dev)
+    mean = torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    Mp = _rup(M)
+    y16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev)
+    cid = next_call_id() if p_pre > 0 else 0
+    d = L.GemmLnDesc(M, K, H, a16.stride(0), float(eps), float(p_pre), cid, Mp, int(tile_rows))
+    L.check(L.load().hamt_gemm_ln_fwd(C.byref(d), _p(a16), _p(w16), _p(bias), _p(r2), _p(gamma), _p(beta), _p(z), _p(y), _p(y16),
+                                      _p(mean), _p(rstd), _p(rng_state(dev)), _stream()), "hamt_gemm_ln_fwd")
+    return y, y16, z, mean, rstd, cid
+
+
 LN_DEFER = os.environ.get("HAMT_NO_DEFER_LNRED") is None      # ablation: reduce the parameter-gradient partials in line
 
 
