@@ -417,6 +417,26 @@ def main():
             out["kernel_table"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in table[:12]]
             out["roofline_subblock_xattn"] = rp.subblock_xattn(model, args.batch, device)
             out["roofline_probe_xattn"] = time_xattn_probe(args.batch, device)
+        if world == 1 and not dist_on and not args.no_probes and graphed is not None and args.prec == "bf16" and args.task == "mix":
+            # What the multi-GPU step's machinery costs before a byte moves: the same steps through the sharded exchange
+            # (parallel.ShardedGradSync: launch groups on two lanes, wire staging, reduce-scatter / owned-slice AdamW / all-gather
+            # calls, the eager section between the graphs) with a ONE-rank RCCL group, against the plain single-GPU step above.
+            try:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 200))
+                torch.distributed.init_process_group(backend=os.environ.get("HAMT_DIST_BACKEND") or "nccl", rank=0, world_size=1)
+                gs1 = make_grad_sync(opt, args.prec, n_groups=int(os.environ.get("HAMT_SYNC_GROUPS", 4)), wire=default_wire(args.prec))
+                plain_graphed, graphed = graphed, GraphedTrainStep(model, opt, max_grad_norm=5.0, grad_sync=gs1)
+                dt_w1, _, _ = timed_region(args.batch, n_distinct, args.steps, verbose=False)
+                out["exchange_overhead_ms_world1"] = round(dt_w1 / args.steps * 1e3 - min(regions), 3)
+                out["world1_exchange_ms_per_step"] = round(dt_w1 / args.steps * 1e3, 3)
+                log(f"one-rank sharded exchange: {dt_w1 / args.steps * 1e3:.3f} ms/step (plain {min(regions):.3f})")
+                gs1.close()
+                graphed = plain_graphed
+                torch.distributed.destroy_process_group()
+            except Exception as e:      # a measurement aid must never cost the bench line
+                out["exchange_overhead_ms_world1"] = None
+                log(f"one-rank exchange probe failed: {type(e).__name__}: {e}")
         log("roofline probes done; timing the CPU oracle baseline")
         if world == 1 and not args.no_cpu_baseline and not args.no_probes:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)

@@ -146,7 +146,10 @@ typedef struct {
               * must use the same tiling to overwrite the same slots: pass NULL for both and reduce that parameter from memory) */
   int K_valid; /* 0 or K: every reduction row counts.  Else rows [K_valid, K) of dy and x are PADDING of any content
                 * (uninitialised memory included): they are neither read (the loads re-read row K_valid - 1) nor multiplied */
-  int reserved_;
+  float wire_scale; /* 0: dW is stored as fp32 (the default).  != 0: `dw` points to a BF16 array of the same shape / ldw and the
+                     * tile stores bf16(wire_scale * dW) -- the value a data-parallel gradient exchange puts on the wire (the stock DDP
+                     * bf16_compress_hook's: divide by the world size, round to bf16), written straight from the accumulators instead
+                     * of an fp32 store followed by a pack pass over the arena.  Store only (accum_dw must be 0), `ss` is ignored. */
 } hamt_wgrad_desc;
 /* `table`: caller-provided DEVICE scratch (16-byte aligned) that holds the launch table: HAMT_WGRAD_TABLE_ENTRY bytes per
  * entry, at most sum over the problems of ceil(M_p / 64) entries (large problems are cut into bands of tile rows); it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can

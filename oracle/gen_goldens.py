@@ -10,6 +10,8 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
                       logits, losses, trunk embeddings, per-parameter gradient norms + small grads
   itm_rng.npz         the negatives the reference drew inside forward_itm under fixed seeds
   canon_pretrain.npz  R2R-canon full config (B=2, L=80, T=5): per-task logits/losses + probes
+  canon_multi.npz     R2R-canon over two more weight seeds and at per-GPU batch 16: losses, trunk probes, gradient norms / probes,
+                      single-candidate-logit gradients for ITM
   optim_tiny.npz      3 steps of clip(5.0) + reference AdamW + warmup schedule on the tiny model
   tiny_finetune.npz   NavCMT language / history / visual modes (incl. no_lang_ca)
   vit.npz             ViT backbone features / gradients from the reference's VisionTransformer class
@@ -462,14 +464,16 @@ def gen_vit():
         store[f"{tag}/images"] = imgs.numpy() if tag == "tiny" else imgs[:, :, :8, :8].numpy()      # b16 inputs are regenerated
         store[f"{tag}/probe"] = probe.numpy()
         store[f"{tag}/feats"] = feats.detach().numpy()
-        if tag == "tiny":
-            (feats * probe).sum().backward()
-            (ofeats * probe).sum().backward()
-            worst = 0.0
-            for k, p_ in ref.named_parameters():
+        (feats * probe).sum().backward()
+        (ofeats * probe).sum().backward()
+        worst = 0.0
+        for k, p_ in ref.named_parameters():
+            if tag == "tiny":
                 store[f"{tag}/grad/{k}"] = p_.grad.numpy()
-                worst = max(worst, (p_.grad - osd[k].grad).abs().max().item())
-            print(f"  [vit {tag}] oracle-vs-reference gradients max|d|={worst:.3e}")
+            worst = max(worst, (p_.grad - osd[k].grad).abs().max().item())
+        if tag == "b16":      # config 4's backbone at full size: per-parameter gradient norms + 257-point probes of the reference's autograd
+            store.update(grads_packed(ref.named_parameters(), "b16/"))
+        print(f"  [vit {tag}] oracle-vs-reference gradients max|d|={worst:.3e}")
     np.savez_compressed(os.path.join(OUT, "vit.npz"), **store)
     print("vit.npz:", len(store), "arrays")
 
@@ -504,6 +508,81 @@ def gen_collate():
                 store[f"{tag}/{k}/list"] = np.asarray(len(v))
     np.savez_compressed(os.path.join(OUT, "collate.npz"), **store)
     print("collate.npz:", len(store), "arrays; oracle restatement bit-exact on", len(COLLATE_CASES), "cases")
+
+
+# (weights seed, batch seed base, per-GPU batch): the second and third weight draws at the golden batch size, and the reference's own
+# per-GPU batch (16, pretrain_r2r.json) on two of them -- bf16 margins measured on ONE seed at B = 2 say little
+CANON_MULTI = [(7, 300, 2), (99, 500, 2), (2024, 700, 16), (7, 900, 16)]
+MULTI_PROBE = 65
+
+
+def grads_packed_n(named_params, prefix, n):
+    names, norms, probes = [], [], []
+    for k, p in named_params:
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(p.grad.detach().double().norm().item())
+        probes.append(grad_probe(p.grad, n))
+    return {f"{prefix}grad_names": np.array(names), f"{prefix}grad_norms": np.array(norms, dtype=np.float64), f"{prefix}grad_probes": np.stack(probes)}
+
+
+def gen_canon_multi():
+    """R2R-canon again over CANON_MULTI: per task the loss, trunk probes, per-parameter gradient norms and 65-point gradient
+    probes from the REFERENCE; for ITM additionally the gradients of single candidate logits (sum_b logits[b, k], k = 0 positive and
+    k = 3 a shuffled negative): the loss gradient is a difference of five nearly equal such terms, so its cosine measures
+    cancellation noise -- the terms themselves are gated like every other task."""
+    torch.set_num_threads(8)
+    store = {"meta/cases": np.asarray(CANON_MULTI)}
+    cfg = OracleConfig()
+    models = {}
+    for ci, (wseed, bseed, B) in enumerate(CANON_MULTI):
+        if wseed not in models:
+            sd = make_state_dict(pretrain_param_shapes(cfg), seed=wseed)
+            models[wseed] = build_ref_pretrain(cfg, sd)
+        model, vil = models[wseed]
+        for i, task in enumerate(("mlm", "sap", "sar", "sprel", "mrc", "itm")):
+            batch = make_batch(task, B if task != "itm" else 2 * B, cfg, seed=bseed + i, txt_len=80, hist_len=5)
+            pre = f"c{ci}/{task}/"
+            itm_rng = None
+            with torch.no_grad():
+                if task == "itm":
+                    np.random.seed(4321 + ci)
+                    torch.manual_seed(4321 + ci)
+                    with RngRecorder(vil) as rec:
+                        loss = model(batch, task, True)
+                    itm_rng = itm_rng_from_record(rec, batch)
+                    store.update(to_np(itm_rng, pre + "rng/"))
+                else:
+                    loss = model(batch, task, True)
+                    g = lambda k: batch.get(k)
+                    t, h, o = model.bert(g("txt_ids"), g("txt_masks"), g("hist_img_fts"), g("hist_ang_fts"), g("hist_pano_img_fts"),
+                                         g("hist_pano_ang_fts"), g("hist_masks"), g("ob_img_fts"), g("ob_ang_fts"), g("ob_nav_types"), g("ob_masks"))
+                    store[pre + "txt_probe"] = t[:, :4, :32].numpy().copy()
+                    store[pre + "hist_embeds"] = h.numpy()
+                    if o is not None:
+                        store[pre + "ob_probe"] = o[:, :, :16].numpy().copy()
+            store[pre + "loss"] = loss.numpy()
+            model.zero_grad(set_to_none=True)
+            if task == "itm":
+                np.random.seed(4321 + ci)
+                torch.manual_seed(4321 + ci)
+            model(batch, task, True).mean().backward()
+            store.update(grads_packed_n(model.named_parameters(), pre, MULTI_PROBE))
+            if task == "itm":
+                for k in (0, 3):
+                    model.zero_grad(set_to_none=True)
+                    np.random.seed(4321 + ci)
+                    torch.manual_seed(4321 + ci)
+                    lg = model(batch, task, False)
+                    lg = lg[0] if isinstance(lg, tuple) else lg
+                    store[pre + "logits"] = lg.detach().numpy()
+                    (lg[:, k].sum() / lg.shape[0]).backward()
+                    store.update(grads_packed_n(model.named_parameters(), pre + f"logit{k}/", MULTI_PROBE))
+            model.zero_grad(set_to_none=True)
+            print(f"  [canon multi c{ci} w{wseed} B{B} {task}] loss {loss.mean().item():.4f}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "canon_multi.npz"), **store)
+    print("canon_multi.npz:", len(store), "arrays")
 
 
 # ------------------------------------------------------------------------------------------------ N4: readers + loaders
@@ -668,7 +747,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "loader"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "loader", "canon_multi"]
     for w in which:
         {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
-         "r2r_data": gen_r2r_data, "loader": gen_loader}[w]()
+         "r2r_data": gen_r2r_data, "loader": gen_loader, "canon_multi": gen_canon_multi}[w]()

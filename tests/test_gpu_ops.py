@@ -191,20 +191,23 @@ def test_gemm_k_groups(layout, shape, variant):
 # SHAPES above never reach the 256-square two-phase tile (gemm_p8_kernel needs >= ~200 tiles and K >= 128) nor the 128-row plain
 # tile; round 2 shipped a NaN in exactly that family which only a training soak saw.
 BENCH_GEMMS = [   # (layout, M, N, K, epilogue, C dtype, kernel the launcher must pick)
-    ("nt", 5120, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),          # text QKV
-    ("nt", 7872, 2304, 768, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),   # packed QKV over text + vision rows: 279 256-square tiles = two rounds -> plain 128-row tiles
+    ("nt", 5120, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false, 3>"),       # text QKV: 240 tiles of 256 x 192 = one full round
+    ("nt", 7872, 2304, 768, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),   # packed QKV over text + vision rows: two rounds of either 256-row tile -> plain 128-row tiles
     ("nt", 11520, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),         # panorama QKV
     ("nt", 5120, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false>"),    # text FFN-1 (+ saved gelu')
     ("nt", 11520, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false>"),   # panorama FFN-1
-    ("nt", 5003, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),          # ragged last tile row
+    ("nt", 5003, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false, 3>"),       # ragged last tile row
+    ("nt", 5120, 2304, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false, 3>"), # (FFN-1's epilogue on the narrow tile)
+    ("nt", 5120, 2250, 768, "bias", "f32", "gemm_p8_kernel<1, false, false, 3>"),        # ragged last 192-column tile (138 columns), fp32 C
     ("nt", 5120, 2318, 768, "bias", "f32", "gemm_p8_kernel<1, false, false>"),           # ragged last tile column, fp32 C
-    ("nt", 11520, 768, 3072, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),         # panorama FFN-2
+    ("nt", 11520, 768, 3072, "bias", "bf16", "gemm_p8_kernel<1, false, false, 3>"),      # panorama FFN-2
     ("nt", 11520, 768, 3072, "drop_res", "f32", "gemm_p8_kernel<1537, false, false>"),   # bias + dropout + residual (pre-LN ViT form)
     ("nn", 5120, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),       # dgrad of FFN-2 x gelu'
-    ("nn", 11520, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),
-    ("nn", 11520, 768, 3072, "acc", "f32", "gemm_p8_kernel<8, false, true>"),            # dgrad of FFN-1 into the residual gradient
-    ("nn", 11520, 768, 2304, "acc", "f32", "gemm_p8_kernel<8, false, true>"),            # dgrad of QKV into the residual gradient
-    ("nn", 5120, 2304, 768, "none", "bf16", "gemm_p8_kernel<0, false, true>"),
+    ("nn", 11520, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 3>"),
+    ("nn", 11520, 768, 3072, "acc", "f32", "gemm_p8_kernel<8, false, true, 3>"),         # dgrad of FFN-1 into the residual gradient
+    ("nn", 11520, 768, 2304, "acc", "f32", "gemm_p8_kernel<8, false, true, 3>"),         # dgrad of QKV into the residual gradient
+    ("nn", 5120, 2304, 768, "none", "bf16", "gemm_p8_kernel<0, false, true, 3>"),
+    ("nn", 5013, 2248, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 3>"),    # ragged rows and a ragged 192-column tile, K-strided B
     ("nn", 5009, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),       # ragged rows
     ("nt", 5120, 768, 768, "bias", "bf16", "gemm_fast_kernel<64, 1, false, false>"),     # attention output projection
     ("nn", 5120, 768, 768, "none", "bf16", "gemm_fast_kernel<64, 0, false, true>"),      # its dgrad
@@ -522,12 +525,24 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         kr = kv if kv else K
         rw = dy[:kr].double().cpu().t() @ x[:kr].double().cpu() + (dw0.double() if aw else 0)
         rb = (dy[:kr].double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
+        if not aw and i % 5 == 4:      # wire output (hamt_wgrad_desc.wire_scale): bf16(0.5 dW) into a bf16 array, no fp32 store, no ss
+            dw = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            keep.append(dw)
+            d.dw, d.wire_scale, ss = dw.data_ptr(), 0.5, None
+            rw = 0.5 * rw
         refs.append((dw, db, rw, rb, ss))
     tab = torch.empty(sum((sp[1] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
     L.check(lib.hamt_debug_fill_lds(0x7FC07FC0, ops._stream()), "hamt_debug_fill_lds")     # every CU's LDS = bf16 NaNs: a tile read before its DMA landed shows
     L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
     torch.cuda.synchronize()
+    n_wire = 0
     for i, (dw, db, rw, rb, ss) in enumerate(refs):
+        if dw.dtype == torch.bfloat16:
+            n_wire += 1
+            assert bool(torch.isfinite(dw).all()), (i, "unwritten wire elements")
+            close(dw.float(), rw, 2 ** -8, f"wire dW[{i}] {specs[i]}")
+            close(db, rb, 3e-5, f"db[{i}] {specs[i]}")
+            continue
         close(dw, rw, 3e-5, f"dW[{i}] {specs[i]}")
         close(db, rb, 3e-5, f"db[{i}] {specs[i]}")
         if ss is not None:       # sum over the tiles' slots = ||dW||^2 of the FINAL values (after accumulation), whatever the tile size
@@ -535,6 +550,7 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
             got = float(ss.double().sum())
             assert abs(got - want) <= 2e-5 * want and bool(torch.isfinite(ss).all()), (i, specs[i], got, want)
             assert int((ss != 0).sum()) <= ss.numel()
+    assert n_wire >= 4
     # argument validation is loud
     descs[0].K = 100
     with pytest.raises(L.HamtError):

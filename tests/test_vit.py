@@ -45,6 +45,20 @@ def test_vit_oracle_matches_reference_goldens(tag):
             assert _rel(v.grad, store[f"{tag}/grad/{k}"]) <= 1e-6, k
 
 
+def _b16_grad_check(named, store, what, cos_min, norm_tol):
+    """gradients of sum(features * probe) at ViT-B/16, 224 x 224 against the reference's autograd (vit.npz b16/grad_*)"""
+    from _util import grad_probe
+    names = [str(n) for n in store["b16/grad_names"]]
+    norms, probes = store["b16/grad_norms"], store["b16/grad_probes"].astype(np.float64)
+    assert set(names) == set(named), set(names) ^ set(named)
+    got = np.stack([grad_probe(named[k].grad, probes.shape[1]) for k in names]).astype(np.float64)
+    gn = np.array([float(named[k].grad.double().norm()) for k in names])
+    pcos = float((got * probes).sum() / np.sqrt((got ** 2).sum() * (probes ** 2).sum()))
+    nerr = float(np.max(np.abs(gn - norms) / np.maximum(norms, 5e-2 * float(norms.max()))))
+    print(f"[vit b16 backward {what}] probe cosine {pcos:.6f}, worst per-parameter norm error {nerr:.2e}")
+    assert pcos >= cos_min and nerr <= norm_tol, (what, pcos, nerr)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("tag", ["tiny", "b16"])
@@ -60,6 +74,15 @@ def test_vit_hip_matches_reference_goldens(tag, prec):
     if tag == "b16":
         with torch.no_grad():                                                           # the no-grad panorama pass
             feats = model.forward_features(imgs.cuda())
+        if "b16/grad_names" in store:       # BASELINE config 4's backbone, backward at full size (history / observation views train it)
+            model.train(True)
+            for m_ in model.modules():
+                if isinstance(m_, torch.nn.Dropout):
+                    m_.p = 0.0
+            f2 = model.forward_features(imgs.cuda())
+            assert _rel(f2, store["b16/feats"]) <= TOL[prec]
+            (f2 * probe.cuda()).sum().backward()
+            _b16_grad_check(dict(model.named_parameters()), store, prec, 0.99999 if prec == "fp32" else 0.995, 2e-3 if prec == "fp32" else 6e-2)
     else:
         feats = model.forward_features(imgs.cuda())
     e = _rel(feats, store[f"{tag}/feats"])

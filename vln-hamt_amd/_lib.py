@@ -58,7 +58,7 @@ WGRAD_TABLE_ENTRY = 80      # HAMT_WGRAD_TABLE_ENTRY
 class WgradDesc(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32), ("ldy", i32),
                 ("ldx", i32), ("ldw", i32), ("accum_dw", i32), ("accum_db", i32), ("ss", vp), ("K_valid", i32),
-                ("reserved_", i32)]
+                ("wire_scale", f32)]
 
 
 SIGNATURES = {

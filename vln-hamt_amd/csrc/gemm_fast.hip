@@ -531,7 +531,8 @@ constexpr int WG_MAX = 48;                       // table entries carried by one
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db; float* ss;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
-  int kv, pad_;                                  // kv: valid reduction rows (<= K): rows behind are padding of any content
+  int kv;                                        // valid reduction rows (<= K): rows behind are padding of any content
+  float wscale;                                  // != 0: dw is a bf16 array, the tile stores bf16(wscale * dW) (hamt_wgrad_desc.wire_scale)
 };
 static_assert(sizeof(WgradProb) == HAMT_WGRAD_TABLE_ENTRY, "HAMT_WGRAD_TABLE_ENTRY");
 struct WgradChunk { WgradProb p[WG_MAX]; };
@@ -561,8 +562,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const Wgrad
   const WgradProb q = tab[lo];
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + BNT - 1) / BNT;
-  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
-              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
+  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0,
+              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
   gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, q.K / BK, 0, q.db, q.flags & 2);
 }
 
@@ -628,24 +629,52 @@ template <int GS> __device__ __forceinline__ int p8_index(int r, int half) {
 // Per-lane source description of one operand's two units (2 DMA pieces each), computed once per tile.
 //   K-contiguous: off[h][j] = byte offset of (row, chunk) at k = 0; a k-tile adds 128 bytes.
 //   K-strided:    col[h][j] = element column, kk[j] = k row within the tile; offset = min(k0 + kk, kmax) * ld + col.
-template <bool KM> struct P8Src { unsigned off[2][2]; int kk[2]; };
+template <bool KM> struct P8Src { unsigned off[2][2]; int kk[2]; int kk1; };
 
-template <bool KM, int GS>
+// B-operand column of unit-local index r of unit `half` when a wave column owns NB = 3 fragments (a 256 x 192 tile: unit 0 =
+// the b0 columns, 2 fragments = 32 per wave column; unit 1 = the b1 columns, ONE fragment = 16 per wave column, a 64-wide unit):
+// K-contiguous B: wave column g owns tile columns [48 g, 48 g + 48); K-strided B: unit 0 = columns [0, 128), unit 1 = [128, 192).
+template <bool KM> __device__ __forceinline__ int p8_bcol3(int r, int half) {
+  if constexpr (KM) return half * 128 + r;
+  else return half == 0 ? 48 * (r >> 5) + (r & 31) : 48 * (r >> 4) + 32 + (r & 15);
+}
+
+// H1 = rows / columns of unit 1 (128, or 64 for the B operand of the 192-column tile: one DMA piece per wave instead of two)
+template <bool KM, int GS, int H1 = 128>
 __device__ __forceinline__ void p8_src_init(P8Src<KM>& sd, int ld, int o0, int omax, int w, int lane) {
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if (H1 == 64 && h == 1) {
+        if (j == 1) continue;
+        if constexpr (!KM) {     // image [64][64 k], chunk ^= row & 7
+          const int r = w * 8 + (lane >> 3);
+          const int chunk = (lane & 7) ^ (r & 7);
+          int gr = o0 + p8_bcol3<KM>(r, 1);
+          gr = gr < omax ? gr : omax;
+          sd.off[1][0] = ((unsigned)gr * (unsigned)ld + (unsigned)chunk * 8u) * 2u;
+        } else {                 // image [64 k][64], 16-byte chunk ^= col_swz<64>(k row)
+          const int kk = w * 8 + (lane >> 3);
+          const int chunk = (lane & 7) ^ col_swz<64>(kk);
+          int c = o0 + p8_bcol3<KM>(chunk * 8, 1);
+          const int cmax = min(ld - 8, (omax >> 3) << 3);
+          c = c < cmax ? c : cmax;
+          sd.off[1][0] = (unsigned)c;
+          sd.kk1 = kk;
+        }
+        continue;
+      }
       if constexpr (!KM) {     // image [128][64], chunk ^= row & 7
         const int r = w * 16 + j * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (r & 7);
-        int gr = o0 + p8_index<GS>(r, h);
+        int gr = o0 + (H1 == 64 ? p8_bcol3<KM>(r, h) : p8_index<GS>(r, h));
         gr = gr < omax ? gr : omax;
         sd.off[h][j] = ((unsigned)gr * (unsigned)ld + (unsigned)chunk * 8u) * 2u;
       } else {                 // image [64][128], 16-byte chunk ^= col_swz<128>(k row)
         const int kk = w * 8 + j * 4 + (lane >> 4);
         const int chunk = (lane & 15) ^ col_swz<128>(kk);
-        int c = o0 + p8_index<GS>(chunk * 8, h);
+        int c = o0 + (H1 == 64 ? p8_bcol3<KM>(chunk * 8, h) : p8_index<GS>(chunk * 8, h));
         const int cmax = min(ld - 8, (omax >> 3) << 3);     // never behind the last 8-column chunk that holds a needed column:
         c = c < cmax ? c : cmax;                            // stays inside the operand (a slice of a wider buffer, the buffer's last row)
         sd.off[h][j] = (unsigned)c;
@@ -654,8 +683,17 @@ __device__ __forceinline__ void p8_src_init(P8Src<KM>& sd, int ld, int o0, int o
     }
 }
 
-template <bool KM>
+template <bool KM, int H1 = 128>
 __device__ __forceinline__ void p8_issue(const P8Src<KM>& sd, const bf16_t* __restrict__ P, int ld, int kt, int kmax, unsigned dst, int h, int w) {
+  if (H1 == 64 && h == 1) {      // the 64-wide unit: one piece per wave
+    if constexpr (!KM) glds16_off(P, sd.off[1][0] + (unsigned)kt * (BK * 2), dst + (unsigned)((w * 8) * BK * 2));
+    else {
+      int gk = kt * BK + sd.kk1;
+      gk = gk < kmax ? gk : kmax;
+      glds16_off(P, ((unsigned)gk * (unsigned)ld + sd.off[1][0]) * 2u, dst + (unsigned)((w * 8) * 64 * 2));
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if constexpr (!KM) {
@@ -669,8 +707,9 @@ __device__ __forceinline__ void p8_issue(const P8Src<KM>& sd, const bf16_t* __re
 }
 
 template <int N> __device__ __forceinline__ void p8_wait() {
-  static_assert(N == 0 || N == 2 || N == 6 || N == 8, "p8_wait");
+  static_assert(N == 0 || N == 2 || N == 6 || N == 7 || N == 8, "p8_wait");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -679,8 +718,12 @@ template <int N> __device__ __forceinline__ void p8_wait() {
 // COLSUM (weight-gradient form, A = dY stored [K][M]): wave column 0 of the tiles with n0 == 0 also reduces A over k --
 // one extra MFMA per A fragment against an operand that holds ones in row i only, so that the column sums of the wave's
 // 8 fragments land in the 8 rows of ONE accumulator (4 registers): the bias gradient, for free of any extra pass over dY.
-template <int EPI, bool A_KM, bool B_KM, bool COLSUM>
+// NB = B fragments per wave: 4 = the 256-column tile above; 3 = a 256 x 192 tile (wave output 128 x 48: b0 two fragments, b1 one;
+// unit Y1 is 64 wide, one DMA piece per wave) for grids whose 256-square tiling leaves the last round mostly empty -- 5120 x 2304 is
+// 180 tiles of 256 x 256 (0.70 of a round of 256 CUs) and 240 of 256 x 192 (0.94): the round is 0.8 as long and all of it is used.
+template <int EPI, bool A_KM, bool B_KM, bool COLSUM, int NB = 4>
 __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, float* db, int db_accum) {
+  constexpr int H1B = NB == 3 ? 64 : 128;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * P8_BUF];          // 128 KiB
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
   const bool do_cs = COLSUM && db != nullptr && n0 == 0 && wc == 0;        // wave-uniform
@@ -688,21 +731,21 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   const int nk = g.K / BK;
   const unsigned lds0 = lds_base_of(lds);
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NB];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[4][2], bf_[4][2];
+    for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bf_[NB][2];
 
   P8Src<A_KM> sa;
   P8Src<B_KM> sb;
   p8_src_init<A_KM, 6>(sa, g.lda, m0, g.M - 1, w, lane);
   constexpr int BGS = B_KM ? 7 : 5;
-  p8_src_init<B_KM, BGS>(sb, g.ldb, n0, g.N - 1, w, lane);
+  p8_src_init<B_KM, BGS, H1B>(sb, g.ldb, n0, g.N - 1, w, lane);
   auto slot = [&](int kt, int ty) { return lds0 + (unsigned)(((kt & 1) * P8_BUF + ty * P8_UNIT) * 2); };
   auto issue_x = [&](int kt, int h) { p8_issue<A_KM>(sa, g.A, g.lda, kt, g.ka_max, slot(kt, h ? 3 : 0), h, w); };
-  auto issue_y = [&](int kt, int h) { p8_issue<B_KM>(sb, g.B, g.ldb, kt, g.kb_max, slot(kt, 1 + h), h, w); };
+  auto issue_y = [&](int kt, int h) { p8_issue<B_KM, H1B>(sb, g.B, g.ldb, kt, g.kb_max, slot(kt, 1 + h), h, w); };
   // prologue: k-tile 0 and X0, Y0 of k-tile 1; phase A(0) reads X0, Y0, Y1 of k-tile 0 (three younger units may be in flight)
   issue_x(0, 0); issue_y(0, 0); issue_y(0, 1); issue_x(0, 1); issue_x(1, 0); issue_y(1, 0);
   p8_wait<6>();
@@ -727,8 +770,10 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
         for (int j = 0; j < 2; ++j) bf_[j][s] = frag<B_KM, 128>(buf + 1 * P8_UNIT, 32 * wc + j * 16, s, lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i][s] = frag<A_KM, 128>(buf + 0 * P8_UNIT, 64 * wr + i * 16, s, lane);
+        if constexpr (NB == 4) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf_[2 + j][s] = frag<B_KM, 128>(buf + 2 * P8_UNIT, 32 * wc + j * 16, s, lane);
+          for (int j = 0; j < 2; ++j) bf_[2 + j][s] = frag<B_KM, 128>(buf + 2 * P8_UNIT, 32 * wc + j * 16, s, lane);
+        } else bf_[2][s] = frag<B_KM, 64>(buf + 2 * P8_UNIT, 16 * wc, s, lane);
       }
     } else {
 #pragma unroll
@@ -746,7 +791,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (P == 0) {       // A(t): Y1, X1 of k-tile t+1; the next phase reads X1(t)
-      if constexpr (MODE < 2) { issue_y(kt + 1, 1); issue_x(kt + 1, 1); p8_wait<8>(); }
+      if constexpr (MODE < 2) { issue_y(kt + 1, 1); issue_x(kt + 1, 1); p8_wait<NB == 4 ? 8 : 7>(); }
       else p8_wait<0>();
     } else {                      // B(t): X0, Y0 of k-tile t+2; the next phase reads X0, Y0, Y1 of k-tile t+1
       if constexpr (MODE == 0) { issue_x(kt + 2, 0); issue_y(kt + 2, 0); p8_wait<6>(); }
@@ -765,7 +810,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NB; ++j)
           acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j][s], af[i][s], acc[I0 + i][j], 0, 0, 0);
     if constexpr (COLSUM) {
       if (do_cs) {
@@ -833,7 +878,10 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   // the transpose: inside epi_store each load sits behind the previous piece's store and its latency is paid 16 times per thread.
   constexpr bool PRE_AUX = EPI >= 0 && (EPI & HAMT_EPI_MUL_AUX) != 0;
   constexpr bool PRE_C = false;   // the same for the fp32 C of `acc` (16 registers per piece) measured 1 us SLOWER per launch: off
-  const int c8 = lane & 7, col = n0 + p8_index<BGS>(32 * wc + (c8 & 3) * 8, c8 >> 2);
+  const int c8 = lane & 7;
+  int col;
+  if constexpr (NB == 4) col = n0 + p8_index<BGS>(32 * wc + (c8 & 3) * 8, c8 >> 2);
+  else col = c8 < 6 ? n0 + p8_bcol3<B_KM>(c8 < 4 ? 32 * wc + c8 * 8 : 16 * wc + (c8 - 4) * 8, c8 >> 2) : g.N;   // (chunks 6, 7: no columns)
   bool pre_ok = false;
   if constexpr (PRE_AUX) pre_ok = col + 8 <= g.N && g.dtype_aux == HAMT_BF16 && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
   if constexpr (PRE_C) pre_ok = col + 8 <= g.N && g.dtype_c == HAMT_F32 && (g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0;
@@ -855,7 +903,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NB; ++j) {
         const int rl = i * 16 + (lane & 15), c4 = j * 4 + (lane >> 4);
         *(f32x4*)(ct + rl * 64 + ((c4 ^ (rl & 7)) << 2)) = acc[4 * h + i][j];
       }
@@ -878,11 +926,12 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   }
 }
 
-template <int EPI, bool A_KM, bool B_KM>
+template <int EPI, bool A_KM, bool B_KM, int NB = 4>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgsF g) {
-  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  constexpr int TN = 64 * NB;
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + TN - 1) / TN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  p8_tile<EPI, A_KM, B_KM, false>(g, (bid / tiles_n) * 256, (bid % tiles_n) * 256, nullptr, 0);
+  p8_tile<EPI, A_KM, B_KM, false, NB>(g, (bid / tiles_n) * 256, (bid % tiles_n) * TN, nullptr, 0);
 }
 
 // the grouped weight-gradient launch (see wgrad_grouped_kernel) on the two-phase tile
@@ -898,23 +947,23 @@ __global__ __launch_bounds__(512) void wgrad_grouped_p8_kernel(const WgradProb* 
   const WgradProb q = tab[lo];
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + 255) / 256;
-  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0, 1.0f,
-              q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
+  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0,
+              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
   p8_tile<-2, true, true, true>(g, (local / tiles_n) * 256, (local % tiles_n) * 256, q.db, q.flags & 2);
 }
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, int NB = 4>
 bool launch_p8(const GemmArgsF& g, hipStream_t s) {
-  const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256));
+  const dim3 grid(((g.M + 255) / 256) * ((g.N + 64 * NB - 1) / (64 * NB)));
   const int e = g.epi;
-#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_p8_kernel<E, A_KM, B_KM>), grid, dim3(512), 0, s, g); \
-                    hamt_set_last_kernel("gemm_p8_kernel<%d, %s, %s>", (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
+#define HAMT_L(E) do { hipLaunchKernelGGL((gemm_p8_kernel<E, A_KM, B_KM, NB>), grid, dim3(512), 0, s, g); \
+                    hamt_set_last_kernel(NB == 4 ? "gemm_p8_kernel<%d, %s, %s>" : "gemm_p8_kernel<%d, %s, %s, 3>", (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);
   else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD);
   else if (e == HAMT_EPI_MUL_AUX) HAMT_L(HAMT_EPI_MUL_AUX);
-  else if constexpr (!B_KM) {      // forward-only epilogues (the pre-LN ViT blocks: residual add / dropout in the epilogue)
+  else if constexpr (!B_KM && NB == 4) {      // forward-only epilogues (the pre-LN ViT blocks: residual add / dropout in the epilogue)
     if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX);
     else if (e == (HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT);
     else if (e == (HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT)) HAMT_L(HAMT_EPI_BIAS | HAMT_EPI_GELU_GRAD | HAMT_EPI_DROPOUT);
@@ -1063,11 +1112,21 @@ void hamt_gemm_fast_launch(const hamt_gemm_desc* d, const void* A, const void* B
   // step's shapes at ~620 TFLOP/s.  HAMT_P8=0 / 1 = never / whenever eligible.
   static const int p8 = getenv("HAMT_P8") ? atoi(getenv("HAMT_P8")) : -1;
   if (ks == 1 && p8 != 0 && !force_bm && d->K >= 128 && !d->a_kmajor && (!d->b_kmajor || d->ldb >= 256)) {
-    const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256), t192 = (long)((d->M + 255) / 256) * ((d->N + 191) / 192);
     const double t_p8 = (double)((t256 + 255) / 256) * (6.0 + 1.55 * (d->K / BK));
+    // 256 x 192 tiles: 3/4 of the MFMA work and 7/8 of the operand bytes of a 256-square tile per k-tile -- but measured 0.92-0.94 of
+    // its TIME at K = 768 .. 3072 (tools/gemm_bench.py with HAMT_P8_BN = 192 / 256: a tile's life is prologue, barriers and the
+    // store tail as much as MFMA issue): worth it only where it does not add a round -- 5120 x 2304 x 768: 180 tiles -> 240, one
+    // round either way, 27.6 -> 26.0 us; 11520 x 768 x 3072: 65.2 -> 59.8; 11520 x 768 x 2304 (NN, acc): 55.3 -> 50.9.  The FFN-1
+    // epilogue (gelu + gelu', two stores per tile) measured 4 % SLOWER with the narrow tile at 720 tiles: kept on 256 columns there.
+    static const int bn_force = getenv("HAMT_P8_BN") ? atoi(getenv("HAMT_P8_BN")) : 0;      // 192 / 256: tuning and tests
+    const double t_p8n = (double)((t192 + 255) / 256) * (6.0 + 1.44 * (d->K / BK));
+    const bool n192 = bn_force ? bn_force == 192 : (t_p8n < 0.97 * t_p8 && !((d->epilogue & HAMT_EPI_GELU_GRAD) && t192 > 512));
     const double t_small = 2.0 * d->M * d->N * d->K / 620e6;
-    if (p8 == 1 || t_p8 < 0.95 * t_small) {
-      const bool ok = !d->b_kmajor ? launch_p8<false, false>(g, s) : launch_p8<false, true>(g, s);
+    if (p8 == 1 || (n192 ? t_p8n : t_p8) < 0.95 * t_small) {
+      bool ok = false;
+      if (n192) ok = !d->b_kmajor ? launch_p8<false, false, 3>(g, s) : launch_p8<false, true, 3>(g, s);
+      if (!ok) ok = !d->b_kmajor ? launch_p8<false, false>(g, s) : launch_p8<false, true>(g, s);
       if (ok) return;
     }
   }
@@ -1153,6 +1212,8 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     HAMT_CHECK_ARG((uintptr_t)d.dy % 16 == 0 && (uintptr_t)d.x % 16 == 0, "hamt_wgrad_grouped: problem %d: operands must be 16-byte aligned", i);
     HAMT_CHECK_ARG(2.0 * d.K * d.ldy < 4294967296.0 && 2.0 * d.K * d.ldx < 4294967296.0, "hamt_wgrad_grouped: problem %d: operands must be smaller than 4 GiB (32-bit DMA offsets)", i);
     HAMT_CHECK_ARG(d.K_valid >= 0 && d.K_valid <= d.K, "hamt_wgrad_grouped: problem %d: K_valid = %d outside [0, K = %d]", i, d.K_valid, d.K);
+    HAMT_CHECK_ARG(d.wire_scale == 0.f || (!d.accum_dw && d.K > 0 && d.ldw % 8 == 0 && (uintptr_t)d.dw % 16 == 0),
+                   "hamt_wgrad_grouped: problem %d: a bf16 wire output (wire_scale != 0) is store-only and needs ldw %% 8 == 0 and a 16-byte aligned dw", i);
     if (d.K > 0) order.push_back(i);
     else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
   }
@@ -1225,11 +1286,13 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
         const Unit& un = units[u];
         const hamt_wgrad_desc& d = probs[un.prob];
         tiles += un.tiles;
-        flat.push_back(WgradProb{(const bf16_t*)d.dy + un.m_lo, (const bf16_t*)d.x, d.dw + (size_t)un.m_lo * d.ldw,
+        const bool wire = d.wire_scale != 0.f;     // bf16 output: the band's first row is m_lo * ldw ELEMENTS of 2 bytes further
+        float* dw_band = wire ? (float*)((bf16_t*)d.dw + (size_t)un.m_lo * d.ldw) : d.dw + (size_t)un.m_lo * d.ldw;
+        flat.push_back(WgradProb{(const bf16_t*)d.dy + un.m_lo, (const bf16_t*)d.x, dw_band,
                                  d.db ? d.db + un.m_lo : nullptr,
-                                 d.ss ? d.ss + (size_t)(un.m_lo >> 6) * ((d.N + 127) >> 7) : nullptr,     // (bands start on multiples of 64 rows)
+                                 (d.ss && !wire) ? d.ss + (size_t)(un.m_lo >> 6) * ((d.N + 127) >> 7) : nullptr,     // (bands start on multiples of 64 rows)
                                  un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
-                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, kv_of(d), 0});
+                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, kv_of(d), d.wire_scale});
         flat.back().K = keff(d);                        // whole k-tiles behind the last valid row are not multiplied at all
         launch_flops += 2.0 * un.m_rows * d.N * keff(d);
       }

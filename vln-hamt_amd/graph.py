@@ -162,6 +162,21 @@ class GraphedTrainStep:
         if overl:
             self.grad_sync.mode = "eager"
             plan = self.grad_sync.take_plan()  # the pass's weight-gradient GEMMs: launched between the two graphs
+            if plan is not None and os.environ.get("HAMT_NO_GROUP_GRAPHS") is None:
+                # each launch group (its table-write kernels + the grouped kernels) as a small graph of its own: replayed on the
+                # group's lane stream between the collectives, instead of 3-10 host launches per group in the eager section
+                from . import wgrad
+                plan.graphs = []
+                for gi, (_descs, n_) in enumerate(plan.groups):
+                    if not n_:
+                        plan.graphs.append(None)
+                        continue
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
+                        wgrad.launch_group(plan, gi)
+                    plan.graphs.append(gg)
+            if getattr(self.grad_sync, "sharded", False) and os.environ.get("HAMT_NO_GROUP_GRAPHS") is None:
+                self.grad_sync.capture_update(self.max_norm, self.pool, side, self.capture_mode)
         if self.grad_sync is not None and not getattr(self.grad_sync, "sharded", False):
             if self.update_graph is None:      # norm + AdamW over the arena: the same launches for every key
                 self.update_graph = torch.cuda.CUDAGraph()
@@ -218,14 +233,18 @@ class GraphedTrainStep:
         self.opt.prepare_step(active)
         g.replay()
         if self.grad_sync is not None:
+            sharded = getattr(self.grad_sync, "sharded", False)
             if plan is not None:
-                self.grad_sync.run(plan)       # wgrad groups + overlapped all-reduces
+                if sharded:
+                    self.grad_sync.run(plan, sumsq=True)   # wgrad groups + overlapped reduce-scatters, norm partials per range
+                else:
+                    self.grad_sync.run(plan)   # wgrad groups + overlapped all-reduces
             else:
                 self.opt._packed = True        # the replay packed the gradients; only the collective is left
                 self.grad_sync(self.opt)
                 self.opt._packed = False
-            if getattr(self.grad_sync, "sharded", False):
-                self.grad_sync.update(self.max_norm)     # eager: owned-slice norm + 4-byte all-reduce + AdamW + all-gathers
+            if sharded:
+                self.grad_sync.update(self.max_norm, have_sumsq=plan is not None)   # 4-byte all-reduce, AdamW (captured), all-gathers
                 ops.advance_rng_epoch(loss_c.device)
             else:
                 self.update_graph.replay()

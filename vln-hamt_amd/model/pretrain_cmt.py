@@ -4,6 +4,7 @@ contract (losses with reduction='none'; MRC and ITM return 2-tuples when compute
 """
 from __future__ import annotations
 
+import os
 from collections import defaultdict
 
 import torch
@@ -12,6 +13,14 @@ from torch import nn
 from .. import ops
 from ..modeling import precision_of
 from .vilmodel import BertLayerNorm, BertOnlyMLMHead, BertPreTrainedModel, NavPreTrainedModel
+
+
+# The five small prediction heads compute in exact fp32 (v_mfma_f32_16x16x4_f32) in bf16 mode too: they sit BEHIND the trunk, where
+# an error is no longer averaged by anything -- their LayerNorm re-scales whatever rounding the first dense layer added -- and they
+# are a few hundred to 2 400 rows of 768: ~0.02 ms per step averaged over the task mix.  Measured on the R2R-canon model at per-GPU
+# batch 16 (tests/golden/canon_multi.npz, three weight seeds): ITM logits 1.06e-2 / 1.35e-2 / 1.00e-2 off the reference with bf16
+# heads -- over north_star's 1e-2 -- against 8.6e-3 / 9.5e-3 / 5.2e-3 with fp32 heads.  HAMT_HEADS_BF16=1 restores bf16 heads.
+HEADS_FP32 = os.environ.get("HAMT_HEADS_BF16") is None
 
 
 class _MlpHead(nn.Module):
@@ -26,14 +35,19 @@ class _MlpHead(nn.Module):
         mods.append(nn.Linear(hidden_size, out_size))
         self.net = nn.Sequential(*mods)
         self.prec = prec
+        if HEADS_FP32:      # read as fp32 masters, never through the bf16 shadow: the fp32-read region of the optimizer's arena
+            mods[0].weight._hamt_fp32_read = True      # (what a sharded data-parallel update all-gathers in fp32, optim.adamw.shadow_only)
+            mods[-1].weight._hamt_fp32_read = True
 
     def forward(self, x):
         lin0, ln, last = self.net[0], self.net[2], self.net[-1]
         p = float(self.net[3].p) if (len(self.net) == 5 and self.training) else 0.0
-        h = ops.linear(x, lin0.weight, lin0.bias, ops.ACT_RELU, self.prec)
+        prec = "fp32" if HEADS_FP32 else self.prec
+        if prec == "fp32" and x.dtype != torch.float32:
+            x = x.float()
+        h = ops.linear(x, lin0.weight, lin0.bias, ops.ACT_RELU, prec)
         h = ops.layer_norm(h, None, ln, p_post=p)
-        # the 1..3 / 1000-wide output projections are tiny: keep them exact
-        return ops.linear(h, last.weight, last.bias, ops.ACT_NONE, self.prec)
+        return ops.linear(h, last.weight, last.bias, ops.ACT_NONE, prec)
 
 
 class NextActionPrediction(_MlpHead):          # pretrain_cmt.py:13-23

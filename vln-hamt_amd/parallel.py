@@ -199,7 +199,7 @@ class OverlappedGradSync:
 
     def _on_flush(self, items):
         from . import wgrad
-        plan = wgrad.build_plan(items, self.opt, self.n_groups)
+        plan = wgrad.build_plan(items, self.opt, self.n_groups, wire=self._wire_spec())
         if plan is None:                   # some parameter lives outside the arena: plain semantics
             ps = wgrad._Pass()
             ps.items = list(items)
@@ -215,6 +215,20 @@ class OverlappedGradSync:
     def take_plan(self):
         p, self.plan = self.plan, None
         return p
+
+    def _wire_spec(self):
+        """None, or (bf16 staging arena, scale, first element NOT covered) for weight-gradient launches that write the wire value
+        themselves (wgrad.build_plan)."""
+        return None
+
+    @staticmethod
+    def _launch_group(plan, g):
+        """group g's launches on the current stream: the captured graph when graph.GraphedTrainStep made one, else eagerly"""
+        from . import wgrad
+        if plan.graphs is not None and plan.graphs[g] is not None:
+            plan.graphs[g].replay()
+        else:
+            wgrad.launch_group(plan, g)
 
     def run(self, plan):
         """Launch the plan's groups with the arena all-reduces on the communication stream.  Consecutive groups go to two
@@ -252,7 +266,7 @@ class OverlappedGradSync:
             for d in plan.deps[g]:                 # a buffer written by group d and accumulated into by group g
                 ln.wait_event(done[d])
             with torch.cuda.stream(ln):
-                wgrad.launch_group(plan, g)
+                self._launch_group(plan, g)
             done.append(ln.record_event())
             reduce_ready(g)
         for ln in lanes:
@@ -355,15 +369,24 @@ class ShardedGradSync(OverlappedGradSync):
         self._ranges = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]      # static: see shard_cuts
         o._sharded_sync = self
         o._shard_stale = False             # True: moments / masters of foreign chunks are out of date (gather_state() clears)
-        self._stage = torch.empty(o._n, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
+        # bf16 staging arena of the wire format (same element offsets as the gradient arena).  Zero-initialised: slots of parameters
+        # without a gradient are exchanged as they are (the update skips such parameters), so they must at least be finite
+        self._stage = torch.zeros(o._n, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
+        self.direct_wire = wire == "bf16" and os.environ.get("HAMT_NO_DIRECT_WIRE") is None
         self._own16 = torch.empty(o._n // self.world + 8, dtype=torch.bfloat16, device=o._flat_g.device) if wire == "bf16" else None
         self._own32 = torch.empty(o._n // self.world + 8, dtype=torch.float32, device=o._flat_g.device)
         self._gsq = torch.zeros(1, dtype=torch.float32, device=o._flat_g.device)
+        self._upd = None                   # (norm graph, update graph, max_norm) once graph.GraphedTrainStep captured them
 
     def close(self):
         super().close()
         if getattr(self.opt, "_sharded_sync", None) is self:
             self.opt._sharded_sync = None
+
+    def _wire_spec(self):
+        if not self.direct_wire:
+            return None
+        return (self._stage, 1.0 / self.world, self.opt._n_shadow_only)
 
     # ---- collectives (gloo has neither reduce_scatter nor all_gather_into_tensor: same arithmetic through all_reduce / all_gather)
     def _reduce_scatter(self, out, inp):
@@ -391,28 +414,52 @@ class ShardedGradSync(OverlappedGradSync):
         else:
             dist.all_gather_into_tensor(buf, buf[self.rank * c:(self.rank + 1) * c])
 
-    def _exchange_range(self, lo, hi):
-        """flat_g[lo:hi] -> mean over ranks of chunk `rank`, written back in place; the rest of the range zeroed"""
+    def _exchange_range(self, lo, hi, plan=None, sumsq=None):
+        """flat_g[lo:hi] -> mean over ranks of chunk `rank`, written back in place.  bf16 wire with a plan whose launches wrote
+        their wire values themselves (`plan.pack_segs`, GEMM-weight region): only the listed fp32 segments are packed, and the
+        rest of the range is NOT zeroed -- nothing reads a gradient slot of that region outside the owned chunk (the weight-gradient
+        launches store, the update and the norm walk the owned segments).  Else: pack the range, zero it, write the owned chunk."""
         from . import _lib as L
         from .ops import _p, _stream
         g = self.opt._flat_g[lo:hi]
         c = (hi - lo) // self.world
         if self.wire == "bf16":
             st, own = self._stage[lo:hi], self._own16[:c]
-            L.check(L.load().hamt_wire_pack_bf16(hi - lo, _p(g), _p(st), 1.0 / self.world, _stream()), "hamt_wire_pack_bf16")
+            lib = L.load()
+            direct = plan is not None and plan.pack_segs is not None and hi <= self.opt._n_shadow_only
+            if direct:
+                for (so, sc) in plan.pack_segs:
+                    a, b = max(so, lo), min(so + sc, hi)
+                    if b > a:
+                        L.check(lib.hamt_wire_pack_bf16(b - a, _p(self.opt._flat_g[a:b]), _p(self._stage[a:b]), 1.0 / self.world, _stream()), "hamt_wire_pack_bf16")
+            else:
+                L.check(lib.hamt_wire_pack_bf16(hi - lo, _p(g), _p(st), 1.0 / self.world, _stream()), "hamt_wire_pack_bf16")
             self._reduce_scatter(own, st)
-            g.zero_()
-            L.check(L.load().hamt_wire_unpack_bf16(c, _p(own), _p(g[self.rank * c:(self.rank + 1) * c]), _stream()), "hamt_wire_unpack_bf16")
+            if not direct:
+                g.zero_()
+            L.check(lib.hamt_wire_unpack_bf16(c, _p(own), _p(g[self.rank * c:(self.rank + 1) * c]), _stream()), "hamt_wire_unpack_bf16")
         else:
             own = self._own32[:c]
             self._reduce_scatter(own, g)
             g.zero_()
             torch.mul(own, 1.0 / self.world, out=g[self.rank * c:(self.rank + 1) * c])
+        if sumsq is not None and c:
+            # this range's share of the global gradient norm, right behind its exchange on the communication stream (sumsq = is this
+            # the first range of the step?): hidden under the weight-gradient launches instead of a serial run of 2 x 9 small
+            # launches in front of the update.  Needs the step's hyper-parameter table (which parameters are active) on the device
+            # already: graph.GraphedTrainStep uploads it before the replay.
+            o = self.opt
+            f = lo + self.rank * c
+            L.check(L.load().hamt_sumsq_table(f, c, _p(o._flat_g[f:f + c]), _p(o._ends), _p(o._hyp), len(o._params), _p(self._gsq), int(not sumsq),
+                                              _p(o._ws), _stream()), "hamt_sumsq_table")
 
-    def run(self, plan):
-        """The plan's groups with the reduce-scatters on the communication stream (same overlap structure as the parent)."""
+    def run(self, plan, sumsq=False):
+        """The plan's groups with the reduce-scatters on the communication stream (same overlap structure as the parent).
+        sumsq: also reduce each range's owned chunk into the global squared norm as it arrives (see _exchange_range); `update`
+        is then called with have_sumsq=True."""
         from . import wgrad
         main = torch.cuda.current_stream()
+        n_done = [0]
         rng = getattr(plan, "_shard_rng", None)
         if rng is None:
             rng = plan._shard_rng = range_finality(self._ranges, plan.ranges)
@@ -429,7 +476,8 @@ class ShardedGradSync(OverlappedGradSync):
                 else:
                     self.comm.wait_stream(main)
                 with torch.cuda.stream(self.comm):
-                    self._exchange_range(lo, hi)
+                    self._exchange_range(lo, hi, plan, (n_done[0] == 0) if sumsq else None)
+                n_done[0] += 1
                 k += 1
 
         reduce_ready(-1)
@@ -442,7 +490,7 @@ class ShardedGradSync(OverlappedGradSync):
             for d in plan.deps[g]:
                 ln.wait_event(done[d])
             with torch.cuda.stream(ln):
-                wgrad.launch_group(plan, g)
+                self._launch_group(plan, g)
             done.append(ln.record_event())
             reduce_ready(g)
         for ln in lanes:
@@ -469,24 +517,60 @@ class ShardedGradSync(OverlappedGradSync):
                 out.append((lo + self.rank * c, c))
         return out
 
-    @torch.no_grad()
-    def update(self, max_norm: float):
-        """Global-norm clip + AdamW over the owned segments, then the all-gathers.  The host part (optimizer.prepare_step) must
-        have run; replaces clip_grad_norm_ + optimizer.step() + zero_grad() of the unsharded loop."""
+    def _launch_sumsq(self):
+        """sum of squares of the owned gradient chunks -> self._gsq (active parameters only: see optim.AdamW._keep)"""
         from . import _lib as L
         from .ops import _p, _stream
         o, lib = self.opt, L.load()
-        segs = self.owned()
-        for i, (f, c) in enumerate(segs):
+        for i, (f, c) in enumerate(self.owned()):
             L.check(lib.hamt_sumsq_table(f, c, _p(o._flat_g[f:f + c]), _p(o._ends), _p(o._hyp), len(o._params), _p(self._gsq), int(i > 0),
-                                         _p(o._ws), _stream()), "hamt_sumsq_table")      # (active parameters only: see optim.AdamW._keep)
-        if dist.is_initialized() and not DRY[0]:
-            dist.all_reduce(self._gsq, op=dist.ReduceOp.SUM)          # 4 bytes: the global squared norm
+                                         _p(o._ws), _stream()), "hamt_sumsq_table")
+
+    def _launch_adamw(self, max_norm: float):
+        """clip + AdamW over the owned chunks"""
+        from . import _lib as L
+        from .ops import _p, _stream
+        o, lib = self.opt, L.load()
         b1, b2 = o.param_groups[0]["betas"]
-        for f, c in segs:
+        for f, c in self.owned():
             L.check(lib.hamt_adamw_table_range(f, c, _p(o._flat_p[f:f + c]), _p(o._flat_g[f:f + c]), _p(o._flat_m[f:f + c]), _p(o._flat_v[f:f + c]),
                                                _p(o._flat_p16[f:f + c]), _p(o._ends), _p(o._hyp), len(o._params), _p(self._gsq), float(max_norm),
                                                b1, b2, o.param_groups[0]["eps"], 1, _stream()), "hamt_adamw_table_range")
+
+    def capture_update(self, max_norm: float, pool, stream, mode):
+        """graph.GraphedTrainStep: the two launch runs of `update` (norm partials; clip + AdamW) as captured graphs -- 2 x 9 launches
+        the host no longer issues one by one between the collectives of every step.  Everything they read is static (arena
+        pointers, owned segments, the device hyper-parameter table)."""
+        if self._upd is not None and self._upd[2] == float(max_norm):
+            return
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=pool, stream=stream, capture_error_mode=mode):
+            self._launch_sumsq()
+        with torch.cuda.graph(g2, pool=pool, stream=stream, capture_error_mode=mode):
+            self._launch_adamw(max_norm)
+        self._upd = (g1, g2, float(max_norm))
+
+    @torch.no_grad()
+    def update(self, max_norm: float, have_sumsq: bool = False):
+        """Global-norm clip + AdamW over the owned segments, then the all-gathers.  The host part (optimizer.prepare_step) must
+        have run; replaces clip_grad_norm_ + optimizer.step() + zero_grad() of the unsharded loop.  have_sumsq: the exchange
+        (`run(plan, sumsq=True)`) already left this rank's sum of squares in self._gsq."""
+        from . import _lib as L
+        from .ops import _p, _stream
+        o, lib = self.opt, L.load()
+        graphs = self._upd if (self._upd is not None and self._upd[2] == float(max_norm)) else None
+        if have_sumsq:
+            pass
+        elif graphs is not None:
+            graphs[0].replay()
+        else:
+            self._launch_sumsq()
+        if dist.is_initialized() and not DRY[0]:
+            dist.all_reduce(self._gsq, op=dist.ReduceOp.SUM)          # 4 bytes: the global squared norm
+        if graphs is not None:
+            graphs[1].replay()
+        else:
+            self._launch_adamw(max_norm)
         n_a = o._n_shadow_only
         for lo, hi in self._ranges:
             if hi <= n_a:

@@ -373,12 +373,37 @@ class Plan:
         self.ranges: List[tuple] = []
         self.deps: List[set] = []          # deps[g]: earlier groups that wrote a buffer group g accumulates into
         self.keep: list = []               # operand tensors: alive as long as the plan (graph replays re-use their memory)
+        self.pack_segs: Optional[list] = None   # wire mode: [(offset, count)] arena segments whose gradients are still fp32 in the
+        #                                         gradient arena when the groups have run (everything else active in the wire
+        #                                         region was written to the bf16 staging arena by the launches themselves)
+        self.graphs: Optional[list] = None      # per group: a captured hipGraph of its launches (graph.GraphedTrainStep)
 
 
-def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
+def build_plan(items, optimizer, n_groups: int = 4, wire=None) -> Optional[Plan]:
     """Resolve `items` to arena slots (every parameter must own one) and publish `.grad` views.  A parameter that
     already has an autograd-produced `.grad` gets accum = 1: the caller packs that gradient into the slot BEFORE the
-    groups run.  Returns None when some parameter has no arena slot (caller falls back to flush semantics)."""
+    groups run.  Returns None when some parameter has no arena slot (caller falls back to flush semantics).
+
+    `wire` = (stage16, scale, n_wire): a data-parallel exchange with bf16 on the wire (parallel.ShardedGradSync).  A weight gradient
+    that is STORED once in this pass into an arena slot below element `n_wire` (the GEMM-weight region) is then written by its
+    launch as bf16(scale * dW) straight into `stage16` (the exchange's staging arena, same element offsets) -- what the pack pass
+    over the fp32 arena would have produced -- and the fp32 slot is not written at all.  `plan.pack_segs` lists what is left for
+    the pack kernel in that region: weights written twice in the pass (shared cross-attention weights: fp32 accumulation first),
+    and gradients that came through autograd."""
+    return _build_plan(items, optimizer, n_groups, wire)
+
+
+def _merge_segs(segs):
+    out = []
+    for o, c in sorted(segs):
+        if out and out[-1][0] + out[-1][1] >= o:
+            out[-1] = (out[-1][0], max(out[-1][1], o + c - out[-1][0]))
+        else:
+            out.append((o, c))
+    return out
+
+
+def _build_plan(items, optimizer, n_groups, wire):
     flat_g = optimizer._flat_g
     base, n_total = flat_g.data_ptr(), flat_g.numel()
 
@@ -421,6 +446,10 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
     plan.deps = [{d for (g, d) in dep_pairs if g == gg} for gg in range(ng)]
     written: dict = {}
     per_group: List[list] = [[] for _ in range(ng)]
+    n_writes: dict = {}
+    for (ow, *_r) in probs:
+        n_writes[ow] = n_writes.get(ow, 0) + 1
+    direct = set()                         # arena offsets of the weights whose launch writes the bf16 wire value itself
     for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
         # (a gradient that exists already -- an autograd tensor the caller packs into the slot before the groups run, or the slot
         # itself holding what was added in place during the pass: an embedding table tied to this weight -- is accumulated onto)
@@ -430,6 +459,8 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
             ab = 1 if (ob in written or b.grad is not None) else 0
             written[ob] = True
         written[ow] = True
+        if wire is not None and not aw and n_writes[ow] == 1 and ow + w.numel() <= wire[2] and w.shape[1] % 8 == 0:
+            direct.add(ow)
         per_group[group_of[i]].append((ow, ob, w, b, dy16, x16, aw, ab))
         plan.keep += [dy16, x16]
     for grp in per_group:
@@ -441,6 +472,8 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), w.shape[1]
             d.accum_dw, d.accum_db = aw, ab
             d.K_valid = valid_rows(dy16)
+            if ow in direct:
+                d.dw, d.wire_scale = wire[0].data_ptr() + 2 * ow, float(wire[1])
         plan.groups.append((descs, len(grp)))
         plan.tables.append(torch.empty(max(1, table_entries(descs, len(grp))) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=flat_g.device))
     # arena ranges and the launch group after which each is final
@@ -461,6 +494,17 @@ def build_plan(items, optimizer, n_groups: int = 4) -> Optional[Plan]:
             w.grad = w._hamt_grad_slot
         if b is not None and b.grad is None:
             b.grad = b._hamt_grad_slot
+    if wire is not None:
+        # what the pack kernel still has to convert in the wire region: every parameter there that has a gradient now (queued
+        # weights just got theirs published; the rest came through autograd) and was not written directly
+        segs = []
+        for p, o in zip(optimizer._params, optimizer._offs):
+            if o >= wire[2]:
+                break
+            if p.grad is not None and o not in direct:
+                segs.append((o, (p.numel() + 7) // 8 * 8))
+        plan.pack_segs = _merge_segs(segs)
+        plan.keep.append(wire[0])
     return plan
 
 
