@@ -380,6 +380,10 @@ int hamt_sumsq_table(size_t first, size_t n, const float* g, const int* ends, co
 /* active == 3: like 2, and hamt_sumsq_table skips the parameter as well -- its sum of squares comes from the weight-gradient
  * tiles (hamt_wgrad_desc.ss).  hamt_sumsq_partials: out (+)= sum of the n floats of `partials` (fixed order). */
 int hamt_sumsq_partials(size_t n, const float* partials, float* out, int accumulate, void* stream);
+/* g[0 .. n) = float(y16[0 .. n)) and out (+)= sum of g^2 over the ACTIVE parameters (table as hamt_sumsq_table; `first` = arena offset
+ * of element 0): the widening of a reduce-scattered bf16 gradient chunk and its share of the global norm in one pass. */
+int hamt_wire_unpack_sumsq(size_t first, size_t n, const void* y16, float* g, const int* ends, const float* hyp, int nparams,
+                           float* out, int accumulate, float* ws, void* stream);
 /* g *= min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  -- standalone clip for torch-optimiser users */
 int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, void* stream);
 

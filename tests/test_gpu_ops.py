@@ -1022,6 +1022,31 @@ def test_wire_pack_unpack_bf16(off, n):
     assert torch.equal(base[:off], keep[:off]) and torch.equal(base[off + n:], keep[off + n:])
 
 
+def test_wire_unpack_sumsq():
+    """hamt_wire_unpack_sumsq: widen a bf16 chunk of the gradient arena to fp32 (every element) and add the sum of squares of the
+    ACTIVE parameters' elements (table flags as hamt_sumsq_table: 0 = no gradient this step, 3 = accounted for elsewhere)."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as L
+    ops = _ops()
+    sizes, flags = [1024, 2048, 512, 4096, 1536], [1.0, 0.0, 2.0, 3.0, 1.0]
+    ends = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device=DEV)
+    hyp = torch.zeros(len(sizes), 4, device=DEV)
+    hyp[:, 3] = torch.tensor(flags)
+    n_all = sum(sizes)
+    y = rnd(n_all, seed=4).to(torch.bfloat16).to(DEV)
+    first, n = 512, n_all - 512 - 1024                      # a chunk that starts and ends inside parameters
+    g = torch.full((n_all,), float("nan"), device=DEV)
+    out = torch.full((1,), 3.0, device=DEV)
+    ws = torch.empty(1024, device=DEV)
+    L.check(L.load().hamt_wire_unpack_sumsq(first, n, ops._p(y[first:first + n]), ops._p(g[first:first + n]), ops._p(ends), ops._p(hyp), len(sizes),
+                                            ops._p(out), 1, ops._p(ws), ops._stream()), "hamt_wire_unpack_sumsq")
+    torch.cuda.synchronize()
+    assert torch.equal(g[first:first + n], y[first:first + n].float()) and bool(torch.isnan(g[:first]).all()) and bool(torch.isnan(g[first + n:]).all())
+    act = torch.cat([torch.full((sz,), f not in (0.0, 3.0)) for sz, f in zip(sizes, flags)]).to(DEV)
+    want = 3.0 + float((y.double() ** 2)[first:first + n][act[first:first + n]].sum())
+    assert abs(float(out) - want) <= 1e-5 * want, (float(out), want)
+
+
 @pytest.mark.parametrize("normalize,with_ent", [("total", True), ("batch", False), ("none", True)])
 def test_a2c_loss_vs_reference_restatement(normalize, with_ent):
     """ops.a2c_loss (one scan kernel over [T, B]) against the statement-by-statement restatement of the agent's loop

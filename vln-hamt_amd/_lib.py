@@ -117,6 +117,7 @@ SIGNATURES = {
     "hamt_sumsq": [sz, vp, vp, i32, vp, vp],
     "hamt_sumsq_table": [sz, sz, vp, vp, vp, i32, vp, i32, vp, vp],
     "hamt_sumsq_partials": [sz, vp, vp, i32, vp],
+    "hamt_wire_unpack_sumsq": [sz, sz, vp, vp, vp, vp, i32, vp, i32, vp, vp],
     "hamt_adamw_flat": [sz, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table": [sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
     "hamt_adamw_table_range": [sz, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],

@@ -170,6 +170,47 @@ __global__ __launch_bounds__(256) void sumsq_table_partial_kernel(size_t n, cons
   __syncthreads();
   if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// The same walk fused with the widening of a reduce-scattered bf16 gradient chunk: g[i] = float(y16[i]) for EVERY element of the
+// chunk, sum of squares over the active parameters only -- one pass instead of hamt_wire_unpack_bf16 followed by hamt_sumsq_table
+// (the exchange of a data-parallel step runs this once per arena range, behind the range's reduce-scatter).
+__global__ __launch_bounds__(256) void unpack_sumsq_partial_kernel(size_t n, const bf16_t* __restrict__ y, float* __restrict__ g,
+                                                                   const int* __restrict__ ends, const float4* __restrict__ hyp, int nparams,
+                                                                   size_t first4, float* __restrict__ ws) {
+  const size_t n4 = n >> 2;
+  const size_t per_block = (n4 + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per_block, hi = min(n4, lo + per_block);
+  int pi = 0;
+  {
+    int a = 0, b = nparams - 1;
+    const long e0 = (long)(lo + first4) * 4;
+    while (a < b) { const int mid = (a + b) >> 1; if ((long)ends[mid] > e0) b = mid; else a = mid + 1; }
+    pi = a;
+  }
+  float s = 0.f;
+  for (size_t seg = lo; seg < hi; ++pi) {
+    const size_t pend = pi < nparams - 1 ? min(hi, ((size_t)ends[pi] >> 2) - first4) : hi;
+    const bool act = hyp[pi].w != 0.f && hyp[pi].w != 3.f;
+    for (size_t i = seg + threadIdx.x; i < pend; i += 256 * 4) {
+      uint2 u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = i + (size_t)q * 256 < pend ? ((const uint2*)y)[i + (size_t)q * 256] : make_uint2(0u, 0u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i + (size_t)q * 256 < pend) {
+          const float4 v = make_float4(__uint_as_float(u[q].x << 16), __uint_as_float(u[q].x & 0xffff0000u), __uint_as_float(u[q].y << 16), __uint_as_float(u[q].y & 0xffff0000u));
+          ((float4*)g)[i + (size_t)q * 256] = v;
+          if (act) s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+      }
+    }
+    seg = pend;
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ void clip_scale_kernel(size_t n, float* __restrict__ g, const float* __restrict__ gnorm_sq, float max_norm) {
   const float coef = clip_coef(gnorm_sq, max_norm);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= coef;
@@ -197,6 +238,19 @@ extern "C" int hamt_sumsq_table(size_t first, size_t n, const float* g, const in
   hipLaunchKernelGGL(sumsq_table_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ends, (const float4*)hyp, nparams, first / 4, ws);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
   HAMT_CHECK_LAUNCH("hamt_sumsq_table");
+  return HAMT_OK;
+}
+extern "C" int hamt_wire_unpack_sumsq(size_t first, size_t n, const void* y16, float* g, const int* ends, const float* hyp, int nparams,
+                                     float* out, int accumulate, float* ws, void* stream) {
+  HAMT_CHECK_ARG(y16 && g && out && ws && ends && hyp && nparams > 0 && n % 4 == 0 && first % 4 == 0 && ((uintptr_t)g % 16) == 0 &&
+                 ((uintptr_t)y16 % 8) == 0 && ((uintptr_t)hyp % 16) == 0,
+                 "hamt_wire_unpack_sumsq: bad argument (ws needs 1024 floats, g / hyp 16-byte and y16 8-byte aligned, first and n multiples of 4)");
+  hipStream_t s = as_stream(stream);
+  size_t b = (n / 4 + 1023) / 1024;
+  int nb = (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  hipLaunchKernelGGL(unpack_sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, n, (const bf16_t*)y16, g, ends, (const float4*)hyp, nparams, first / 4, ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
+  HAMT_CHECK_LAUNCH("hamt_wire_unpack_sumsq");
   return HAMT_OK;
 }
 // out (+)= sum of n floats, one block of 1024 threads, four independent 16-byte loads in flight per thread (the ~18 k tile
