@@ -5,7 +5,7 @@ CPU, operating on a flat ``state_dict``) of the arithmetic of the reference's
 ``pretrain_src/model/{vilmodel,pretrain_cmt}.py`` and of the finetune twin
 ``finetune_src/models/vilmodel_cmt.py``.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-it; the product package (``vln-hamt_amd/``) never does.
+it; the product package (``vln_hamt_amd/``) never does.
 
 Parity status: **pinned**.  ``oracle/gen_goldens.py`` imports the real reference
 from ``/root/reference`` (through ``oracle/ref_shim.py``), runs it on seeded

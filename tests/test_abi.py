@@ -65,8 +65,8 @@ def test_struct_layouts_match_header():
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing under vln-hamt_amd/ may import it (or torch CPU fallbacks)."""
-    pkg = os.path.join(ROOT, "vln-hamt_amd")
+    """The oracle is test infrastructure: nothing under vln_hamt_amd/ may import it (or torch CPU fallbacks)."""
+    pkg = os.path.join(ROOT, "vln_hamt_amd")
     for dp, _, fs in os.walk(pkg):
         for f in fs:
             if f.endswith(".py"):

@@ -3,7 +3,7 @@
 workgroup barrier, issuing DMA, reading fragments + issuing MFMAs).  Needs a private build of the library with the
 instrumentation compiled in -- never the shipped one:
 
-    rm vln-hamt_amd/csrc/build/gemm_fast.o; HAMT_EXTRA_FLAGS=-DHAMT_PROF python vln-hamt_amd/csrc/build.py
+    rm vln_hamt_amd/csrc/build/gemm_fast.o; HAMT_EXTRA_FLAGS=-DHAMT_PROF python vln_hamt_amd/csrc/build.py
     python tools/gemm_prof.py            # then rebuild without the flag
 
 Reports per-wave average shader cycles per k-tile for a few shapes / tile heights and for the grouped weight-gradient

@@ -1,9 +1,14 @@
-"""Importable alias for the product package, which lives in ``vln-hamt_amd/`` (a hyphen is not a
-valid Python identifier).  ``import vln_hamt_amd`` resolves every submodule from that directory."""
-import os as _os
+"""vln_hamt_amd: MI355X-native implementation of the HAMT hot path (model forward/backward).
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "vln-hamt_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+(`vln-hamt_amd` at the repository root is a symbolic link to this directory.)  Layout:
+
+* ``csrc/``            hand-written HIP kernels for gfx950 + the C-ABI (``include/hamt.h``)
+* ``_lib.py``          ctypes loader for ``libhamt_hip.so`` (fails loudly when missing)
+* ``ops.py``           autograd Functions over the C-ABI
+* ``model/``           mirror of the reference's ``pretrain_src/model`` class surface
+* ``models/``          mirror of ``finetune_src/models``
+* ``optim/``           HF-style AdamW / schedule / name-based decay groups on the flat arenas
+* ``parallel.py``      data-parallel gradient reduction over RCCL
+* ``synth.py``         synthetic batches with the reference's collate conventions
+"""
+__version__ = "0.1.0"

@@ -1,7 +1,7 @@
 """ctypes binding of libhamt_hip.so (include/hamt.h).
 
 The product path has NO fallback: if the library is missing, or a call returns a negative status,
-this module raises.  Build it with ``python vln-hamt_amd/csrc/build.py`` (or
+this module raises.  Build it with ``python vln_hamt_amd/csrc/build.py`` (or
 ``__graft_entry__.build()``).
 """
 from __future__ import annotations
@@ -138,7 +138,7 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise HamtError(f"{LIB_PATH} is missing: build it with `python vln-hamt_amd/csrc/build.py` "
+        raise HamtError(f"{LIB_PATH} is missing: build it with `python vln_hamt_amd/csrc/build.py` "
                         "(there is no CPU/PyTorch fallback for the HAMT kernels)")
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():

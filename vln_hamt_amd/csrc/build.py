@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Build libhamt_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python vln-hamt_amd/csrc/build.py [--force]
+    python vln_hamt_amd/csrc/build.py [--force]
 
-Objects go to csrc/build/, the library next to the Python package (vln-hamt_amd/libhamt_hip.so), so it
+Objects go to csrc/build/, the library next to the Python package (vln_hamt_amd/libhamt_hip.so), so it
 travels with the tree to the GPU box.  Re-compiles only sources newer than their object.
 """
 import os

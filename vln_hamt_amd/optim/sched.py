@@ -1,10 +1,5 @@
-"""Learning-rate schedules with the reference's semantics (pretrain_src/optim/sched.py:10-30)."""
-
-
-def noam_schedule(step, warmup_step=4000):
-    if step <= warmup_step:
-        return step / warmup_step
-    return (warmup_step ** 0.5) * (step ** -0.5)
+"""The learning-rate schedule the pretraining loop uses (pretrain_src/optim/sched.py:17-30: linear warm-up, linear decay, floor 1e-8;
+main_r2r.py:255).  The reference's `noam_schedule` (sched.py:10-14) has no caller on the path and is not mirrored."""
 
 
 def warmup_linear(step, warmup_step, tot_step):
