@@ -301,8 +301,8 @@ def test_unzeroed_weight_gradient_slots_do_not_leak(tiny, monkeypatch):
             assert abs(norms[-1] - ref) <= 1e-5 * ref, (i, t, norms[-1], ref)      # table norm + the weight-gradient tiles' sums == torch's norm
             o.step()
             o.zero_grad()
-            if i == 1:          # after the mlm step: the sap head (net.0.weight is a GEMM weight) did not train in it
-                w = m.next_action.net[0].weight
+            if i == 1:          # after the mlm step: the observation embedder (img_linear.weight is a GEMM weight) did not train in it
+                w = m.bert.img_embeddings.img_linear.weight      # (the prediction heads compute in fp32 since round 3: their slots are zeroed)
                 stale = float(w._hamt_grad_slot.abs().max())
         torch.cuda.synchronize()
         return m, o, norms, stale
