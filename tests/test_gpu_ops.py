@@ -193,22 +193,22 @@ def test_gemm_k_groups(layout, shape, variant):
 BENCH_GEMMS = [   # (layout, M, N, K, epilogue, C dtype, kernel the launcher must pick)
     ("nt", 5120, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false, 3>"),       # text QKV: 240 tiles of 256 x 192 = one full round
     ("nt", 7872, 2304, 768, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),   # packed QKV over text + vision rows: two rounds of either 256-row tile -> plain 128-row tiles
-    ("nt", 11520, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false>"),         # panorama QKV
-    ("nt", 5120, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false>"),    # text FFN-1 (+ saved gelu')
-    ("nt", 11520, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false>"),   # panorama FFN-1
+    ("nt", 11520, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false, 4>"),         # panorama QKV
+    ("nt", 5120, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false, 4>"),    # text FFN-1 (+ saved gelu')
+    ("nt", 11520, 3072, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false, 4>"),   # panorama FFN-1
     ("nt", 5003, 2304, 768, "bias", "bf16", "gemm_p8_kernel<1, false, false, 3>"),       # ragged last tile row
     ("nt", 5120, 2304, 768, "gelugrad", "bf16", "gemm_p8_kernel<129, false, false, 3>"), # (FFN-1's epilogue on the narrow tile)
     ("nt", 5120, 2250, 768, "bias", "f32", "gemm_p8_kernel<1, false, false, 3>"),        # ragged last 192-column tile (138 columns), fp32 C
-    ("nt", 5120, 2318, 768, "bias", "f32", "gemm_p8_kernel<1, false, false>"),           # ragged last tile column, fp32 C
+    ("nt", 5120, 2318, 768, "bias", "f32", "gemm_p8_kernel<1, false, false, 4>"),           # ragged last tile column, fp32 C
     ("nt", 11520, 768, 3072, "bias", "bf16", "gemm_p8_kernel<1, false, false, 3>"),      # panorama FFN-2
-    ("nt", 11520, 768, 3072, "drop_res", "f32", "gemm_p8_kernel<1537, false, false>"),   # bias + dropout + residual (pre-LN ViT form)
-    ("nn", 5120, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),       # dgrad of FFN-2 x gelu'
+    ("nt", 11520, 768, 3072, "drop_res", "f32", "gemm_p8_kernel<1537, false, false, 4>"),   # bias + dropout + residual (pre-LN ViT form)
+    ("nn", 5120, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 4>"),       # dgrad of FFN-2 x gelu'
     ("nn", 11520, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 3>"),
     ("nn", 11520, 768, 3072, "acc", "f32", "gemm_p8_kernel<8, false, true, 3>"),         # dgrad of FFN-1 into the residual gradient
     ("nn", 11520, 768, 2304, "acc", "f32", "gemm_p8_kernel<8, false, true, 3>"),         # dgrad of QKV into the residual gradient
     ("nn", 5120, 2304, 768, "none", "bf16", "gemm_p8_kernel<0, false, true, 3>"),
     ("nn", 5013, 2248, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 3>"),    # ragged rows and a ragged 192-column tile, K-strided B
-    ("nn", 5009, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true>"),       # ragged rows
+    ("nn", 5009, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 4>"),       # ragged rows
     ("nt", 5120, 768, 768, "bias", "bf16", "gemm_fast_kernel<64, 1, false, false>"),     # attention output projection
     ("nn", 5120, 768, 768, "none", "bf16", "gemm_fast_kernel<64, 0, false, true>"),      # its dgrad
     ("nt", 2752, 768, 768, "bias", "f32", "gemm_fast_kernel<64, 1, false, false>"),      # vision stream

@@ -957,7 +957,7 @@ bool launch_p8(const GemmArgsF& g, hipStream_t s) {
   const dim3 grid(((g.M + 255) / 256) * ((g.N + 64 * NB - 1) / (64 * NB)));
   const int e = g.epi;
 #define HAMT_L(E) do { hipLaunchKernelGGL((gemm_p8_kernel<E, A_KM, B_KM, NB>), grid, dim3(512), 0, s, g); \
-                    hamt_set_last_kernel(NB == 4 ? "gemm_p8_kernel<%d, %s, %s>" : "gemm_p8_kernel<%d, %s, %s, 3>", (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false"); } while (0)
+                    hamt_set_last_kernel("gemm_p8_kernel<%d, %s, %s, %d>", (int)(E), A_KM ? "true" : "false", B_KM ? "true" : "false", NB); } while (0)
   if (e == 0) HAMT_L(0);
   else if (e == HAMT_EPI_BIAS) HAMT_L(HAMT_EPI_BIAS);
   else if (e == HAMT_EPI_ACCUM) HAMT_L(HAMT_EPI_ACCUM);

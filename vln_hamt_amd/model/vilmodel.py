@@ -582,7 +582,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
                 ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)
             return hist, ob
 
-        if txt_ids.is_cuda and streams.two_stream_enabled():
+        if txt_ids.is_cuda and streams.two_stream_enabled("trunk"):
             # history / observation embedders (incl. the panorama encoder) on the second stream, next to the text embedder
             # and the text-only layers: the two chains do not meet before the first cross-modal layer
             main = torch.cuda.current_stream()
@@ -650,7 +650,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
                 neg_m.append(hist_m)
             return torch.cat([hist] + neg_h, 0), torch.cat([hist_m] + neg_m, 0)
 
-        if txt_ids.is_cuda and streams.two_stream_enabled():     # history side next to the text side, as in forward()
+        if txt_ids.is_cuda and streams.two_stream_enabled("trunk"):     # history side next to the text side, as in forward()
             main = torch.cuda.current_stream()
             side = streams.side_stream(dev)
             streams.fork(main, side)

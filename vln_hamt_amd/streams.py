@@ -12,11 +12,14 @@ import os
 import torch
 
 _ENABLED = [os.environ.get("HAMT_NO_XSTREAM") is None]
+# which of the two regions use the second stream: "all" (default), "xlayers" (the vision side of the cross-modal layers only),
+# "trunk" (the history / observation embedders incl. the panorama encoder next to the text layers only) -- measurement switch
+_MODE = os.environ.get("HAMT_XSTREAM_MODE", "all")
 _side: dict = {}
 
 
-def two_stream_enabled() -> bool:
-    return _ENABLED[0]
+def two_stream_enabled(where: str = "xlayers") -> bool:
+    return _ENABLED[0] and _MODE in ("all", where)
 
 
 def set_two_stream(flag: bool):
