@@ -30,7 +30,9 @@ def side_stream(device) -> torch.cuda.Stream:
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     s = _side.get(key)
     if s is None:
-        s = _side[key] = torch.cuda.Stream(device=key)
+        # HAMT_SIDE_PRIORITY = -1 / 0: measurement switch (default stream priority otherwise)
+        pr = os.environ.get("HAMT_SIDE_PRIORITY")
+        s = _side[key] = torch.cuda.Stream(device=key, priority=int(pr)) if pr is not None else torch.cuda.Stream(device=key)
     return s
 
 
