@@ -17,6 +17,7 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
   vit.npz             ViT backbone features / gradients from the reference's VisionTransformer class
   collate.npz         outputs of the reference's six *_collate functions on seeded ragged samples
   r2r_tiny/ + r2r_data.npz   a tiny R2R-style dataset (data files) and what the reference's MultiStepNavData reads / builds from it
+  r2r_tasks.npz       items of the reference's six task datasets under fixed python / numpy seeds
   loader.npz          (task, batch) sequences of the reference's MetaLoader and build_dataloader's loader attributes
 Weights always come from oracle.hamt_oracle.make_state_dict (numpy PCG64), never from random init.
 """
@@ -699,6 +700,37 @@ def gen_r2r_data():
     print("r2r_data.npz:", len(store), "arrays from the reference's MultiStepNavData on tests/golden/r2r_tiny")
 
 
+TASK_DS_CASES = [("mlm", [0, 2, 5]), ("mrc", [1, 3, 4]), ("itm", [0, 4]), ("sap", [0, 3, 7, 11, 14]), ("sar", [1, 2, 9, 13]), ("sprel", [0, 5, 8, 12])]
+
+
+def task_datasets(mod, db):
+    import types
+    tok = types.SimpleNamespace(cls_token_id=101, sep_token_id=102, mask_token_id=103, pad_token_id=0)
+    return {"mlm": mod.MlmDataset(db, tok), "mrc": mod.MrcDataset(db, tok, 0.5), "itm": mod.ItmDataset(db, tok),
+            "sap": mod.SapDataset(db, tok, 0.3, 0.43), "sar": mod.SarDataset(db, tok, 0.3, 0.43), "sprel": mod.SprelDataset(db, tok, 0.3, 0.43)}
+
+
+def gen_r2r_tasks():
+    """Row N4 (task datasets): the reference's six Dataset classes (r2r_tasks.py) over its own MultiStepNavData on the tiny dataset,
+    python / numpy / torch RNGs seeded per item: word masking, region masks, view / angle kills, SPREL anchors and targets."""
+    import random
+    make_r2r_tiny()
+    rd = ref_shim.import_r2r_data(os.path.join(R2R_TINY, "img_fts.npz"))
+    rt = ref_shim.import_collate()
+    db = rd.MultiStepNavData(**r2r_tiny_kwargs())
+    dss = task_datasets(rt, db)
+    store = {}
+    for task, idxs in TASK_DS_CASES:
+        store[f"{task}/len"] = np.asarray(len(dss[task]))
+        for i in idxs:
+            random.seed(1000 + i); np.random.seed(2000 + i); torch.manual_seed(3000 + i)
+            item = dss[task][i]
+            for k, v in item.items():
+                store[f"{task}/{i}/{k}"] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "r2r_tasks.npz"), **store)
+    print("r2r_tasks.npz:", len(store), "arrays from the reference's six task datasets")
+
+
 LOADER_RATIOS = {"mlm": 5, "sap": 1, "itm": 2}
 
 
@@ -747,7 +779,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "loader", "canon_multi"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi"]
     for w in which:
         {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
-         "r2r_data": gen_r2r_data, "loader": gen_loader, "canon_multi": gen_canon_multi}[w]()
+         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi}[w]()

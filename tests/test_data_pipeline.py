@@ -187,3 +187,39 @@ def test_metaloader_shared_seed_schedule_needs_no_collective():
     assert abs(frac - 5 / 8) < 0.08, frac
     c = tasks(7, 2, 40)
     assert c[0::2] == c[1::2] and c[0::2] == a[:20]
+
+
+# ------------------------------------------------------------------------------------------------ the six task datasets
+TASK_DS_CASES = [("mlm", [0, 2, 5]), ("mrc", [1, 3, 4]), ("itm", [0, 4]), ("sap", [0, 3, 7, 11, 14]), ("sar", [1, 2, 9, 13]), ("sprel", [0, 5, 8, 12])]
+
+
+@pytest.mark.parametrize("task,idxs", TASK_DS_CASES)
+def test_task_datasets_match_the_reference_classes(task, idxs):
+    """Same python / numpy / torch seeds -> the same items as the reference's MlmDataset ... SprelDataset (r2r_tasks.py): word
+    masking and labels, region masks with zeroed views, view / angle kills, action targets, SPREL anchors and targets.  The
+    items then go through this package's own *_collate + device unpack (the path a DataLoader takes)."""
+    import random
+    from vln_hamt_amd.data import r2r_tasks as T
+    from vln_hamt_amd.data.r2r_data import MultiStepNavData
+    g = np.load(os.path.join(GOLD, "r2r_tasks.npz"))
+    db = MultiStepNavData(**_kw())
+    tok = types.SimpleNamespace(cls_token_id=101, sep_token_id=102, mask_token_id=103, pad_token_id=0)
+    ds = {"mlm": lambda: T.MlmDataset(db, tok), "mrc": lambda: T.MrcDataset(db, tok, 0.5), "itm": lambda: T.ItmDataset(db, tok),
+          "sap": lambda: T.SapDataset(db, tok, 0.3, 0.43), "sar": lambda: T.SarDataset(db, tok, 0.3, 0.43),
+          "sprel": lambda: T.SprelDataset(db, tok, 0.3, 0.43)}[task]()
+    assert len(ds) == int(g[f"{task}/len"])
+    items = []
+    for i in idxs:
+        random.seed(1000 + i); np.random.seed(2000 + i); torch.manual_seed(3000 + i)
+        item = ds[i]
+        items.append(item)
+        keys = {k.split("/")[2] for k in g.files if k.startswith(f"{task}/{i}/")}
+        assert keys == set(item), (task, i, keys ^ set(item))
+        for k, v in item.items():
+            want = g[f"{task}/{i}/{k}"]
+            got = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+            assert got.shape == want.shape and got.dtype == want.dtype, (task, i, k, got.dtype, want.dtype, got.shape, want.shape)
+            assert np.array_equal(got, want), (task, i, k)
+    # the items are what the collate functions take (host packing only: no GPU here)
+    packed = getattr(T, f"{task}_collate")(items)
+    assert packed.B == len(items) and packed.nbytes > 0
