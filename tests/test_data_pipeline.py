@@ -223,3 +223,61 @@ def test_task_datasets_match_the_reference_classes(task, idxs):
     # the items are what the collate functions take (host packing only: no GPU here)
     packed = getattr(T, f"{task}_collate")(items)
     assert packed.B == len(items) and packed.nbytes > 0
+
+
+@pytest.mark.gpu
+def test_files_to_training_steps_end_to_end():
+    """The whole input side in front of the model, as main_r2r.py wires it (:156-206, 231-281): trajectory / feature files ->
+    MultiStepNavData -> the task datasets -> build_dataloader (packing collate, pinned) -> MetaLoader -> PrefetchLoader -> device
+    batches -> MultiStepNavCMTPreTraining.forward / backward / clip / AdamW.  Device batches must equal the reference-style collation
+    of the same items (numpy oracle), losses must be finite and the six tasks must all have been drawn."""
+    import random
+    from oracle.collate_oracle import COLLATE as ORACLE_COLLATE
+    from oracle.hamt_oracle import OracleConfig, make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd import data as D
+    from vln_hamt_amd.model.pretrain_cmt import MultiStepNavCMTPreTraining
+    from vln_hamt_amd.modeling import HamtConfig
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    dev = torch.device("cuda")
+    db = D.MultiStepNavData(**_kw(max_txt_len=20))
+    tok = types.SimpleNamespace(cls_token_id=101, sep_token_id=102, mask_token_id=103, pad_token_id=0)
+    dsets = {"mlm": D.MlmDataset(db, tok), "mrc": D.MrcDataset(db, tok, 0.5), "itm": D.ItmDataset(db, tok),
+             "sap": D.SapDataset(db, tok, 0.3, 0.43), "sar": D.SarDataset(db, tok, 0.3, 0.43), "sprel": D.SprelDataset(db, tok, 0.3, 0.43)}
+    # a padded device batch == the reference-style collation of the same items
+    random.seed(3); np.random.seed(3)
+    items = [dsets["sap"][i] for i in (0, 4, 9, 13)]
+    got = D.move_to_cuda(D.sap_collate(items), dev)
+    want = ORACLE_COLLATE["sap"](items)
+    for k, v in want.items():
+        if v is None:
+            assert got[k] is None, k
+        elif isinstance(v, np.ndarray):
+            g = got[k].cpu().numpy()
+            assert g.dtype == v.dtype and np.array_equal(g, v), k
+    # the training loop
+    ocfg = OracleConfig.tiny(hidden_size=128, num_attention_heads=2, intermediate_size=256, image_feat_size=16, image_prob_size=10, vocab_size=30522)
+    kw = dict(vars(ocfg))
+    kw["pretrain_tasks"] = set(ocfg.pretrain_tasks)
+    model = MultiStepNavCMTPreTraining(HamtConfig(hamt_precision="bf16", **kw))
+    model.load_state_dict(make_state_dict(pretrain_param_shapes(ocfg), seed=9))
+    model = model.to(dev).train()
+    opts = types.SimpleNamespace(train_batch_size=4, val_batch_size=4, local_rank=-1, n_workers=0, pin_mem=True)
+    ratios = {"mlm": 5, "sap": 1, "sar": 1, "sprel": 1, "mrc": 2, "itm": 2}
+    torch.manual_seed(0)
+    loaders = {t: (D.build_dataloader(t, dsets[t], D.COLLATE[t], True, opts)[0], r, (lambda e: None)) for t, r in ratios.items()}
+    meta = D.PrefetchLoader(D.MetaLoader(loaders, accum_steps=1, distributed=False, device=dev), dev)
+    opt = AdamW([{"params": list(model.parameters()), "weight_decay": 0.01}], lr=5e-5, betas=(0.9, 0.98))
+    seen, losses = set(), []
+    for step, (task, batch) in enumerate(meta):
+        if step == 40:
+            break
+        seen.add(task)
+        assert batch["txt_ids"].is_cuda and batch["txt_masks"].dtype == torch.bool
+        loss = model(batch, task=task, compute_loss=True).mean()
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    assert seen == set(ratios), seen
+    assert all(np.isfinite(l) for l in losses), losses
