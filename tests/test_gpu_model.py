@@ -1114,7 +1114,10 @@ def test_uninitialised_memory_never_reaches_a_result(B):
             # re-round: up to ~3e-4 on every weight.  The key bias of an attention has a zero true gradient (rounding noise only).
             if n.endswith("key.bias"):
                 continue
-            tol = {"sprel": 5e-3, "itm": 5e-2}.get(task, 1e-4)      # (ITM's net gradient is what is left of five candidates' terms cancelling)
+            # (ITM's net gradient is what is left of five candidates' terms cancelling.  The other tasks: 1e-4 held in > 40 runs and
+            # failed once in a full-suite run at 1.6e-3 of a 6e-3 gradient -- atomics order on two streams; a poisoned read shows
+            # as NaN / inf or as an O(1) difference, so 5e-3 loses nothing of what this test is for)
+            tol = {"itm": 5e-2}.get(task, 5e-3)
             assert float((a - c).abs().max()) <= tol * max(float(a.abs().max()), 1e-6), (task, n, float((a - c).abs().max()), float(a.abs().max()))
     del model
     torch.cuda.empty_cache()
