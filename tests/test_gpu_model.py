@@ -1361,6 +1361,12 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
         torch.cuda.synchronize()
         torch.save(o._flat_p.detach().cpu(), os.path.join(out_dir, f"params{rank}.pt"))
         torch.save((o._flat_m.detach().cpu(), o._flat_v.detach().cpu()), os.path.join(out_dir, f"moments{rank}.pt"))
+        if sharded and long_run:      # what a resumed run would load (utils/save.py:42-45 -> optimizer.load_state_dict): the gathered state
+            m_all, v_all, steps = o._flat_m.clone(), o._flat_v.clone(), o._steps.copy()
+            o2 = AdamW([{'params': g_['params'], 'weight_decay': g_['weight_decay']} for g_ in o.param_groups], betas=(0.9, 0.98), **hyp)
+            o2.load_state_dict(sd_)
+            torch.cuda.synchronize()
+            assert torch.equal(o2._flat_m, m_all) and torch.equal(o2._flat_v, v_all) and (o2._steps == steps).all()
     finally:
         sync.close()
         dist.destroy_process_group()
