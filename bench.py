@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak, same guide
-H, FFN, L_TXT, T_HIST, V = 768, 3072, 80, 5, 36
+H, FFN, L_TXT, T_HIST, V = 768, 3072, int(os.environ.get("HAMT_BENCH_L", 80)), 5, 36      # (HAMT_BENCH_L: what-if measurements only)
 
 
 def layer_flops(S):            # 24*S*H^2 + 4*S^2*H

@@ -185,6 +185,16 @@ int hamt_attn_small_bwd(const hamt_attn_desc* d, const void* q, const void* k, c
                         const float* add_mask, const void* o, const void* d_o, const float* lse,
                         float* delta, void* dq, void* dk, void* dv, const uint64_t* rng, void* stream);
 
+/* Packed ("varlen") self-attention, bf16 path: the B sequences lie back to back, sample b owns rows [cu_seqlens[b], cu_seqlens[b + 1])
+ * of q / k / v / o / d_o / dq / dk / dv (row strides as in the descriptor), at most d->Sq = d->Sk <= 128 tokens each, every key real (no
+ * mask); lse is [B, heads, d->Sq].  = hamt_attn_small_* on the real tokens of a padded batch (vilmodel.py:96-129) without computing
+ * the padded rows; a sequence of length 0 is skipped. */
+int hamt_attn_varlen_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_seqlens,
+                         void* o, float* lse, const uint64_t* rng, void* stream);
+int hamt_attn_varlen_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_seqlens,
+                         const void* o, const void* d_o, const float* lse, void* dq, void* dk, void* dv,
+                         const uint64_t* rng, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ln: y = dropout_post( LayerNorm( dropout_pre(x) + residual ) )      fp32 statistics
  *   BertSelfOutput / BertOutput (A3/A5, vilmodel.py:139-143, 181-185): p_pre = p, residual, p_post = 0

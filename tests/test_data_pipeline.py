@@ -265,14 +265,15 @@ def test_files_to_training_steps_end_to_end():
     ratios = {"mlm": 5, "sap": 1, "sar": 1, "sprel": 1, "mrc": 2, "itm": 2}
     torch.manual_seed(0)
     loaders = {t: (D.build_dataloader(t, dsets[t], D.COLLATE[t], True, opts)[0], r, (lambda e: None)) for t, r in ratios.items()}
-    meta = D.PrefetchLoader(D.MetaLoader(loaders, accum_steps=1, distributed=False, device=dev), dev)
+    meta = D.PrefetchLoader(D.MetaLoader(loaders, accum_steps=1, distributed=False, device=dev), dev, text_pack=True)
     opt = AdamW([{"params": list(model.parameters()), "weight_decay": 0.01}], lr=5e-5, betas=(0.9, 0.98))
-    seen, losses = set(), []
+    seen, losses, n_packed = set(), [], 0
     for step, (task, batch) in enumerate(meta):
         if step == 40:
             break
         seen.add(task)
         assert batch["txt_ids"].is_cuda and batch["txt_masks"].dtype == torch.bool
+        n_packed += "txt_pack_idx" in batch
         loss = model(batch, task=task, compute_loss=True).mean()
         loss.backward()
         clip_grad_norm_(model.parameters(), 5.0, optimizer=opt)

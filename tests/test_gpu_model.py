@@ -12,6 +12,14 @@ import torch
 
 from _util import batch_from, load_npz, sub, tiny_cfg
 
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max|d|={err:.3e} scale={scale:.3e} tol={tol}"
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = {"fp32": 1e-3, "bf16": 1e-2}
@@ -1282,6 +1290,95 @@ def test_overlapped_update_gates_every_parameter_read(tiny, which):
     assert max(abs(a - c) for a, c in zip(l1, l2)) < 5e-4, (l1, l2)
     worst = max(float((a - c).abs().max()) for (_, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()))
     assert worst < 1e-4, worst
+
+
+@pytest.mark.parametrize("task", ["mlm", "sap", "itm"])
+def test_text_packing_matches_the_padded_batch(tiny, task):
+    """A ragged batch with a text packing plan (`txt_pack_idx` / `txt_cu` / `txt_unpack_idx`: the nine text-only layers run on the real
+    tokens back to back, self-attention per sequence by hamt_attn_varlen_*, vilmodel.NavPreTrainedModel._text) against the same
+    batch computed the reference's way (every padded position through every layer, vilmodel.py:441-443): same losses, same text
+    embeddings at every REAL position, same history / observation embeddings, same parameter gradients (dropout off).  bf16 mode
+    (the packed form exists on the bf16 path); the two runs pick different GEMM tiles for their different row counts, hence 1e-2."""
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+    _, cfg, sd = tiny
+    m = build(cfg, sd, "bf16")
+    named = list(m.named_parameters())
+    b_pack = make_batch(task, 24, cfg, seed=91, txt_len=64, hist_len=4, ragged=True, device=DEV)
+    assert "txt_pack_idx" in b_pack and b_pack["txt_pack_idx"].numel() < b_pack["txt_ids"].numel()
+    assert int(b_pack["txt_cu"][-1]) == b_pack["txt_pack_idx"].numel()
+    if task == "itm":
+        r = make_itm_rng(b_pack, seed=3)
+        b_pack["itm_neg_idxs"], b_pack["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
+    b_pad = {k: v for k, v in b_pack.items() if k not in ("txt_pack_idx", "txt_cu", "txt_unpack_idx")}
+    outs = []
+    for b in (b_pack, b_pad):
+        for _, p in named:
+            p.grad = None
+        loss = m(b, task, True)
+        loss.mean().backward()
+        emb = None
+        if task != "itm":
+            with torch.no_grad():
+                if "txt_pack_idx" in b:
+                    b["txt_ids"]._hamt_pack = (b["txt_pack_idx"], b["txt_cu"], b["txt_unpack_idx"])
+                else:
+                    b["txt_ids"]._hamt_pack = None
+                g = b.get
+                emb = m.bert(g("txt_ids"), g("txt_masks"), g("hist_img_fts"), g("hist_ang_fts"), g("hist_pano_img_fts"), g("hist_pano_ang_fts"),
+                             g("hist_masks"), g("ob_img_fts"), g("ob_ang_fts"), g("ob_nav_types"), g("ob_masks"))
+        outs.append((loss.detach().clone(), emb, {n: p.grad.detach().clone() for n, p in named if p.grad is not None}))
+    (l1, e1, g1), (l0, e0, g0) = outs
+    assert rel_err(l1, l0.cpu().numpy()) <= 1e-2
+    if e1 is not None:
+        real = b_pack["txt_masks"].unsqueeze(-1)
+        assert rel_err(e1[0] * real, (e0[0] * real).cpu().numpy()) <= 1e-2                 # text at the real positions
+        assert rel_err(e1[1], e0[1].cpu().numpy()) <= 1e-2                                # history
+        if e1[2] is not None:
+            assert rel_err(e1[2], e0[2].cpu().numpy()) <= 1e-2
+    assert set(g1) == set(g0)
+    num = sum(float((g1[n].double() * g0[n].double()).sum()) for n in g0)
+    den = (sum(float((g1[n].double() ** 2).sum()) for n in g0) * sum(float((g0[n].double() ** 2).sum()) for n in g0)) ** 0.5
+    print(f"[text packing {task}] gradient cosine packed vs padded {num / den:.6f}")
+    assert num / den >= (0.995 if task == "itm" else 0.9995), num / den
+
+
+@pytest.mark.parametrize("lens", [[80, 80, 3, 17], [1, 2, 128, 64, 33], [16] * 9])
+def test_attention_varlen_matches_per_sequence_attention(lens):
+    """hamt_attn_varlen_fwd / _bwd on sequences packed back to back == hamt_attn_small_* run on each sequence alone (same kernels,
+    same per-(head, query) dropout stream keyed by the sequence index): outputs, lse, dq / dk / dv."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as L, ops
+    heads, H = 2, 128
+    S = max(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    M = int(cu[-1])
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(M, 3 * H, device=DEV, generator=g).to(torch.bfloat16)
+    do = torch.randn(M, H, device=DEV, generator=g).to(torch.bfloat16)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    lib, p, rng = L.load(), ops._p, ops.rng_state(torch.device(DEV))
+    d = L.AttnDesc(len(lens), heads, S, S, 64, 3 * H, 3 * H, 3 * H, H, L.HAMT_BF16, L.HAMT_BF16, 0.125, 0.0, 11, L.PREC_BF16)
+    o = torch.full((M, H), float("nan"), device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(len(lens) * heads * S, device=DEV)
+    L.check(lib.hamt_attn_varlen_fwd(C.byref(d), p(q), p(k), p(v), p(cu), p(o), p(lse), p(rng), ops._stream()), "hamt_attn_varlen_fwd")
+    dqkv = torch.full((M, 3 * H), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.check(lib.hamt_attn_varlen_bwd(C.byref(d), p(q), p(k), p(v), p(cu), p(o), p(do), p(lse), p(dqkv[:, :H]), p(dqkv[:, H:2 * H]), p(dqkv[:, 2 * H:]),
+                                     p(rng), ops._stream()), "hamt_attn_varlen_bwd")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(dqkv).all())
+    for b, n in enumerate(lens):
+        r0 = int(cu[b])
+        qb = qkv[r0:r0 + n].float()
+        qq, kk, vv = (qb[:, i * H:(i + 1) * H].view(n, heads, 64).transpose(0, 1).double().requires_grad_() for i in range(3))
+        sc = qq @ kk.transpose(-1, -2) * 0.125
+        out = (torch.softmax(sc, -1) @ vv)
+        out.backward(do[r0:r0 + n].float().view(n, heads, 64).transpose(0, 1).double())
+        close(o[r0:r0 + n].float(), out.transpose(0, 1).reshape(n, H), 1e-2, f"varlen output seq {b}")
+        want_lse = torch.logsumexp(sc, -1)                                   # [heads, n]
+        got_lse = lse.view(len(lens), heads, S)[b, :, :n]
+        close(got_lse, want_lse, 1e-3, f"lse seq {b}")
+        for i, (t, nm) in enumerate(((qq, "dq"), (kk, "dk"), (vv, "dv"))):
+            close(dqkv[r0:r0 + n, i * H:(i + 1) * H].float(), t.grad.transpose(0, 1).reshape(n, H), 2e-2, f"{nm} seq {b}")
 
 
 # ------------------------------------------------------------------------------------------- two ranks on one GPU

@@ -77,6 +77,8 @@ SIGNATURES = {
     "hamt_colsum": [i32, i32, vp, i32, i32, vp, i32, vp, vp],
     "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_attn_small_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_attn_varlen_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_attn_varlen_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_gemm_ln_fwd": [C.POINTER(GemmLnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -152,10 +152,20 @@ def _wgrad(w, b, dy16, x16, M):
 
 # ================================================================================================= self attention block
 class SelfAttnBlockFn(torch.autograd.Function):
+    """`seq` = None for a padded batch x [B, S, H] with an additive key mask, or (cu_seqlens int32 [B + 1], B, S_max) for a PACKED
+    batch x [M, H]: B sequences back to back, sequence b = rows [cu[b], cu[b + 1]), cu[B] == M (rows added to reach a bucketed M
+    form sequences of their own: every row is written by every kernel, nothing is ever NaN), attention by hamt_attn_varlen_* --
+    every other kernel of the block is row-wise and does not care."""
+
     @staticmethod
-    def forward(ctx, x, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta):
-        B, S, H = x.shape
-        M = B * S
+    def forward(ctx, x, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, seq=None):
+        if seq is not None:
+            cu, B, S = seq
+            M, H = x.shape
+            assert add_mask is None
+        else:
+            B, S, H = x.shape
+            M = B * S
         dev = x.device
         x2 = x.reshape(M, H)
         if not x2.is_contiguous():
@@ -171,22 +181,27 @@ class SelfAttnBlockFn(torch.autograd.Function):
         rng = rng_state(dev)
         d = _attn_desc(B, heads, S, S, H, 3 * H, 3 * H, 3 * H, p_attn, cid)
         q, k, v = qkv16[:, :H], qkv16[:, H:2 * H], qkv16[:, 2 * H:]
-        L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(lse), _p(rng), _stream()),
-                "hamt_attn_small_fwd")
+        if seq is not None:      # (every row of x belongs to a sequence: bucket-padding rows form sequences of their own)
+            L.check(L.load().hamt_attn_varlen_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(cu), _p(ctx16), _p(lse), _p(rng), _stream()),
+                    "hamt_attn_varlen_fwd")
+        else:
+            L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(lse), _p(rng), _stream()),
+                    "hamt_attn_small_fwd")
         o = torch.empty(M, H, dtype=O_DTYPE, device=dev)      # bf16: what a linear returns under autocast (ops._ln_fwd reads it as such)
         gemm(ctx16[:M], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma)
         ctx.ln_params = (gamma, beta, bo)          # their gradients come from the LayerNorm-backward partials (ops._ln_bwd)
         ctx.meta = (B, S, H, M, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
+        ctx.cu = seq[0] if seq is not None else None
         ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
-        return y.view(B, S, H), y16
+        return y.view(x.shape), y16
 
     @staticmethod
     def backward(ctx, dy, _unused=None):
         if dy is None:
-            return (None,) * 16
+            return (None,) * 17
         x16, qkv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wk, bk, wv, bv, wo, bo, gamma = ctx.saved_tensors
         B, S, H, M, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
         dev = dy.device
@@ -200,10 +215,14 @@ class SelfAttnBlockFn(torch.autograd.Function):
         d = _attn_desc(B, heads, S, S, H, 3 * H, 3 * H, 3 * H, p_attn, cid)
         q, k, v = qkv16[:, :H], qkv16[:, H:2 * H], qkv16[:, 2 * H:]
         dq, dk, dv = dqkv16[:, :H], dqkv16[:, H:2 * H], dqkv16[:, 2 * H:]
-        L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(dctx16), _p(lse), None,
-                                             _p(dq), _p(dk), _p(dv), _p(rng_state(dev)), _stream()), "hamt_attn_small_bwd")
+        if ctx.cu is not None:
+            L.check(L.load().hamt_attn_varlen_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(ctx.cu), _p(ctx16), _p(dctx16), _p(lse),
+                                                  _p(dq), _p(dk), _p(dv), _p(rng_state(dev)), _stream()), "hamt_attn_varlen_bwd")
+        else:
+            L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(mask2), _p(ctx16), _p(dctx16), _p(lse), None,
+                                                 _p(dq), _p(dk), _p(dv), _p(rng_state(dev)), _stream()), "hamt_attn_small_bwd")
         dx, dws, dbs = _proj_bwd(dqkv16, M, x16, (wq, wk, wv), (bq, bk, bv), dx_accum_into=dz)
-        return (dx.view(B, S, H), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dgamma, dbeta)
+        return (dx.view(dy.shape), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dgamma, dbeta, None)
 
 
 # ================================================================================================= cross attention block
@@ -473,11 +492,15 @@ def usable(prec: str, x: torch.Tensor) -> bool:
 def self_attn_block(x, add_mask, att_self, att_out, training):
     pa = float(att_self.dropout.p) if training else 0.0
     ph = float(att_out.dropout.p) if training else 0.0
-    y, y16 = SelfAttnBlockFn.apply(x, add_mask, att_self.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
+    seq = getattr(x, "_hamt_seq", None)      # a packed batch (model.vilmodel.NavPreTrainedModel._text): see SelfAttnBlockFn
+    y, y16 = SelfAttnBlockFn.apply(x, None if seq is not None else add_mask, att_self.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
                                    att_self.query.weight, att_self.query.bias, att_self.key.weight, att_self.key.bias,
                                    att_self.value.weight, att_self.value.bias, att_out.dense.weight, att_out.dense.bias,
-                                   att_out.LayerNorm.weight, att_out.LayerNorm.bias)
-    return _tag(y, y16)
+                                   att_out.LayerNorm.weight, att_out.LayerNorm.bias, seq)
+    y = _tag(y, y16)
+    if seq is not None:
+        y._hamt_seq = seq
+    return y
 
 
 def cross_attn_block(x, c, add_mask, att, att_out, training):
@@ -498,4 +521,8 @@ def ffn_block(x, inter, out, training):
     ph = float(out.dropout.p) if training else 0.0
     y, y16 = FfnBlockFn.apply(x, ph, out.LayerNorm.eps, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias,
                               out.LayerNorm.weight, out.LayerNorm.bias)
-    return _tag(y, y16)
+    y = _tag(y, y16)
+    seq = getattr(x, "_hamt_seq", None)
+    if seq is not None:
+        y._hamt_seq = seq
+    return y

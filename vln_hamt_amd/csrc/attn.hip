@@ -331,9 +331,42 @@ int check_desc(const hamt_attn_desc* d, const char* who) {
 }  // namespace
 
 void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
-                            float* lse, const uint64_t* rng, hipStream_t s);
+                            float* lse, const uint64_t* rng, hipStream_t s, const int* cu = nullptr);
 void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
-                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s);
+                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s,
+                            const int* cu = nullptr);
+
+// Packed ("varlen") self-attention: the B sequences lie back to back, sample b owns rows [cu[b], cu[b + 1]) of q / k / v / o (every
+// one of its keys is real: no mask), at most d->Sq = d->Sk <= 128 rows each; lse is [B, heads, d->Sq].  What BertSelfAttention
+// (vilmodel.py:96-129) computes for the REAL tokens of a padded batch, without the padded rows.
+static int check_varlen(const hamt_attn_desc* d, const int* cu, const char* who) {
+  int rc = check_desc(d, who);
+  if (rc) return rc;
+  HAMT_CHECK_ARG(cu != nullptr, "%s: cu_seqlens is null", who);
+  HAMT_CHECK_ARG(d->prec == HAMT_PREC_BF16 && d->Sq == d->Sk && d->Sq <= 128, "%s: packed attention is built for the bf16 path, self-attention, <= 128 tokens per sequence (Sq %d, Sk %d)", who, d->Sq, d->Sk);
+  return HAMT_OK;
+}
+extern "C" int hamt_attn_varlen_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_seqlens,
+                                    void* o, float* lse, const uint64_t* rng, void* stream) {
+  int rc = check_varlen(d, cu_seqlens, "hamt_attn_varlen_fwd");
+  if (rc) return rc;
+  HAMT_CHECK_ARG(q && k && v && o && lse, "hamt_attn_varlen_fwd: null pointer");
+  if (d->B == 0) return HAMT_OK;
+  hamt_attn16_fwd_launch(d, q, k, v, nullptr, o, lse, rng, as_stream(stream), cu_seqlens);
+  HAMT_CHECK_LAUNCH("hamt_attn_varlen_fwd");
+  return HAMT_OK;
+}
+extern "C" int hamt_attn_varlen_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_seqlens,
+                                    const void* o, const void* d_o, const float* lse, void* dq, void* dk, void* dv,
+                                    const uint64_t* rng, void* stream) {
+  int rc = check_varlen(d, cu_seqlens, "hamt_attn_varlen_bwd");
+  if (rc) return rc;
+  HAMT_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv, "hamt_attn_varlen_bwd: null pointer");
+  if (d->B == 0) return HAMT_OK;
+  hamt_attn16_bwd_launch(d, q, k, v, nullptr, o, d_o, lse, dq, dk, dv, rng, as_stream(stream), cu_seqlens);
+  HAMT_CHECK_LAUNCH("hamt_attn_varlen_bwd");
+  return HAMT_OK;
+}
 
 extern "C" int hamt_attn_small_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v,
                                    const float* add_mask, void* o, float* lse, const uint64_t* rng, void* stream) {

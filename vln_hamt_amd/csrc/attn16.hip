@@ -31,6 +31,7 @@ struct Attn16Args {
   void *out, *dq, *dk, *dv;
   float* lse;
   const uint64_t* rng;
+  const int* cu;   // packed self-attention (hamt_attn_varlen_*): sample b owns rows [cu[b], cu[b + 1]) of q / k / v / o; else nullptr
 };
 
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&f)[8]);
@@ -445,28 +446,37 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   const hamt_attn_desc& d = a.d;
   const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
+  // rows and lengths of this sample: fixed stride (padded batch), or its own row range of a packed batch (every key is real)
+  int Sq = d.Sq, Sk = d.Sk;
+  size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
+  if (a.cu) {
+    const int c0 = a.cu[b];
+    Sq = Sk = a.cu[b + 1] - c0;
+    qrow0 = krow0 = (size_t)c0;
+    if (Sq <= 0) return;                               // (whole workgroup: an empty slot of a bucketed batch)
+  }
   constexpr int SKP = KB * 16;                         // staged key rows: zeros (K, V) and -inf (mask) beyond Sk, so the
   bf16_t* Ks = sm;                                     // whole kernel is branch-free in the key dimension
   bf16_t* Vs = sm + SKP * AST;
   float* mk_s = (float*)(Vs + SKP * AST);
-  const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
-  const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
-  const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
+  const TI* Q = (const TI*)a.q + qrow0 * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + krow0 * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + krow0 * d.ldv + h * 64;
   Raw8<TI> rk[IT], rv[IT];                             // the launcher guarantees 8 * SKP <= IT * nt
-  rows_load<TI, IT>(K, d.ldk, d.Sk, t, nt, rk);
-  rows_load<TI, IT>(V, d.ldv, d.Sk, t, nt, rv);
+  rows_load<TI, IT>(K, d.ldk, Sk, t, nt, rk);
+  rows_load<TI, IT>(V, d.ldv, Sk, t, nt, rv);
   const int q0 = 128 * blockIdx.z;
   const int qrow = q0 + 16 * w + l15;                  // the ONE query row this lane owns
-  const bool qok = qrow < d.Sq;
+  const bool qok = qrow < Sq;
   bf16x8 qf[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)   // clamped, not branched (rows >= Sq are never stored)
-    qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : d.Sq - 1) * d.ldq + 32 * s + 8 * g);
-  stage_mask(a.mask, b, d.Sk, SKP, mk_s, t, nt);
+    qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : Sq - 1) * d.ldq + 32 * s + 8 * g);
+  stage_mask(a.cu ? nullptr : a.mask, b, Sk, SKP, mk_s, t, nt);
   rows_store<TI, IT>(rk, SKP, Ks, t, nt);
   rows_store<TI, IT>(rv, SKP, Vs, t, nt);
   __syncthreads();
-  if (q0 + 16 * w >= d.Sq || w >= 8) return;           // waves that only helped staging (no barrier below)
+  if (q0 + 16 * w >= Sq || w >= 8) return;             // waves that only helped staging (no barrier below)
   const RngKey key = rng_key(a.rng, d.call_id);
   const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
   const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + qrow) ^ key.k0);
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   }
   const float l_run = xg_sum(rs);
   if (qok) {
-    TO* O = (TO*)a.out + (size_t)b * d.Sq * d.ldo + h * 64 + (size_t)qrow * d.ldo;
+    TO* O = (TO*)a.out + qrow0 * d.ldo + h * 64 + (size_t)qrow * d.ldo;
     const float inv = 1.0f / l_run;
 #pragma unroll
     for (int db = 0; db < 4; ++db) st4<TO>(O + 16 * db + 4 * g, of[db][0] * inv, of[db][1] * inv, of[db][2] * inv, of[db][3] * inv);
@@ -522,7 +532,15 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   const hamt_attn_desc& d = a.d;
   const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int nqb = (d.Sq + 15) >> 4, nkb = (d.Sk + 15) >> 4, sq16 = nqb * 16, sk16 = nkb * 16, PST = sq16 + 8;
+  int Sq = d.Sq, Sk = d.Sk;                            // (as in the forward kernel: fixed stride, or this sample's rows of a packed batch)
+  size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
+  if (a.cu) {
+    const int c0 = a.cu[b];
+    Sq = Sk = a.cu[b + 1] - c0;
+    qrow0 = krow0 = (size_t)c0;
+    if (Sq <= 0) return;
+  }
+  const int nqb = (Sq + 15) >> 4, nkb = (Sk + 15) >> 4, sq16 = nqb * 16, sk16 = nkb * 16, PST = sq16 + 8;
   bf16_t* Qs = sm;
   bf16_t* dOs = Qs + sq16 * AST;
   bf16_t* Ks = dOs + sq16 * AST;
@@ -532,20 +550,20 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   float* lse_s = (float*)(dSt + sk16 * PST);
   float* delta_s = lse_s + sq16;
   float* mk_s = delta_s + sq16;
-  const TI* Q = (const TI*)a.q + (size_t)b * d.Sq * d.ldq + h * 64;
-  const TI* K = (const TI*)a.k + (size_t)b * d.Sk * d.ldk + h * 64;
-  const TI* V = (const TI*)a.v + (size_t)b * d.Sk * d.ldv + h * 64;
-  const TO* O = (const TO*)a.o + (size_t)b * d.Sq * d.ldo + h * 64;
-  const TO* dO = (const TO*)a.d_o + (size_t)b * d.Sq * d.ldo + h * 64;
+  const TI* Q = (const TI*)a.q + qrow0 * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + krow0 * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + krow0 * d.ldv + h * 64;
+  const TO* O = (const TO*)a.o + qrow0 * d.ldo + h * 64;
+  const TO* dO = (const TO*)a.d_o + qrow0 * d.ldo + h * 64;
   {  // all five matrices in flight at once (nt = 64 * max(nqb, nkb) => 2 pieces per thread and matrix)
     Raw8<TI> rq[2], rk[2], rv[2];
     Raw8<TO> rdo[2], ro[2];
-    rows_load<TI, 2>(Q, d.ldq, d.Sq, t, nt, rq);
-    rows_load<TO, 2>(dO, d.ldo, d.Sq, t, nt, rdo);
-    rows_load<TO, 2>(O, d.ldo, d.Sq, t, nt, ro);
-    rows_load<TI, 2>(K, d.ldk, d.Sk, t, nt, rk);
-    rows_load<TI, 2>(V, d.ldv, d.Sk, t, nt, rv);
-    stage_mask(a.mask, b, d.Sk, sk16, mk_s, t, nt);
+    rows_load<TI, 2>(Q, d.ldq, Sq, t, nt, rq);
+    rows_load<TO, 2>(dO, d.ldo, Sq, t, nt, rdo);
+    rows_load<TO, 2>(O, d.ldo, Sq, t, nt, ro);
+    rows_load<TI, 2>(K, d.ldk, Sk, t, nt, rk);
+    rows_load<TI, 2>(V, d.ldv, Sk, t, nt, rv);
+    stage_mask(a.cu ? nullptr : a.mask, b, Sk, sk16, mk_s, t, nt);
     for (int i = t; i < sk16 * PST / 8; i += nt) { ((uint4*)Pt)[i] = make_uint4(0, 0, 0, 0); ((uint4*)dSt)[i] = make_uint4(0, 0, 0, 0); }
     rows_store<TI, 2>(rq, sq16, Qs, t, nt);
     rows_store<TO, 2>(rdo, sq16, dOs, t, nt);
@@ -559,7 +577,7 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += f[j] * o8[j];
       acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-      if ((t & 7) == 0 && r < sq16) { delta_s[r] = acc; lse_s[r] = r < d.Sq ? a.lse[((size_t)b * d.heads + h) * d.Sq + r] : 0.f; }
+      if ((t & 7) == 0 && r < sq16) { delta_s[r] = acc; lse_s[r] = r < Sq ? a.lse[((size_t)b * d.heads + h) * d.Sq + r] : 0.f; }
     }
     rows_store<TI, 2>(rk, sk16, Ks, t, nt);
     rows_store<TI, 2>(rv, sk16, Vs, t, nt);
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
     for (int s = 0; s < 2; ++s) { qf[s] = rfrag(Qs, ql, 32 * s + 8 * g); df[s] = rfrag(dOs, ql, 32 * s + 8 * g); }
     const float lse_q = lse_s[ql], delta_q = delta_s[ql];
     const uint32_t rowh = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + ql) ^ key.k0);
-    const bool qv = ql < d.Sq;                         // padding queries keep their (zero) columns; the MFMAs need every lane
+    const bool qv = ql < Sq;                         // padding queries keep their (zero) columns; the MFMAs need every lane
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       if (kb < nkb) {
@@ -617,9 +635,9 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
       }
     }
     const int kk = 16 * w + l15;
-    if (kk < d.Sk) {
-      TI* dK = (TI*)a.dk + (size_t)b * d.Sk * d.ldk + h * 64 + (size_t)kk * d.ldk;
-      TI* dV = (TI*)a.dv + (size_t)b * d.Sk * d.ldv + h * 64 + (size_t)kk * d.ldv;
+    if (kk < Sk) {
+      TI* dK = (TI*)a.dk + krow0 * d.ldk + h * 64 + (size_t)kk * d.ldk;
+      TI* dV = (TI*)a.dv + krow0 * d.ldv + h * 64 + (size_t)kk * d.ldv;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         st4<TI>(dK + 16 * db + 4 * g, dkf[db][0], dkf[db][1], dkf[db][2], dkf[db][3]);
@@ -640,8 +658,8 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
       }
     }
     const int qq = 16 * w + l15;
-    if (qq < d.Sq) {
-      TI* dQ = (TI*)a.dq + (size_t)b * d.Sq * d.ldq + h * 64 + (size_t)qq * d.ldq;
+    if (qq < Sq) {
+      TI* dQ = (TI*)a.dq + qrow0 * d.ldq + h * 64 + (size_t)qq * d.ldq;
 #pragma unroll
       for (int db = 0; db < 4; ++db) st4<TI>(dQ + 16 * db + 4 * g, dqf[db][0], dqf[db][1], dqf[db][2], dqf[db][3]);
     }
@@ -720,11 +738,11 @@ bool use_s128_bwd(const hamt_attn_desc* d) {
 }  // namespace
 
 void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
-                            float* lse, const uint64_t* rng, hipStream_t s) {
-  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng};
+                            float* lse, const uint64_t* rng, hipStream_t s, const int* cu) {
+  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng, cu};
   dim3 grid((d->Sq + T64 - 1) / T64, d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
-  if (use_s128_fwd(d)) {
+  if (use_s128_fwd(d) || cu) {      // (the packed form exists in the single-pass kernels only)
     if (!ib && !ob) launch_s128_fwd<float, float>(a, s);
     else if (ib && ob) launch_s128_fwd<bf16_t, bf16_t>(a, s);
     else if (ib) launch_s128_fwd<bf16_t, float>(a, s);
@@ -738,11 +756,11 @@ void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* 
 }
 
 void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
-                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s) {
-  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng};
+                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s, const int* cu) {
+  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng, cu};
   dim3 grid(d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
-  if (use_s128_bwd(d)) {
+  if (use_s128_bwd(d) || cu) {
     if (!ib && !ob) launch_s128_bwd<float, float>(a, s);
     else if (ib && ob) launch_s128_bwd<bf16_t, bf16_t>(a, s);
     else if (ib) launch_s128_bwd<bf16_t, float>(a, s);

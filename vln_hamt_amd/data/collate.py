@@ -54,9 +54,12 @@ class PackedBatch:
     def nbytes(self) -> int:
         return self.buf.numel()
 
-    def to_device(self, device, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, object]:
+    def to_device(self, device, out: Optional[Dict[str, torch.Tensor]] = None, text_pack: bool = False) -> Dict[str, object]:
         """H2D copy of the buffer + unpack kernels on the current stream -> the reference's collated batch on `device`.
-        `out`: tensors to fill in place where key, shape and dtype match (static inputs of a captured graph)."""
+        `out`: tensors to fill in place where key, shape and dtype match (static inputs of a captured graph).
+        `text_pack`: add the text packing plan of the batch (`txt_pack_idx`, `txt_cu`, `txt_unpack_idx`: synth.text_pack_plan over the
+        instruction lengths) -- three small index tensors beyond the reference's keys, with which the model's text-only layers skip
+        the padded positions (model.vilmodel.NavPreTrainedModel._text); absent when the batch has (almost) no padding."""
         device = torch.device(device)
         if device.type != "cuda":
             raise L.HamtError("PackedBatch.to_device: the collation kernels have no CPU path")
@@ -103,6 +106,12 @@ class PackedBatch:
                 res[name] = t
             else:
                 res[name] = src
+        if text_pack and "txt" in self.lens:
+            from ..synth import text_pack_plan
+            plan = text_pack_plan(self.lens["txt"], max(self.lens["txt"]))
+            if plan is not None:
+                for name, t in zip(("txt_pack_idx", "txt_cu", "txt_unpack_idx"), plan):
+                    res[name] = t.pin_memory().to(device, non_blocking=True)
         dbuf.record_stream(torch.cuda.current_stream(device))
         return res
 

@@ -83,18 +83,18 @@ class MetaLoader:
             yield task, batch
 
 
-def move_to_cuda(batch, device, out=None):
-    """loader.py:77-87, plus PackedBatch -> the collated dict on `device`"""
+def move_to_cuda(batch, device, out=None, text_pack=False):
+    """loader.py:77-87, plus PackedBatch -> the collated dict on `device` (text_pack: see PackedBatch.to_device)"""
     if isinstance(batch, PackedBatch):
-        return batch.to_device(device, out=out)
+        return batch.to_device(device, out=out, text_pack=text_pack)
     if isinstance(batch, torch.Tensor):
         return batch.to(device, non_blocking=True)
     if isinstance(batch, list):
-        return [move_to_cuda(t, device) for t in batch]
+        return [move_to_cuda(t, device, text_pack=text_pack) for t in batch]
     if isinstance(batch, tuple):
-        return tuple(move_to_cuda(t, device) for t in batch)
+        return tuple(move_to_cuda(t, device, text_pack=text_pack) for t in batch)
     if isinstance(batch, dict):
-        return {n: move_to_cuda(t, device) for n, t in batch.items()}
+        return {n: move_to_cuda(t, device, text_pack=text_pack) for n, t in batch.items()}
     return batch
 
 
@@ -113,8 +113,10 @@ class PrefetchLoader:
     """overlap compute and host->device transfer (loader.py:90-124): same `__iter__` / `__len__` / attribute forwarding;
     the transfer of batch i+1 is issued on a copy stream as soon as batch i has been handed out."""
 
-    def __init__(self, loader, device: torch.device):
+    def __init__(self, loader, device: torch.device, text_pack: bool = False):
+        """text_pack: batches carry their text packing plan (three index tensors beyond the reference's keys, PackedBatch.to_device)"""
         self.loader = loader
+        self.text_pack = text_pack
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
@@ -136,10 +138,10 @@ class PrefetchLoader:
             self.batch = None
             return
         if self.stream is None:
-            self.batch = move_to_cuda(self.batch, self.device)
+            self.batch = move_to_cuda(self.batch, self.device, text_pack=self.text_pack)
             return
         with torch.cuda.stream(self.stream):
-            self.batch = move_to_cuda(self.batch, self.device)
+            self.batch = move_to_cuda(self.batch, self.device, text_pack=self.text_pack)
 
     def next(self, it):
         batch = self.batch

@@ -21,6 +21,7 @@ from .vilmodel import BertLayerNorm, BertOnlyMLMHead, BertPreTrainedModel, NavPr
 # batch 16 (tests/golden/canon_multi.npz, three weight seeds): ITM logits 1.06e-2 / 1.35e-2 / 1.00e-2 off the reference with bf16
 # heads -- over north_star's 1e-2 -- against 8.6e-3 / 9.5e-3 / 5.2e-3 with fp32 heads.  HAMT_HEADS_BF16=1 restores bf16 heads.
 HEADS_FP32 = os.environ.get("HAMT_HEADS_BF16") is None
+TXT_PACK = os.environ.get("HAMT_NO_TXT_PACK") is None      # use a batch's text packing plan when it carries one
 
 
 class _MlpHead(nn.Module):
@@ -106,6 +107,11 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
 
     def forward(self, batch, task, compute_loss=True):
         batch = defaultdict(lambda: None, batch)
+        if batch['txt_ids'] is not None:
+            # optional packing plan of a ragged batch (synth.make_batch / data.collate): the text-only layers then skip the padding
+            # (vilmodel.NavPreTrainedModel._text); it rides on the id tensor so that the trunk keeps the reference's signature
+            pk = batch['txt_pack_idx']
+            batch['txt_ids']._hamt_pack = (pk, batch['txt_cu'], batch['txt_unpack_idx']) if (pk is not None and TXT_PACK) else None
         hist = (batch['txt_ids'], batch['txt_masks'], batch['hist_img_fts'], batch['hist_ang_fts'],
                 batch['hist_pano_img_fts'], batch['hist_pano_ang_fts'], batch['hist_masks'])
         ob = (batch['ob_img_fts'], batch['ob_ang_fts'], batch['ob_nav_types'], batch['ob_masks'])

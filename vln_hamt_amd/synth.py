@@ -29,8 +29,33 @@ def _angles(rng, shape):
     return np.stack([np.sin(h), np.cos(h), np.sin(e), np.cos(e)], -1).astype(np.float32)  # r2r_data.py:14-17
 
 
+def text_pack_plan(lens, L: int, bucket: int = 128):
+    """(pack_idx int64 [M], cu_seqlens int32 [n + 1], unpack_idx int64 [B L]) for a padded text batch [B, L] with `lens` real tokens per
+    row, or None when (almost) nothing is padding.  pack_idx = the flat positions b L + i of the real tokens, row by row, then filler
+    positions up to a multiple of `bucket` rows (a static length per bucket for captured graphs); cu_seqlens = the B sequences' row
+    ranges followed by filler sequences of at most L rows each, so that every packed row belongs to a sequence; unpack_idx sends each
+    padded position to a packed row -- its own for a real token, its sequence's first row for padding (any finite value serves there).
+    Consumed by model.vilmodel.NavPreTrainedModel._text."""
+    lens = np.asarray(lens).astype(np.int64)
+    B = lens.shape[0]
+    M = int(lens.sum())
+    Mb = (M + bucket - 1) // bucket * bucket
+    if Mb >= B * L:
+        return None
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    valid = np.arange(L)[None, :] < lens[:, None]
+    flat = np.flatnonzero(valid.reshape(-1))
+    pack = np.concatenate([flat, np.full(Mb - M, flat[0], dtype=np.int64)])
+    cu = list(starts)
+    while cu[-1] < Mb:
+        cu.append(min(Mb, cu[-1] + L))
+    unpack = np.repeat(starts[:-1], L)                       # padding -> the sequence's first row
+    unpack[flat] = np.arange(M)
+    return torch.from_numpy(pack), torch.tensor(cu, dtype=torch.int32), torch.from_numpy(unpack)
+
+
 def make_batch(task: str, batch_size: int, cfg, seed: int = 0, txt_len: int = 80, hist_len: int = 5,
-               num_views: int = 36, ragged: bool = False, device="cpu", mlm_exact: int | None = None) -> dict:
+               num_views: int = 36, ragged: bool = False, device="cpu", mlm_exact: int | None = None, txt_pack: bool = True) -> dict:
     """Build one collated batch for `task` (one of TASKS).
 
     ragged=True draws per-sample text lengths in [txt_len//4, txt_len] and history lengths in
@@ -70,6 +95,10 @@ def make_batch(task: str, batch_size: int, cfg, seed: int = 0, txt_len: int = 80
         out["txt_labels"] = torch.from_numpy(labels)
         out["txt_label_idx"] = torch.from_numpy(np.flatnonzero(labels.reshape(-1) != -1).astype(np.int64))
     out["txt_ids"] = torch.from_numpy(ids)
+    if ragged and txt_pack:
+        plan = text_pack_plan(lens, L)
+        if plan is not None:
+            out["txt_pack_idx"], out["txt_cu"], out["txt_unpack_idx"] = plan
 
     # ---- history
     hl = rng.integers(0, T + 1, size=B) if ragged else np.full(B, T)
