@@ -1158,8 +1158,11 @@ def test_uninitialised_memory_never_reaches_a_rollout_result(no_lang_ca):
             assert float((a - c).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1e-6), (n, float((a - c).abs().max()), float(a.abs().max()))
 
 
-def test_training_soak_losses_fall():
-    """End to end at full size: 120 graph-replayed steps of the six-task mix over 12 fixed synthetic batches (B = 32, lr warm-up to
+@pytest.mark.parametrize("ragged", [False, True])
+def test_training_soak_losses_fall(ragged):
+    """(ragged: instructions of 20-80 tokens and 0-7 history steps per sample -- the text packing path of round 3: packed text layers,
+    hamt_attn_varlen_*, filler sequences of the bucketed row count.)
+    End to end at full size: 120 graph-replayed steps of the six-task mix over 12 fixed synthetic batches (B = 32, lr warm-up to
     5e-5, clip 5.0) must stay finite and overfit (tools/soak.py, shortened).  This is the test that catches what the parity tests
     cannot: a NaN that only some inputs / some step produces (round 2: the folded bias column sums of the 256-square weight-gradient
     tile let 0 x NaN from an out-of-range row of the ragged last tile of the 30 522-row MLM decoder into valid sums -- every parity
@@ -1185,7 +1188,9 @@ def test_training_soak_losses_fall():
         task = sched.task_at(s)
         key = (task, s % 12)
         if key not in batches:
-            b = make_batch(task, 32, cfg, seed=100 + s % 12, txt_len=80, hist_len=5, mlm_exact=12 if task == "mlm" else None, device=dev)
+            b = make_batch(task, 32, cfg, seed=100 + s % 12, txt_len=80, hist_len=7 if ragged else 5, ragged=ragged,
+                           mlm_exact=12 if (task == "mlm" and not ragged) else None, device=dev)
+            assert ("txt_pack_idx" in b) == ragged
             if task == "itm":
                 r = make_itm_rng(b, seed=s)
                 b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
