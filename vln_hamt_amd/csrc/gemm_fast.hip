@@ -46,6 +46,7 @@ struct GemmArgsF {
   uint32_t call_id;
   const uint64_t* rng;
   float* ss;            // weight-gradient tiles: slot array for the sum of squares of each tile's FINAL values (or nullptr)
+  int ss_ld;            // slots per 64-row band of `ss` (0: those of this N; a column band of a wider output passes the full width's)
 };
 
 #ifdef HAMT_PROF   // cycle accounting of the main loop (tools/gemm_prof.py builds a private copy with -DHAMT_PROF)
@@ -206,7 +207,7 @@ __device__ __forceinline__ void tile_sumsq_store(const GemmArgsF& g, int m0, int
   if (t == 0) {
     float tot = 0.f;
     for (int i = 0; i < nw; ++i) tot += red[i];
-    g.ss[(size_t)(m0 >> 6) * ((g.N + 127) >> 7) + (n0 >> 7)] = tot;
+    g.ss[(size_t)(m0 >> 6) * (g.ss_ld ? g.ss_ld : ((g.N + 127) >> 7)) + (n0 >> 7)] = tot;
   }
 }
 
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
 constexpr int WG_MAX = 48;                       // table entries carried by one kernarg block (80 bytes each, < 4 KiB)
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db; float* ss;
-  int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=; tile_end = exclusive prefix end
+  int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=, >> 8 = ss slots per 64-row band; tile_end = exclusive prefix end
   int kv;                                        // valid reduction rows (<= K): rows behind are padding of any content
   float wscale;                                  // != 0: dw is a bf16 array, the tile stores bf16(wscale * dW) (hamt_wgrad_desc.wire_scale)
 };
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const Wgrad
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + BNT - 1) / BNT;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0,
-              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
+              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss, q.flags >> 8};
   gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, q.K / BK, 0, q.db, q.flags & 2);
 }
 
@@ -715,9 +716,11 @@ template <int N> __device__ __forceinline__ void p8_wait() {
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-// COLSUM (weight-gradient form, A = dY stored [K][M]): wave column 0 of the tiles with n0 == 0 also reduces A over k --
-// one extra MFMA per A fragment against an operand that holds ones in row i only, so that the column sums of the wave's
-// 8 fragments land in the 8 rows of ONE accumulator (4 registers): the bias gradient, for free of any extra pass over dY.
+// COLSUM (weight-gradient form, A = dY stored [K][M]): the tiles with n0 == 0 also reduce A over k -- one extra MFMA per k-half
+// and phase in EVERY wave: the four wave columns of a wave row hold the same eight A fragments, wave column c sums fragment c of
+// a0 (phase A) and of a1 (phase B) against an operand that holds ones in row P only, so both land in rows 0 / 1 of ONE accumulator
+// (4 registers): the bias gradient, for free of any extra pass over dY.  (Round 2 had wave column 0 sum all eight: +25 % MFMA
+// issue on SIMD 0 alone, which every barrier of the tile then waited for -- 11 % of the grouped launch.)
 // NB = B fragments per wave: 4 = the 256-column tile above; 3 = a 256 x 192 tile (wave output 128 x 48: b0 two fragments, b1 one;
 // unit Y1 is 64 wide, one DMA piece per wave) for grids whose 256-square tiling leaves the last round mostly empty -- 5120 x 2304 is
 // 180 tiles of 256 x 256 (0.70 of a round of 256 CUs) and 240 of 256 x 192 (0.94): the round is 0.8 as long and all of it is used.
@@ -726,7 +729,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   constexpr int H1B = NB == 3 ? 64 : 128;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * P8_BUF];          // 128 KiB
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
-  const bool do_cs = COLSUM && db != nullptr && n0 == 0 && wc == 0;        // wave-uniform
+  const bool do_cs = COLSUM && db != nullptr && n0 == 0;                   // workgroup-uniform
   f32x4 cs = {0.f, 0.f, 0.f, 0.f};
   const int nk = g.K / BK;
   const unsigned lds0 = lds_base_of(lds);
@@ -805,33 +808,35 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
     P8_STAMP(P, 2)
     __builtin_amdgcn_s_setprio(1);
     constexpr int I0 = P * 4;
+    // COLSUM: this wave's fragment (af[wc], picked by selects that run under the MFMAs -- no branch inside the multiply run) against
+    // ones in row P, one MFMA behind each k-half of the product.
+    // Rows of A beyond M (a ragged last tile) hold whatever lies behind the operand's last column -- padding, the next
+    // row -- possibly NaN bit patterns.  In the main product such a row only feeds its own (unstored) output row; HERE
+    // both fragments accumulate into the same 16 x 16 block, and 0 x NaN from one fragment's row would poison the column
+    // sums of the other's (first seen as a NaN gradient of the 30 522-row MLM decoder bias).
+    union { uint4 u; bf16x8 v; } sel, csa[2];
+    if constexpr (COLSUM) {
+      const uint32_t o2 = (lane & 15) == P ? 0x3F803F80u : 0u;               // bf16 ones in row P of the operand
+      sel.u = make_uint4(o2, o2, o2, o2);
+      const bool live = m0 + 128 * wr + 64 * P + 16 * wc + (lane & 15) < g.M;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s) {
+        union { uint4 u; bf16x8 v; } f0, f1, f2, f3;
+        f0.v = af[0][s]; f1.v = af[1][s]; f2.v = af[2][s]; f3.v = af[3][s];
+        const uint4 lo = wc & 1 ? f1.u : f0.u, hi = wc & 1 ? f3.u : f2.u;
+        csa[s].u = wc & 2 ? hi : lo;
+        if (!live) csa[s].u = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
           acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j][s], af[i][s], acc[I0 + i][j], 0, 0, 0);
-    if constexpr (COLSUM) {
-      if (do_cs) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t o2 = (lane & 15) == I0 + i ? 0x3F803F80u : 0u;       // bf16 ones in row I0 + i of the operand
-          union { uint4 u; bf16x8 v; } sel;
-          sel.u = make_uint4(o2, o2, o2, o2);
-          // Rows of A beyond M (a ragged last tile) hold whatever lies behind the operand's last column -- padding, the next
-          // row -- possibly NaN bit patterns.  In the main product such a row only feeds its own (unstored) output row; HERE
-          // every fragment accumulates into the same 16 x 16 block, and 0 x NaN from fragment 3's row 58 poisoned the column
-          // sums of rows 10, 26, 42 of fragments 0 .. 2 (first seen as a NaN gradient of the 30 522-row MLM decoder bias).
-          const bool live = m0 + 128 * wr + 64 * P + 16 * i + (lane & 15) < g.M;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            union { uint4 u; bf16x8 v; } a_;
-            a_.v = af[i][s];
-            if (!live) a_.u = make_uint4(0u, 0u, 0u, 0u);
-            cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel.v, a_.v, cs, 0, 0, 0);
-          }
-        }
+      if constexpr (COLSUM) {
+        if (do_cs) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel.v, csa[s].v, cs, 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -862,12 +867,11 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
 #endif
 
   if constexpr (COLSUM) {
-    if (do_cs) {   // cs[e] of lane l = column sum of fragment 4 (l >> 4) + e at row l & 15: fragments 0..7 live in lanes 0..31
+    if (do_cs) {   // cs[e] of lanes 0..15 = column sums of this wave's fragment of a0 (e = 0) and of a1 (e = 1) at row `lane`
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int fi = 4 * (lane >> 4) + e;                                // fragment: a0 rows 0..3, a1 rows 4..7
-        const int row = m0 + 128 * wr + 64 * (fi >> 2) + 16 * (fi & 3) + (lane & 15);
-        if (lane < 32 && row < g.M) db[row] = db_accum ? db[row] + cs[e] : cs[e];
+      for (int e = 0; e < 2; ++e) {
+        const int row = m0 + 128 * wr + 64 * e + 16 * wc + lane;
+        if (lane < 16 && row < g.M) db[row] = db_accum ? db[row] + cs[e] : cs[e];
       }
     }
   }
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_p8_kernel(const WgradProb* 
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + 255) / 256;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0,
-              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss};
+              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss, q.flags >> 8};
   p8_tile<-2, true, true, true>(g, (local / tiles_n) * 256, (local % tiles_n) * 256, q.db, q.flags & 2);
 }
 
@@ -1225,6 +1229,10 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   std::vector<int> cls[2];
   for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && keff(probs[i]) >= 128) ? 0 : 1].push_back(i);
   static const int use_p8 = getenv("HAMT_WGRAD_P8") ? atoi(getenv("HAMT_WGRAD_P8")) : 1;   // 0: the one-phase 256-square tile
+  const char* uenv = getenv("HAMT_WGRAD_UNIT_TILES");   // tuning: tiles per XCD-pinned unit (read per call)
+  const int unit_tiles = uenv && atoi(uenv) > 0 ? atoi(uenv) : 12;
+  const char* u2env = getenv("HAMT_WGRAD_UNIT_2D");
+  const int unit_2d = u2env ? atoi(u2env) : 1;
   const char* fenv = getenv("HAMT_WGRAD_TILE");   // test / tuning override: 256, 128 or 64 (read per call)
   const int force = fenv ? atoi(fenv) : 0;
   {
@@ -1248,18 +1256,32 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     int bm = c == 0 ? 256 : (t128 >= 1024 ? 128 : 64);
     if (force == 128 || force == 64) bm = force;
     const int bn = bm == 256 ? 256 : 128;
-    // units: a problem, or bands of tile rows of a problem with many tiles (so that one XCD's share stays ~<= 12 tiles)
-    struct Unit { int prob, m_lo, m_rows, tiles; double cost; };
+    // units: a problem, or rectangles of r x c tiles of a problem with many tiles (so that one XCD's share stays ~<= 12 tiles).  A unit's
+    // tiles read r + c operand panels between them: the rectangle is the one that covers the problem with the fewest panel reads
+    // (3 x 4 for the 3 x 12 tiles of an FFN-2 weight, where a row band reads 13 panels for its 12 tiles).
+    struct Unit { int prob, m_lo, m_rows, n_lo, n_cols, tiles; double cost; };
     std::vector<Unit> units;
     for (int i : v) {
       const hamt_wgrad_desc& d = probs[i];
       const int tm = (d.M + bm - 1) / bm, tn = (d.N + bn - 1) / bn;
-      const int band = tn >= 12 ? 1 : 12 / tn;   // tile rows per unit
-      for (int r = 0; r < tm; r += band) {
-        const int rows = std::min(band * bm, d.M - r * bm);
-        const int t = ((rows + bm - 1) / bm) * tn;
-        units.push_back(Unit{i, r * bm, rows, t, (double)t * keff(d)});
-      }
+      int ur = 1, uc = 1;
+      long best = -1;
+      for (int r = 1; r <= tm; ++r)
+        for (int c = 1; c <= tn; ++c) {
+          if (r * c > unit_tiles && !(r == 1 && c == tn)) continue;                                  // (a single tile row is always allowed)
+          if ((long)((tm + r - 1) / r) * ((tn + c - 1) / c) > (d.M + 63) / 64) continue;             // the caller's table: one entry per 64 output rows
+          long panels = 0;                         // sum over the covering rectangles of (rows + columns)
+          for (int r0 = 0; r0 < tm; r0 += r)
+            for (int c0 = 0; c0 < tn; c0 += c) panels += std::min(r, tm - r0) + std::min(c, tn - c0);
+          if (best < 0 || panels < best || (panels == best && r * c > ur * uc)) { best = panels; ur = r; uc = c; }
+        }
+      if (unit_2d == 0) { uc = tn; ur = tn >= unit_tiles ? 1 : unit_tiles / tn; }   // (row bands only: the round-2 placement, for measurements)
+      for (int r0 = 0; r0 < tm; r0 += ur)
+        for (int c0 = 0; c0 < tn; c0 += uc) {
+          const int rows = std::min(ur * bm, d.M - r0 * bm), cols = std::min(uc * bn, d.N - c0 * bn);
+          const int t = ((rows + bm - 1) / bm) * ((cols + bn - 1) / bn);
+          units.push_back(Unit{i, r0 * bm, rows, c0 * bn, cols, t, (double)t * keff(d)});
+        }
     }
     std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
     std::vector<int> xq[8];
@@ -1287,14 +1309,16 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
         const hamt_wgrad_desc& d = probs[un.prob];
         tiles += un.tiles;
         const bool wire = d.wire_scale != 0.f;     // bf16 output: the band's first row is m_lo * ldw ELEMENTS of 2 bytes further
-        float* dw_band = wire ? (float*)((bf16_t*)d.dw + (size_t)un.m_lo * d.ldw) : d.dw + (size_t)un.m_lo * d.ldw;
-        flat.push_back(WgradProb{(const bf16_t*)d.dy + un.m_lo, (const bf16_t*)d.x, dw_band,
-                                 d.db ? d.db + un.m_lo : nullptr,
-                                 (d.ss && !wire) ? d.ss + (size_t)(un.m_lo >> 6) * ((d.N + 127) >> 7) : nullptr,     // (bands start on multiples of 64 rows)
-                                 un.m_rows, d.N, d.K, d.ldy, d.ldx, d.ldw,
-                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0), tiles, kv_of(d), d.wire_scale});
+        const size_t w_off = (size_t)un.m_lo * d.ldw + un.n_lo;
+        float* dw_band = wire ? (float*)((bf16_t*)d.dw + w_off) : d.dw + w_off;
+        const int ss_ld = (d.N + 127) >> 7;        // (units start on multiples of 64 rows and 128 columns)
+        flat.push_back(WgradProb{(const bf16_t*)d.dy + un.m_lo, (const bf16_t*)d.x + un.n_lo, dw_band,
+                                 (d.db && un.n_lo == 0) ? d.db + un.m_lo : nullptr,       // the column sums of dY: by the unit that holds column 0
+                                 (d.ss && !wire) ? d.ss + (size_t)(un.m_lo >> 6) * ss_ld + (un.n_lo >> 7) : nullptr,
+                                 un.m_rows, un.n_cols, d.K, d.ldy, d.ldx, d.ldw,
+                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0) | (ss_ld << 8), tiles, kv_of(d), d.wire_scale});
         flat.back().K = keff(d);                        // whole k-tiles behind the last valid row are not multiplied at all
-        launch_flops += 2.0 * un.m_rows * d.N * keff(d);
+        launch_flops += 2.0 * un.m_rows * un.n_cols * keff(d);
       }
       max_tiles = std::max(max_tiles, tiles);
     }
