@@ -194,6 +194,20 @@ int hamt_attn_varlen_fwd(const hamt_attn_desc* d, const void* q, const void* k, 
 int hamt_attn_varlen_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_seqlens,
                          const void* o, const void* d_o, const float* lse, void* dq, void* dk, void* dv,
                          const uint64_t* rng, void* stream);
+/* Cross attention with ONE side packed (BertXAttention, vilmodel.py:351-360, in the x-layers of a ragged batch: the instruction tokens
+ * lie back to back, the visual stream keeps its fixed stride).  Exactly one of cu_q / cu_k is given.
+ *   cu_q: query sequence b = rows [cu_q[b], cu_q[b + 1]) of q / o / d_o / dq (<= d->Sq rows), its keys = rows [b * Sk, (b + 1) * Sk)
+ *         of k / v under add_mask [B, Sk] (may be NULL).  Query sequences b >= n_pairs -- the filler sequences that round a packed
+ *         row count up to its bucket -- have no keys: o = 0, dq = 0, nothing added to dk / dv.
+ *   cu_k: queries at the fixed stride d->Sq, sample b's keys = rows [cu_k[b], cu_k[b + 1]) of k / v / dk / dv (<= d->Sk, all real:
+ *         add_mask is ignored); n_pairs = d->B.  Key rows no sample owns are not written: zero dk / dv behind the last real row.
+ * lse is [B, heads, d->Sq] in both forms. */
+int hamt_attn_varlen_cross_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
+                               const int* cu_k, int n_pairs, const float* add_mask, void* o, float* lse,
+                               const uint64_t* rng, void* stream);
+int hamt_attn_varlen_cross_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
+                               const int* cu_k, int n_pairs, const float* add_mask, const void* o, const void* d_o,
+                               const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ln: y = dropout_post( LayerNorm( dropout_pre(x) + residual ) )      fp32 statistics

@@ -234,8 +234,8 @@ class KvProjFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, c, wk, bk, wv, bv):
-        B, Sk, H = c.shape
-        Mk = B * Sk
+        H = c.shape[-1]
+        Mk = c.numel() // H              # [B, Sk, H], or a packed context [M, H] (SelfAttnBlockFn: `seq`)
         c2 = c.reshape(Mk, H)
         if not c2.is_contiguous():
             c2 = c2.contiguous()
@@ -243,7 +243,7 @@ class KvProjFn(torch.autograd.Function):
         kv16 = torch.empty(c16.shape[0], 2 * H, dtype=torch.bfloat16, device=c.device)
         _proj(c16, Mk, (wk, wv), (bk, bv), kv16)
         ctx.save_for_backward(c16, wk, bk, wv, bv)
-        ctx.meta = (B, Sk, H)
+        ctx.meta = (Mk, tuple(c.shape))
         return kv16
 
     @staticmethod
@@ -251,18 +251,31 @@ class KvProjFn(torch.autograd.Function):
         if dkv16 is None:
             return (None,) * 5
         c16, wk, bk, wv, bv = ctx.saved_tensors
-        B, Sk, H = ctx.meta
+        Mk, shape = ctx.meta
         if not dkv16.is_contiguous():
             dkv16 = dkv16.contiguous()
-        dc, dwkv, dbkv = _proj_bwd(dkv16, B * Sk, c16, (wk, wv), (bk, bv), need_dx=ctx.needs_input_grad[0])
-        return (dc.view(B, Sk, H) if dc is not None else None, dwkv[0], dbkv[0], dwkv[1], dbkv[1])
+        dc, dwkv, dbkv = _proj_bwd(dkv16, Mk, c16, (wk, wv), (bk, bv), need_dx=ctx.needs_input_grad[0])
+        return (dc.view(shape) if dc is not None else None, dwkv[0], dbkv[0], dwkv[1], dbkv[1])
 
 
 class CrossAttnBlockFn(torch.autograd.Function):
+    """`seq_q` / `seq_k` (at most one; SelfAttnBlockFn's `seq` = (cu_seqlens, sequences, S_max)): the queries x [M, H], or the context
+    behind kv16, are a PACKED batch (the instruction tokens of a ragged batch in the x-layers) -- hamt_attn_varlen_cross_*.  `pairs` =
+    the number of samples (= the fixed-stride side's batch): packed query sequences behind it are fillers without keys."""
+
     @staticmethod
-    def forward(ctx, x, kv16, Sk, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wo, bo, gamma, beta):
-        B, Sq, H = x.shape
-        Mq, Mk = B * Sq, B * Sk
+    def forward(ctx, x, kv16, Sk, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wo, bo, gamma, beta, seq_q=None, seq_k=None, pairs=0):
+        if seq_q is not None:
+            cu, B, Sq = seq_q
+            Mq, H = x.shape
+            Mk = pairs * Sk
+        else:
+            B, Sq, H = x.shape
+            Mq, Mk = B * Sq, B * Sk
+            if seq_k is not None:
+                assert add_mask is None and pairs == B
+                Sk = seq_k[2]
+                Mk = -1                  # (a packed context: its row count is kv16's business)
         dev = x.device
         x2 = x.reshape(Mq, H)
         if not x2.is_contiguous():
@@ -271,30 +284,37 @@ class CrossAttnBlockFn(torch.autograd.Function):
         Mqp = x16.shape[0]
         q16 = torch.empty(Mqp, H, dtype=torch.bfloat16, device=dev)
         gemm(x16[:Mq], weight_operand(wq, "bf16"), q16[:Mq], bias=bq.detach())
-        mask2 = add_mask.reshape(B, Sk).to(torch.float32).contiguous() if add_mask is not None else None
+        mask2 = add_mask.reshape(-1, Sk).to(torch.float32).contiguous() if add_mask is not None else None
         ctx16 = _zeros_or_empty(Mqp, Mq, H, dev)
         lse = torch.empty(B * heads * Sq, dtype=torch.float32, device=dev)
         cid = next_call_id()
         d = _attn_desc(B, heads, Sq, Sk, H, H, 2 * H, 2 * H, p_attn, cid)
-        L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(lse),
-                                             _p(rng_state(dev)), _stream()), "hamt_attn_small_fwd")
+        cu_q = seq_q[0] if seq_q is not None else None
+        cu_k = seq_k[0] if seq_k is not None else None
+        if cu_q is not None or cu_k is not None:
+            L.check(L.load().hamt_attn_varlen_cross_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(cu_q), _p(cu_k), pairs,
+                                                        _p(mask2), _p(ctx16), _p(lse), _p(rng_state(dev)), _stream()),
+                    "hamt_attn_varlen_cross_fwd")
+        else:
+            L.check(L.load().hamt_attn_small_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(lse),
+                                                 _p(rng_state(dev)), _stream()), "hamt_attn_small_fwd")
         o = torch.empty(Mq, H, dtype=O_DTYPE, device=dev)
         gemm(ctx16[:Mq], weight_operand(wo, "bf16"), o, bias=bo.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
         ctx.save_for_backward(x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma)
         ctx.ln_params = (gamma, beta, bo)
-        ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln)
+        ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln, Mq, Mk, pairs)
+        ctx.cu_q, ctx.cu_k = cu_q, cu_k
         ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
-        return y.view(B, Sq, H), y16
+        return y.view(x.shape), y16
 
     @staticmethod
     def backward(ctx, dy, _unused=None):
         if dy is None:
-            return (None,) * 14
+            return (None,) * 17
         x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma = ctx.saved_tensors
-        B, Sq, Sk, H, heads, p_attn, p_hidden, eps, cid, cid_ln = ctx.meta
-        Mq, Mk = B * Sq, B * Sk
+        B, Sq, Sk, H, heads, p_attn, p_hidden, eps, cid, cid_ln, Mq, Mk, pairs = ctx.meta
         Mqp, Mkp = x16.shape[0], kv16.shape[0]
         dev = dy.device
         dz, _, dx16, dgamma, dbeta, dbo = _ln_bwd(dy.reshape(Mq, H).contiguous(), z, mean, rstd, gamma.detach(), eps, p_hidden, 0.0,
@@ -303,14 +323,21 @@ class CrossAttnBlockFn(torch.autograd.Function):
         gemm(dx16[:Mq], weight_operand(wo, "bf16"), dctx16[:Mq], b_kmajor=True)
         dwo, _ = _wgrad(wo, None, dx16, ctx16, Mq)
         dq16 = _zeros_or_empty(Mqp, Mq, H, dev)
-        dkv16 = _zeros_or_empty(Mkp, Mk, 2 * H, dev)
         d = _attn_desc(B, heads, Sq, Sk, H, H, 2 * H, 2 * H, p_attn, cid)
-        L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(dctx16),
-                                             _p(lse), None, _p(dq16), _p(dkv16[:, :H]), _p(dkv16[:, H:]), _p(rng_state(dev)), _stream()),
-                "hamt_attn_small_bwd")
+        if ctx.cu_q is not None or ctx.cu_k is not None:
+            # packed keys: the filler rows behind the last real sequence belong to no sample -- nobody writes their dK / dV
+            dkv16 = torch.zeros(Mkp, 2 * H, dtype=torch.bfloat16, device=dev) if ctx.cu_k is not None else _zeros_or_empty(Mkp, Mk, 2 * H, dev)
+            L.check(L.load().hamt_attn_varlen_cross_bwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(ctx.cu_q), _p(ctx.cu_k), pairs,
+                                                        _p(mask2), _p(ctx16), _p(dctx16), _p(lse), _p(dq16), _p(dkv16[:, :H]), _p(dkv16[:, H:]),
+                                                        _p(rng_state(dev)), _stream()), "hamt_attn_varlen_cross_bwd")
+        else:
+            dkv16 = _zeros_or_empty(Mkp, Mk, 2 * H, dev)
+            L.check(L.load().hamt_attn_small_bwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(mask2), _p(ctx16), _p(dctx16),
+                                                 _p(lse), None, _p(dq16), _p(dkv16[:, :H]), _p(dkv16[:, H:]), _p(rng_state(dev)), _stream()),
+                    "hamt_attn_small_bwd")
         dx, dwqs, dbqs = _proj_bwd(dq16, Mq, x16, (wq,), (bq,), dx_accum_into=dz)
-        return (dx.view(B, Sq, H), dkv16 if ctx.needs_input_grad[1] else None, None, None, None, None, None, None,
-                dwqs[0], dbqs[0], dwo, dbo, dgamma, dbeta)
+        return (dx.view(dy.shape), dkv16 if ctx.needs_input_grad[1] else None, None, None, None, None, None, None,
+                dwqs[0], dbqs[0], dwo, dbo, dgamma, dbeta, None, None, None)
 
 
 class XBidirBlockFn(torch.autograd.Function):
@@ -511,10 +538,16 @@ def cross_attn_block(x, c, add_mask, att, att_out, training):
         kv16 = cached[1]
     else:
         kv16 = KvProjFn.apply(c, att.key.weight, att.key.bias, att.value.weight, att.value.bias)
-    y, y16 = CrossAttnBlockFn.apply(x, kv16, c.shape[1], add_mask, att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
+    seq_q, seq_k = getattr(x, "_hamt_seq", None), getattr(c, "_hamt_seq", None)     # one side packed: see CrossAttnBlockFn
+    pairs = c.shape[0] if seq_q is not None else (x.shape[0] if seq_k is not None else 0)
+    y, y16 = CrossAttnBlockFn.apply(x, kv16, seq_k[2] if seq_k is not None else c.shape[1], None if seq_k is not None else add_mask,
+                                    att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
                                     att.query.weight, att.query.bias, att_out.dense.weight, att_out.dense.bias,
-                                    att_out.LayerNorm.weight, att_out.LayerNorm.bias)
-    return _tag(y, y16)
+                                    att_out.LayerNorm.weight, att_out.LayerNorm.bias, seq_q, seq_k, pairs)
+    y = _tag(y, y16)
+    if seq_q is not None:
+        y._hamt_seq = seq_q
+    return y
 
 
 def ffn_block(x, inter, out, training):

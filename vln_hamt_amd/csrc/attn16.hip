@@ -31,7 +31,12 @@ struct Attn16Args {
   void *out, *dq, *dk, *dv;
   float* lse;
   const uint64_t* rng;
-  const int* cu;   // packed self-attention (hamt_attn_varlen_*): sample b owns rows [cu[b], cu[b + 1]) of q / k / v / o; else nullptr
+  // packed layouts (hamt_attn_varlen_*): sequence b owns rows [cu_q[b], cu_q[b + 1]) of q / o / d_o / dq and / or rows [cu_k[b], cu_k[b + 1])
+  // of k / v / dk / dv instead of a fixed stride (nullptr: fixed stride b * Sq resp. b * Sk).  Query sequences b >= n_pairs have no keys
+  // (filler sequences of a bucketed packed batch): their outputs / query gradients are zeros.
+  const int* cu_q;
+  const int* cu_k;
+  int n_pairs;
 };
 
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&f)[8]);
@@ -449,11 +454,14 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   // rows and lengths of this sample: fixed stride (padded batch), or its own row range of a packed batch (every key is real)
   int Sq = d.Sq, Sk = d.Sk;
   size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
-  if (a.cu) {
-    const int c0 = a.cu[b];
-    Sq = Sk = a.cu[b + 1] - c0;
-    qrow0 = krow0 = (size_t)c0;
-    if (Sq <= 0) return;                               // (whole workgroup: an empty slot of a bucketed batch)
+  if (a.cu_q) { const int c0 = a.cu_q[b]; Sq = a.cu_q[b + 1] - c0; qrow0 = (size_t)c0; }
+  if (Sq <= 0) return;                                 // (whole workgroup: an empty slot of a bucketed batch)
+  if (a.cu_k) { const int c0 = a.cu_k[b]; Sk = a.cu_k[b + 1] - c0; krow0 = (size_t)c0; }
+  if (((a.cu_q || a.cu_k) && b >= a.n_pairs) || Sk <= 0) {   // a filler query sequence (or an empty key sequence): no keys -> zero output rows, lse 0
+    TO* O0 = (TO*)a.out + qrow0 * d.ldo + h * 64;
+    for (int i = t; i < Sq * 8; i += nt) st4<TO>(O0 + (size_t)(i >> 3) * d.ldo + (i & 7) * 8, 0.f, 0.f, 0.f, 0.f), st4<TO>(O0 + (size_t)(i >> 3) * d.ldo + (i & 7) * 8 + 4, 0.f, 0.f, 0.f, 0.f);
+    for (int i = t; i < Sq; i += nt) a.lse[((size_t)b * d.heads + h) * d.Sq + i] = 0.f;
+    return;
   }
   constexpr int SKP = KB * 16;                         // staged key rows: zeros (K, V) and -inf (mask) beyond Sk, so the
   bf16_t* Ks = sm;                                     // whole kernel is branch-free in the key dimension
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s)   // clamped, not branched (rows >= Sq are never stored)
     qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : Sq - 1) * d.ldq + 32 * s + 8 * g);
-  stage_mask(a.cu ? nullptr : a.mask, b, Sk, SKP, mk_s, t, nt);
+  stage_mask(a.cu_k ? nullptr : a.mask, b, Sk, SKP, mk_s, t, nt);
   rows_store<TI, IT>(rk, SKP, Ks, t, nt);
   rows_store<TI, IT>(rv, SKP, Vs, t, nt);
   __syncthreads();
@@ -534,11 +542,13 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   const int h = blockIdx.x, b = blockIdx.y;
   int Sq = d.Sq, Sk = d.Sk;                            // (as in the forward kernel: fixed stride, or this sample's rows of a packed batch)
   size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
-  if (a.cu) {
-    const int c0 = a.cu[b];
-    Sq = Sk = a.cu[b + 1] - c0;
-    qrow0 = krow0 = (size_t)c0;
-    if (Sq <= 0) return;
+  if (a.cu_q) { const int c0 = a.cu_q[b]; Sq = a.cu_q[b + 1] - c0; qrow0 = (size_t)c0; }
+  if (Sq <= 0) return;
+  if (a.cu_k) { const int c0 = a.cu_k[b]; Sk = a.cu_k[b + 1] - c0; krow0 = (size_t)c0; }
+  if (((a.cu_q || a.cu_k) && b >= a.n_pairs) || Sk <= 0) {   // a filler query sequence: zero query gradients, no keys to give gradients to
+    TI* dQ0 = (TI*)a.dq + qrow0 * d.ldq + h * 64;
+    for (int i = t; i < Sq * 8; i += nt) { st4<TI>(dQ0 + (size_t)(i >> 3) * d.ldq + (i & 7) * 8, 0.f, 0.f, 0.f, 0.f); st4<TI>(dQ0 + (size_t)(i >> 3) * d.ldq + (i & 7) * 8 + 4, 0.f, 0.f, 0.f, 0.f); }
+    return;
   }
   const int nqb = (Sq + 15) >> 4, nkb = (Sk + 15) >> 4, sq16 = nqb * 16, sk16 = nkb * 16, PST = sq16 + 8;
   bf16_t* Qs = sm;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
     rows_load<TO, 2>(O, d.ldo, Sq, t, nt, ro);
     rows_load<TI, 2>(K, d.ldk, Sk, t, nt, rk);
     rows_load<TI, 2>(V, d.ldv, Sk, t, nt, rv);
-    stage_mask(a.cu ? nullptr : a.mask, b, Sk, sk16, mk_s, t, nt);
+    stage_mask(a.cu_k ? nullptr : a.mask, b, Sk, sk16, mk_s, t, nt);
     for (int i = t; i < sk16 * PST / 8; i += nt) { ((uint4*)Pt)[i] = make_uint4(0, 0, 0, 0); ((uint4*)dSt)[i] = make_uint4(0, 0, 0, 0); }
     rows_store<TI, 2>(rq, sq16, Qs, t, nt);
     rows_store<TO, 2>(rdo, sq16, dOs, t, nt);
@@ -738,8 +748,9 @@ bool use_s128_bwd(const hamt_attn_desc* d) {
 }  // namespace
 
 void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
-                            float* lse, const uint64_t* rng, hipStream_t s, const int* cu) {
-  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng, cu};
+                            float* lse, const uint64_t* rng, hipStream_t s, const int* cu_q, const int* cu_k, int n_pairs) {
+  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng, cu_q, cu_k, n_pairs};
+  const int* cu = cu_q ? cu_q : cu_k;
   dim3 grid((d->Sq + T64 - 1) / T64, d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
   if (use_s128_fwd(d) || cu) {      // (the packed form exists in the single-pass kernels only)
@@ -756,8 +767,10 @@ void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* 
 }
 
 void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
-                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s, const int* cu) {
-  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng, cu};
+                            const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s,
+                            const int* cu_q, const int* cu_k, int n_pairs) {
+  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng, cu_q, cu_k, n_pairs};
+  const int* cu = cu_q ? cu_q : cu_k;
   dim3 grid(d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
   if (use_s128_bwd(d) || cu) {

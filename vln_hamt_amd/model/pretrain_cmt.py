@@ -189,9 +189,13 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
         B, S, H = ob_embeds.shape                                  # S = 37; the reference hard-codes 36 views (:211-212)
         flat = ob_embeds.reshape(B * S, H)
         base = torch.arange(B, device=flat.device) * S
-        anchor = ops.gather_rows(flat, (base + sp_anchor_idxs).repeat_interleave(36))
+        # the anchor view's embedding next to each of the 36 views (:211-214).  One row per sample is gathered and BROADCAST: the backward
+        # is a sum over the 36 copies and one add per anchor row -- a gather of 36 repeated indices would scatter-add 36 atomics into
+        # the same row in whatever order they land, and the bf16 images downstream re-round that noise into every weight gradient
+        # (run-to-run differences of up to 5e-3 of a gradient's largest element at small batches: tools/determinism_check.py)
+        anchor = ops.gather_rows(flat, base + sp_anchor_idxs)
         rest = ops.gather_rows(flat, (base[:, None] + torch.arange(S - 1, device=flat.device)[None]).reshape(-1))
-        cat_ob_embeds = torch.cat([anchor, rest], -1).view(B, S - 1, 2 * H)
+        cat_ob_embeds = torch.cat([anchor[:, None].expand(B, S - 1, H), rest.view(B, S - 1, H)], -1)
         prediction_scores = self.sprel_head(cat_ob_embeds)
         if compute_loss:
             return ops.mse_loss(prediction_scores, sp_targets)

@@ -286,7 +286,8 @@ class BertXAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None):
-        if input_tensor.dim() == 3 and blocks.usable(self.att.prec, input_tensor):
+        packed = input_tensor.dim() == 2 and getattr(input_tensor, "_hamt_seq", None) is not None      # (the packed text of a ragged batch)
+        if (input_tensor.dim() == 3 or packed) and blocks.usable(self.att.prec, input_tensor):
             return blocks.cross_attn_block(input_tensor, ctx_tensor, ctx_att_mask, self.att, self.output, self.training)
         return self.output(self.att(input_tensor, ctx_tensor, ctx_att_mask), input_tensor)
 
@@ -303,6 +304,9 @@ def _ffn(inter, out, x, training):
 # layer and no gradient-accumulation adds).  Measured on MI355X it is 0.3 % (B=16) to 0.8 % (B=64) SLOWER than the two separate
 # blocks, which run side by side on the two compute streams, so it is off by default.
 XBIDIR = os.environ.get("HAMT_XBIDIR") == "1"
+# HAMT_NO_X_PACK=1: a packed text stream (ragged batches, NavPreTrainedModel._text) is scattered back to [B, L, H] BEFORE the
+# cross-modal layers instead of behind them (measurement switch)
+X_PACK = os.environ.get("HAMT_NO_X_PACK") != "1"
 
 
 class LXRTXLayer(nn.Module):
@@ -350,7 +354,7 @@ class LXRTXLayer(nn.Module):
         main = torch.cuda.current_stream()
         side = streams.side_stream(lang_feats.device)
         xa = self.visual_attention
-        if XBIDIR and blocks.usable(xa.att.prec, lang_feats) and blocks.usable(xa.att.prec, visn_feats):
+        if XBIDIR and lang_feats.dim() == 3 and blocks.usable(xa.att.prec, lang_feats) and blocks.usable(xa.att.prec, visn_feats):
             # the shared cross attention of both directions is ONE node on `main`; the streams fork behind it
             lang_x, visn_x = self.cross_att(lang_feats, lang_mask, visn_feats, visn_mask)
             streams.fork(main, side)
@@ -410,8 +414,14 @@ class LxmertEncoder(nn.Module):
                 img_embeds=None, extended_img_masks=None, text_done=False):
         if not text_done:       # (the caller may have run them already, next to the vision-side embedders)
             txt_embeds = self.text_layers(txt_embeds, extended_txt_masks)
+        # a PACKED text stream [M, H] (NavPreTrainedModel._text(keep_packed=True): the real tokens of a ragged batch back to back) stays
+        # packed through the cross-modal layers -- their attentions take one packed side (blocks.CrossAttnBlockFn), the rest is
+        # row-wise -- and is scattered back into [B, L, H] behind the last one
+        seq, unpack = getattr(txt_embeds, "_hamt_seq", None), getattr(txt_embeds, "_hamt_unpack", None)
         if not self.update_lang_bert:
             txt_embeds = txt_embeds.detach()
+            if seq is not None:
+                txt_embeds._hamt_seq = seq
         if img_embeds is not None and self.r_layers is not None:
             for layer in self.r_layers:
                 img_embeds = layer(img_embeds, extended_img_masks)[0]
@@ -426,6 +436,8 @@ class LxmertEncoder(nn.Module):
             vis_masks = torch.cat([extended_hist_masks, extended_img_masks], -1)
         for layer in self.x_layers:
             txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks)
+        if unpack is not None:
+            txt_embeds = ops.gather_rows(txt_embeds, unpack[0]).view(unpack[1], unpack[2], -1)
         hist_embeds = vis[:, :n_hist]
         if img_embeds is not None:
             img_embeds = vis[:, n_hist:]
@@ -556,7 +568,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
         self.encoder = LxmertEncoder(config)
         self.init_weights()
 
-    def _text(self, txt_ids, txt_m):
+    def _text(self, txt_ids, txt_m, keep_packed=False):
         """Text embedder + the text-only layers (vilmodel.py:601, 441-443).  With a packing plan on `txt_ids` (`_hamt_pack` = (pack_idx
         [M], cu_seqlens int32 [n + 1], unpack_idx [B L]), put there by MultiStepNavCMTPreTraining.forward from the batch's `txt_pack_idx`
         / `txt_cu` / `txt_unpack_idx`) the nine layers run on the REAL tokens only -- the instructions back to back, self-attention per
@@ -574,6 +586,9 @@ class NavPreTrainedModel(BertPreTrainedModel):
         x._hamt_seq = (cu, int(cu.shape[0]) - 1, L)
         for layer in self.encoder.layer:
             x = layer(x, None)[0]
+        if keep_packed and X_PACK and not XBIDIR:      # (the cross-modal layers go on with the packed rows: LxmertEncoder.forward)
+            x._hamt_unpack = (unpack_idx, B, L)
+            return x
         return ops.gather_rows(x, unpack_idx).view(B, L, H)
 
     @staticmethod
@@ -613,12 +628,12 @@ class NavPreTrainedModel(BertPreTrainedModel):
                 streams.share(t, side)
             with torch.cuda.stream(side):
                 hist, ob = vision_side()
-            txt = self._text(txt_ids, txt_m)
+            txt = self._text(txt_ids, txt_m, keep_packed=True)
             streams.join(main, side)
             streams.share(hist, main)
             streams.share(ob, main)
             return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True)
-        txt = self._text(txt_ids, txt_m)
+        txt = self._text(txt_ids, txt_m, keep_packed=True)
         hist, ob = vision_side()
         return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True)
 
@@ -635,8 +650,9 @@ class NavPreTrainedModel(BertPreTrainedModel):
         def text_side():
             txt = self._text(txt_ids, txt_m1)
             L, H = txt.shape[1:]
-            rep = torch.arange(B, device=dev).repeat(n_rep)
-            return ops.gather_rows(txt.reshape(B, L * H), rep).view(n_rep * B, L, H), txt_m1.repeat(n_rep, 1, 1, 1)
+            # n_rep copies by broadcast: the backward is a sum over the copies in a fixed order (a gather of repeated row indices
+            # would scatter-add them with atomics in whatever order they land)
+            return txt[None].expand(n_rep, B, L, H).reshape(n_rep * B, L, H), txt_m1.repeat(n_rep, 1, 1, 1)
 
         def vision_side(neg_idxs, shuffled_pos_ids):
             cls, nopos = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
