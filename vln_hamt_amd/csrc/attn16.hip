@@ -676,6 +676,195 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   }
 }
 
+// Single-pass backward for sequences of 129 .. 224 tokens (ViT-B/16: S = 197, vision_transformer.py:154-178): one workgroup per
+// head with one wave per 16 rows, NOTHING but the four operands in LDS (130 KB at 224 tokens: the P~ / dS arrays of the kernel
+// above would not fit next to them).  The probabilities are computed twice, once per ownership:
+//   phase A, wave = 16 queries:  S^T, dP^T [key][q] -> dS^T stays in registers as the B operand of dQ^T = K^T dS^T (the forward
+//            kernel's O^T = V^T P^T idiom: the MFMA output layout IS the operand layout when the reduction index is permuted the
+//            same way on both sides);
+//   phase B, wave = 16 keys:     S, dP [q][key] again (4 MFMAs per 16 x 16 block, exp from the saved lse: no row reduction to
+//            redo) -> P~ and dS in registers as the B operands of dV^T = dO^T P~ and dK^T = Q^T dS.
+// No barrier between the phases, no LDS traffic but fragment reads.  Same dropout stream as every other attention kernel: phase B
+// redoes the hash of (query row, group of 4 keys) and picks its key's 16 bits.  (For <= 128 tokens this form was measured against
+// the kernel above and lost: profiles/r03_attn_bwd_recompute.txt.)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(1024) void attn_wide_bwd_kernel(Attn16Args a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  const hamt_attn_desc& d = a.d;
+  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, w = t >> 6, l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int Sq = d.Sq, Sk = d.Sk;
+  const size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
+  const int nqb = (Sq + 15) >> 4, nkb = (Sk + 15) >> 4, sq16 = nqb * 16, sk16 = nkb * 16;
+  bf16_t* Qs = sm;
+  bf16_t* dOs = Qs + sq16 * AST;
+  bf16_t* Ks = dOs + sq16 * AST;
+  bf16_t* Vs = Ks + sk16 * AST;
+  float* lse_s = (float*)(Vs + sk16 * AST);
+  float* delta_s = lse_s + sq16;
+  float* mk_s = delta_s + sq16;
+  uint32_t* rowh_s = (uint32_t*)(mk_s + sk16);         // per query: the row half of the dropout hash
+  const TI* Q = (const TI*)a.q + qrow0 * d.ldq + h * 64;
+  const TI* K = (const TI*)a.k + krow0 * d.ldk + h * 64;
+  const TI* V = (const TI*)a.v + krow0 * d.ldv + h * 64;
+  const TO* O = (const TO*)a.o + qrow0 * d.ldo + h * 64;
+  const TO* dO = (const TO*)a.d_o + qrow0 * d.ldo + h * 64;
+  const RngKey key = rng_key(a.rng, d.call_id);
+  {  // all five matrices in flight at once (nt = 64 * max(nqb, nkb) => 2 pieces per thread and matrix)
+    Raw8<TI> rq[2], rk[2], rv[2];
+    Raw8<TO> rdo[2], ro[2];
+    rows_load<TI, 2>(Q, d.ldq, Sq, t, nt, rq);
+    rows_load<TO, 2>(dO, d.ldo, Sq, t, nt, rdo);
+    rows_load<TO, 2>(O, d.ldo, Sq, t, nt, ro);
+    rows_load<TI, 2>(K, d.ldk, Sk, t, nt, rk);
+    rows_load<TI, 2>(V, d.ldv, Sk, t, nt, rv);
+    stage_mask(a.mask, b, Sk, sk16, mk_s, t, nt);
+    for (int i = t; i < sq16; i += nt) rowh_s[i] = hamt_mix32((uint32_t)((b * d.heads + h) * d.Sq + i) ^ key.k0);
+    rows_store<TI, 2>(rq, sq16, Qs, t, nt);
+    rows_store<TO, 2>(rdo, sq16, dOs, t, nt);
+    // delta = rowsum(dO * O) in fp32 from the un-rounded values (8 threads per row) and the saved lse
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (t >> 3) + i * (nt >> 3);
+      float f[8], o8[8], acc = 0.f;
+      raw_f32(rdo[i], f);
+      raw_f32(ro[i], o8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += f[j] * o8[j];
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+      if ((t & 7) == 0 && r < sq16) { delta_s[r] = acc; lse_s[r] = r < Sq ? a.lse[((size_t)b * d.heads + h) * d.Sq + r] : 0.f; }
+    }
+    rows_store<TI, 2>(rk, sk16, Ks, t, nt);
+    rows_store<TI, 2>(rv, sk16, Vs, t, nt);
+  }
+  __syncthreads();
+  const float inv_keep = d.p_drop > 0.f ? 1.0f / (1.0f - d.p_drop) : 1.0f;
+  if (w < nqb) {   // phase A: this wave's 16 queries x all keys; lane owns query ql = 16w + l15
+    const int ql = 16 * w + l15;
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { qf[s] = rfrag(Qs, ql, 32 * s + 8 * g); df[s] = rfrag(dOs, ql, 32 * s + 8 * g); }
+    const float lse_q = lse_s[ql], delta_q = delta_s[ql];
+    const uint32_t rowh = rowh_s[ql];
+    const bool qv = ql < Sq;                         // (a padding query has Q = dO = 0: its dS is 0 by itself; pinned anyway)
+    // dQ^T[d][q] = K^T dS^T, two key blocks at a time: k-step s covers key blocks 2s, 2s+1; this lane group's k = keys 4g..4g+3 of each
+    f32x4 dqf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqf[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; 2 * s < nkb; ++s) {
+      float ds[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kb = 2 * s + e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[e][r] = 0.f;
+        if (kb < nkb) {
+          f32x4 sf = (f32x4){0.f, 0.f, 0.f, 0.f}, dpf = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            sf = MFMA16(rfrag(Ks, 16 * kb + l15, 32 * s2 + 8 * g), qf[s2], sf);      // S^T[key][q]
+            dpf = MFMA16(rfrag(Vs, 16 * kb + l15, 32 * s2 + 8 * g), df[s2], dpf);    // dP^T[key][q] = V dO^T
+          }
+          const float4 mk = *(const float4*)(mk_s + 16 * kb + 4 * g);
+          const float mk4[4] = {mk.x, mk.y, mk.z, mk.w};
+          float ds4[4] = {1.f, 1.f, 1.f, 1.f};
+          if (d.p_drop > 0.f) drop_scale4(key, rowh, (uint32_t)(4 * kb + g), d.p_drop, inv_keep, ds4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __expf(fmaf(sf[r], d.scale, mk4[r]) - lse_q);          // 0 for the padding keys (mask = -inf)
+            ds[e][r] = qv ? pr * (dpf[r] * ds4[r] - delta_q) * d.scale : 0.f;
+          }
+        }
+      }
+      const bf16x8 sb = pack_frag(ds[0], ds[1]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dqf[db] = MFMA16(tfrag_lim(Ks, AST, 32 * s + 4 * g, 32 * s + 16 + 4 * g, sk16, 16 * db, lane), sb, dqf[db]);
+    }
+    if (qv) {
+      TI* dQ = (TI*)a.dq + qrow0 * d.ldq + h * 64 + (size_t)ql * d.ldq;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) st4<TI>(dQ + 16 * db + 4 * g, dqf[db][0], dqf[db][1], dqf[db][2], dqf[db][3]);
+    }
+  }
+  if (w < nkb) {   // phase B: this wave's 16 keys x all queries; lane owns key kl = 16w + l15
+    const int kl = 16 * w + l15;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { kf[s] = rfrag(Ks, kl, 32 * s + 8 * g); vf[s] = rfrag(Vs, kl, 32 * s + 8 * g); }
+    const float mk = mk_s[kl];
+    const uint32_t grp_h = (uint32_t)(kl >> 2) * 0x9e3779b9u + key.k1, thr = (uint32_t)(d.p_drop * 65536.0f);
+    const bool second = (kl & 2) != 0, high = (kl & 1) != 0;   // which 16 bits of the group's two hash words are this key's
+    f32x4 dkf[4], dvf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dkf[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvf[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int s = 0; 2 * s < nqb; ++s) {
+      float pt[2][4], dsv[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int qb = 2 * s + e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pt[e][r] = 0.f; dsv[e][r] = 0.f; }
+        if (qb < nqb) {
+          f32x4 sf = (f32x4){0.f, 0.f, 0.f, 0.f}, dpf = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            sf = MFMA16(rfrag(Qs, 16 * qb + l15, 32 * s2 + 8 * g), kf[s2], sf);      // S[q][key]
+            dpf = MFMA16(rfrag(dOs, 16 * qb + l15, 32 * s2 + 8 * g), vf[s2], dpf);   // dP[q][key] = dO V^T
+          }
+          const float4 lse4 = *(const float4*)(lse_s + 16 * qb + 4 * g), del4 = *(const float4*)(delta_s + 16 * qb + 4 * g);
+          const uint4 rh4 = *(const uint4*)(rowh_s + 16 * qb + 4 * g);
+          const float lq[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dq_[4] = {del4.x, del4.y, del4.z, del4.w};
+          const uint32_t rh[4] = {rh4.x, rh4.y, rh4.z, rh4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __expf(fmaf(sf[r], d.scale, mk) - lq[r]);
+            float keep = 1.f;
+            if (d.p_drop > 0.f) {                  // drop_scale4's element (kl & 3) of group kl >> 2 of row q
+              uint32_t x = hamt_mix32(rh[r] + grp_h);
+              if (second) x = hamt_mix32(x ^ 0x85ebca6bu);
+              keep = (high ? (x >> 16) : (x & 0xffffu)) >= thr ? inv_keep : 0.0f;
+            }
+            const bool qv = 16 * qb + 4 * g + r < Sq;
+            pt[e][r] = qv ? pr * keep : 0.f;
+            dsv[e][r] = qv ? pr * (dpf[r] * keep - dq_[r]) * d.scale : 0.f;
+          }
+        }
+      }
+      const bf16x8 pb = pack_frag(pt[0], pt[1]), sb = pack_frag(dsv[0], dsv[1]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {   // reduction over the queries 32s + {4g.., 16 + 4g..}
+        dvf[db] = MFMA16(tfrag_lim(dOs, AST, 32 * s + 4 * g, 32 * s + 16 + 4 * g, sq16, 16 * db, lane), pb, dvf[db]);
+        dkf[db] = MFMA16(tfrag_lim(Qs, AST, 32 * s + 4 * g, 32 * s + 16 + 4 * g, sq16, 16 * db, lane), sb, dkf[db]);
+      }
+    }
+    if (kl < Sk) {
+      TI* dK = (TI*)a.dk + krow0 * d.ldk + h * 64 + (size_t)kl * d.ldk;
+      TI* dV = (TI*)a.dv + krow0 * d.ldv + h * 64 + (size_t)kl * d.ldv;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        st4<TI>(dK + 16 * db + 4 * g, dkf[db][0], dkf[db][1], dkf[db][2], dkf[db][3]);
+        st4<TI>(dV + 16 * db + 4 * g, dvf[db][0], dvf[db][1], dvf[db][2], dvf[db][3]);
+      }
+    }
+  }
+}
+
+template <typename TI, typename TO>
+void launch_wide_bwd(const Attn16Args& a, hipStream_t s) {
+  const hamt_attn_desc& d = a.d;
+  const int nqb = (d.Sq + 15) / 16, nkb = (d.Sk + 15) / 16, nb = nqb > nkb ? nqb : nkb;
+  const int sq16 = nqb * 16, sk16 = nkb * 16;
+  const size_t lds = (size_t)2 * (sq16 + sk16) * AST * sizeof(bf16_t) + (size_t)(3 * sq16 + sk16) * sizeof(float);
+  static bool raised = false;                      // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_bwd_kernel<TI, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL((attn_wide_bwd_kernel<TI, TO>), dim3(d.heads, d.B), dim3(64 * nb), lds, s, a);
+}
+
 template <typename TI, typename TO, int KB, int IT>
 void launch_s128_fwd_kb(const Attn16Args& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   static bool raised = false;                      // > 64 KiB of dynamic LDS needs the opt-in once per kernel
@@ -744,6 +933,10 @@ bool use_s128_bwd(const hamt_attn_desc* d) {
   static const bool off = getenv("HAMT_NO_ATTN_S128") != nullptr;
   return !off && d->Sq <= 128 && d->Sk <= 128;
 }
+bool use_wide_bwd(const hamt_attn_desc* d) {     // 129 .. 224 tokens on a side (ViT-B/16: 197): the operands of a head fit in LDS
+  static const bool off = getenv("HAMT_NO_ATTN_WIDE_BWD") != nullptr;
+  return !off && d->Sq <= 224 && d->Sk <= 224;
+}
 
 }  // namespace
 
@@ -778,6 +971,13 @@ void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* 
     else if (ib && ob) launch_s128_bwd<bf16_t, bf16_t>(a, s);
     else if (ib) launch_s128_bwd<bf16_t, float>(a, s);
     else launch_s128_bwd<float, bf16_t>(a, s);
+    return;
+  }
+  if (use_wide_bwd(d)) {
+    if (!ib && !ob) launch_wide_bwd<float, float>(a, s);
+    else if (ib && ob) launch_wide_bwd<bf16_t, bf16_t>(a, s);
+    else if (ib) launch_wide_bwd<bf16_t, float>(a, s);
+    else launch_wide_bwd<float, bf16_t>(a, s);
     return;
   }
   if (!ib && !ob) hipLaunchKernelGGL((attn16_bwd_kernel<float, float>), grid, block, 0, s, a);
