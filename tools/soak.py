@@ -27,7 +27,9 @@ for s in range(steps):
     task = sched.task_at(s)
     key = (task, s % 12)
     if key not in batches:
-        b = make_batch(task, int(os.environ.get("SOAK_B", "32")), cfg, seed=100 + s % 12, txt_len=80, hist_len=5, mlm_exact=12 if task == "mlm" else None, device=dev)
+        ragged = os.environ.get("SOAK_RAGGED") == "1"      # ragged lengths: the text packing path (varlen attention, packed x-layers)
+        b = make_batch(task, int(os.environ.get("SOAK_B", "32")), cfg, seed=100 + s % 12, txt_len=80, hist_len=7 if ragged else 5, ragged=ragged,
+                       mlm_exact=12 if (task == "mlm" and not ragged) else None, device=dev)
         if task == "itm":
             r = make_itm_rng(b, seed=s); b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
         batches[key] = b
