@@ -282,3 +282,31 @@ def test_files_to_training_steps_end_to_end():
         losses.append(float(loss))
     assert seen == set(ratios), seen
     assert all(np.isfinite(l) for l in losses), losses
+
+
+def test_text_pack_plan_invariants():
+    """synth.text_pack_plan: the packed rows are the real tokens in row-major order, then filler rows up to the bucket; every row belongs
+    to exactly one sequence of at most L rows; `cu` has ONE length per (B, L, bucket) whatever the lengths (unused filler slots are
+    empty sequences), so a captured step's key depends on the bucketed row count only; unpack sends real positions to their own row."""
+    from vln_hamt_amd.synth import text_pack_plan
+    rng = np.random.default_rng(3)
+    L, B = 80, 24
+    shapes = set()
+    for bucket in (128, 512):
+        for _ in range(20):
+            lens = rng.integers(1, L + 1, B)
+            lens[rng.integers(B)] = L
+            plan = text_pack_plan(lens, L, bucket=bucket)
+            if plan is None:
+                assert (int(lens.sum()) + bucket - 1) // bucket * bucket >= B * L
+                continue
+            pack, cu, unpack = (t.numpy() for t in plan)
+            M = int(lens.sum())
+            assert pack.shape[0] % bucket == 0 and pack.shape[0] - M < bucket and int(cu[-1]) == pack.shape[0]
+            valid = (np.arange(L)[None] < lens[:, None]).reshape(-1)
+            assert (pack[:M] == np.flatnonzero(valid)).all()
+            assert (np.diff(cu) >= 0).all() and (np.diff(cu) <= L).all() and (cu[:B + 1] == np.concatenate([[0], np.cumsum(lens)])).all()
+            assert cu.shape[0] == B + 1 + (bucket + L - 1) // L
+            assert (unpack[np.flatnonzero(valid)] == np.arange(M)).all() and unpack.min() >= 0 and unpack.max() < M
+            shapes.add((bucket, cu.shape[0]))
+    assert len(shapes) == 2

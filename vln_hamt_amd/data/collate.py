@@ -59,7 +59,9 @@ class PackedBatch:
         `out`: tensors to fill in place where key, shape and dtype match (static inputs of a captured graph).
         `text_pack`: add the text packing plan of the batch (`txt_pack_idx`, `txt_cu`, `txt_unpack_idx`: synth.text_pack_plan over the
         instruction lengths) -- three small index tensors beyond the reference's keys, with which the model's text-only layers skip
-        the padded positions (model.vilmodel.NavPreTrainedModel._text); absent when the batch has (almost) no padding."""
+        the padded positions (model.vilmodel.NavPreTrainedModel._text); absent when the batch has (almost) no padding.  An integer
+        is the bucket of the packed row count (default 128 rows): a captured step (graph.GraphedTrainStep) is keyed by that count,
+        so a coarser bucket trades a little padding for fewer captures."""
         device = torch.device(device)
         if device.type != "cuda":
             raise L.HamtError("PackedBatch.to_device: the collation kernels have no CPU path")
@@ -108,7 +110,7 @@ class PackedBatch:
                 res[name] = src
         if text_pack and "txt" in self.lens:
             from ..synth import text_pack_plan
-            plan = text_pack_plan(self.lens["txt"], max(self.lens["txt"]))
+            plan = text_pack_plan(self.lens["txt"], max(self.lens["txt"]), bucket=128 if text_pack is True else int(text_pack))
             if plan is not None:
                 for name, t in zip(("txt_pack_idx", "txt_cu", "txt_unpack_idx"), plan):
                     res[name] = t.pin_memory().to(device, non_blocking=True)

@@ -33,7 +33,8 @@ def text_pack_plan(lens, L: int, bucket: int = 128):
     """(pack_idx int64 [M], cu_seqlens int32 [n + 1], unpack_idx int64 [B L]) for a padded text batch [B, L] with `lens` real tokens per
     row, or None when (almost) nothing is padding.  pack_idx = the flat positions b L + i of the real tokens, row by row, then filler
     positions up to a multiple of `bucket` rows (a static length per bucket for captured graphs); cu_seqlens = the B sequences' row
-    ranges followed by filler sequences of at most L rows each, so that every packed row belongs to a sequence; unpack_idx sends each
+    ranges followed by ceil(bucket / L) filler slots -- sequences of at most L rows each that cover the filler rows, the rest empty -- so
+    that every packed row belongs to a sequence and `cu` has ONE length per (B, L, bucket); unpack_idx sends each
     padded position to a packed row -- its own for a real token, its sequence's first row for padding (any finite value serves there).
     Consumed by model.vilmodel.NavPreTrainedModel._text."""
     lens = np.asarray(lens).astype(np.int64)
@@ -49,6 +50,9 @@ def text_pack_plan(lens, L: int, bucket: int = 128):
     cu = list(starts)
     while cu[-1] < Mb:
         cu.append(min(Mb, cu[-1] + L))
+    # a FIXED number of filler slots for this (B, L, bucket) -- the unused ones are empty sequences, which the kernels skip -- so that
+    # the shape of `cu` (part of a captured step's key, graph.GraphedTrainStep.key_for) depends on the packed row count's bucket only
+    cu += [Mb] * (B + 1 + (bucket + L - 1) // L - len(cu))
     unpack = np.repeat(starts[:-1], L)                       # padding -> the sequence's first row
     unpack[flat] = np.arange(M)
     return torch.from_numpy(pack), torch.tensor(cu, dtype=torch.int32), torch.from_numpy(unpack)
