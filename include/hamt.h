@@ -347,6 +347,7 @@ int hamt_act_bwd(size_t n, const float* dy, const float* h, int mode, float* dx,
  * losses, reduction='none' as in the reference
  *   ce:  loss[r] = logsumexp(x[r,:C]) - x[r,label[r]]     (A15/A16/A20; -inf logits allowed)
  *        backward  dx[r,c] = g[r] * (softmax(x[r])[c] - [c == label[r]])
+ *        a label outside [0, C) marks an ignored row (F.cross_entropy's ignore_index): loss 0, dx = 0
  *   mse: loss = (x - t)^2 elementwise (A17/A18); backward dx = 2 g (x - t)
  *   kl:  loss[r] = sum_c t*(log t - log_softmax(x)[c]) with 0*log0 = 0 (A19, pretrain_cmt.py:239-240)
  *        backward dx[r,c] = g[r] * (softmax(x)[c] * sum_c t - t[c])

@@ -1389,6 +1389,48 @@ def test_attention_varlen_matches_per_sequence_attention(lens):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("task", ["sap", "mlm"])
+def test_packed_step_replays_with_other_lengths(tiny, task):
+    """The text packing plan is DATA of a captured step, not part of it: a step captured on one ragged batch and replayed with another
+    batch of the same key (same shapes, same bucketed packed row count; other instruction lengths, other row ranges in `txt_cu`) gives
+    the loss the eager step gives on that batch -- nothing derived from the first batch's lengths is baked into the graph (a stale plan
+    would hand tokens to the wrong sequences: a different loss, not a slightly different one)."""
+    from vln_hamt_amd.graph import GraphedTrainStep
+    from vln_hamt_amd.optim import AdamW
+    from vln_hamt_amd.synth import make_batch, text_pack_plan
+    _, cfg, sd = tiny
+    L, B = 48, 16
+    b1 = make_batch(task, B, cfg, seed=41, txt_len=L, hist_len=4, ragged=True, mlm_exact=3 if task == "mlm" else None, device=DEV)
+    assert "txt_pack_idx" in b1
+    # the second batch: the same samples in another order (every tensor rolled along the batch), the plan rebuilt for the new order
+    b2 = {k: (torch.roll(v, 5, 0) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else v) for k, v in b1.items()
+          if not k.startswith("txt_pack") and k not in ("txt_cu", "txt_unpack_idx")}
+    lens2 = b2["txt_masks"].sum(1).cpu().numpy()
+    plan = text_pack_plan(lens2, L)
+    b2["txt_pack_idx"], b2["txt_cu"], b2["txt_unpack_idx"] = (t.to(DEV) for t in plan)
+    if "txt_label_idx" in b2:      # (the masked positions moved with their samples)
+        b2["txt_label_idx"] = (b2["txt_labels"] != -1).reshape(-1).nonzero(as_tuple=False).squeeze(1)
+    assert GraphedTrainStep.key_for(task, b1) == GraphedTrainStep.key_for(task, b2)
+    assert not torch.equal(b1["txt_cu"], b2["txt_cu"])
+
+    def make():
+        m = build(cfg, sd, "bf16", train=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m, AdamW([{"params": list(m.parameters()), "weight_decay": 0.0}], lr=0.0, betas=(0.9, 0.98), eps=1.0)
+
+    m1, _ = make()
+    want = [float(m1(b, task, True).mean()) for b in (b1, b2, b1)]
+    m2, o2 = make()
+    gs = GraphedTrainStep(m2, o2, 5.0)
+    key = GraphedTrainStep.key_for(task, b1)
+    got = [float(gs.step(key, b, task)) for b in (b1, b2, b1)]      # capture on b1, replay with b2, replay with b1 (lr = 0: same weights)
+    for w, g in zip(want, got):
+        assert abs(w - g) <= 2e-3 * max(1.0, abs(w)), (want, got)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("packed_side", ["q", "k"])
 def test_attention_varlen_cross_matches_per_pair_attention(packed_side):
     """hamt_attn_varlen_cross_fwd / _bwd -- ONE side packed back to back, the other at a fixed stride with an additive key mask --

@@ -893,6 +893,7 @@ def test_losses():
     x[2, 5:40] = -float("inf")
     lab = torch.randint(0, Cc, (R,), generator=torch.Generator().manual_seed(2))
     lab[2] = 100
+    lab[7] = -100                                   # F.cross_entropy's ignore_index (pretrain_cmt.py:181): loss 0, zero gradient
     buf = torch.zeros(R, 1008, device=DEV)
     buf[:, :Cc] = x.to(DEV)
     xg = buf[:, :Cc].detach().requires_grad_(True)
@@ -904,6 +905,15 @@ def test_losses():
     loss.backward(gw.to(DEV))
     ref.backward(gw.double())
     close(xg.grad, xr.grad, 1e-5, "ce bwd")
+    assert float(loss[7]) == 0.0 and float(xg.grad[7].abs().max()) == 0.0
+    # any other label outside [0, C) is an ignored row too (never an out-of-bounds read)
+    lab2 = lab.clone(); lab2[3], lab2[4] = -1, Cc
+    xg2 = buf[:, :Cc].detach().requires_grad_(True)
+    loss2 = ops.cross_entropy(xg2, lab2.to(DEV))
+    loss2.backward(gw.to(DEV))
+    assert float(loss2[3]) == 0.0 and float(loss2[4]) == 0.0 and float(xg2.grad[3:5].abs().max()) == 0.0
+    keep = [i for i in range(R) if i not in (3, 4)]
+    close(loss2[keep], ref.detach()[keep], 1e-5, "ce with ignored rows")
     a, t = rnd(7, 36, 2, seed=4), rnd(7, 36, 2, seed=5)
     ag = a.to(DEV).requires_grad_(True)
     l2 = ops.mse_loss(ag, t.to(DEV))

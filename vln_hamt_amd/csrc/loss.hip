@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int C, const float* __restr
   const int r = blockIdx.x;
   const float* xr = x + (size_t)r * ldx;
   const float l = row_lse(xr, C, red);
-  if (threadIdx.x == 0) { lse[r] = l; loss[r] = l - xr[label[r]]; }
+  if (threadIdx.x == 0) {      // a label outside [0, C) is an ignored row (F.cross_entropy's ignore_index = -100, pretrain_cmt.py:181): loss 0
+    const int64_t lab = label[r];
+    lse[r] = l;
+    loss[r] = (lab >= 0 && lab < C) ? l - xr[lab] : 0.f;
+  }
 }
 __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, const float* __restrict__ x, int ldx, const int64_t* __restrict__ label,
                                                      const float* __restrict__ lse, const float* __restrict__ g,
@@ -48,8 +52,10 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, const float* __restr
   const float* xr = x + (size_t)r * ldx;
   float* dr = dx + (size_t)r * lddx;
   const float l = lse[r], gr = g[r];
-  const int lab = (int)label[r];
-  for (int c = threadIdx.x; c < C; c += 256) dr[c] = gr * (expf(xr[c] - l) - (c == lab ? 1.0f : 0.0f));
+  const int64_t lab64 = label[r];
+  const bool ignored = lab64 < 0 || lab64 >= C;      // (an ignored row: zero gradient)
+  const int lab = (int)lab64;
+  for (int c = threadIdx.x; c < C; c += 256) dr[c] = ignored ? 0.f : gr * (expf(xr[c] - l) - (c == lab ? 1.0f : 0.0f));
 }
 __global__ void mse_fwd_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ loss) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
