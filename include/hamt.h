@@ -201,12 +201,16 @@ int hamt_attn_varlen_bwd(const hamt_attn_desc* d, const void* q, const void* k, 
  *         row count up to its bucket -- have no keys: o = 0, dq = 0, nothing added to dk / dv.
  *   cu_k: queries at the fixed stride d->Sq, sample b's keys = rows [cu_k[b], cu_k[b + 1]) of k / v / dk / dv (<= d->Sk, all real:
  *         add_mask is ignored); n_pairs = d->B.  Key rows no sample owns are not written: zero dk / dv behind the last real row.
+ * `pair` (optional device array [B]; NULL = "b pairs with b, fillers behind n_pairs"): the key side of query sequence b -- the key sample
+ * (cu_q form: rows [pair[b] * Sk, ...) and row pair[b] of add_mask) or the entry of cu_k (cu_k form); negative = a filler.  Every key
+ * side must be named by at most one query sequence (dk / dv are stored, not accumulated).  For packed copies of a batch whose fillers lie
+ * between the copies (forward_itm's replicated text, vilmodel.py:672-676).
  * lse is [B, heads, d->Sq] in both forms. */
 int hamt_attn_varlen_cross_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
-                               const int* cu_k, int n_pairs, const float* add_mask, void* o, float* lse,
+                               const int* cu_k, int n_pairs, const int* pair, const float* add_mask, void* o, float* lse,
                                const uint64_t* rng, void* stream);
 int hamt_attn_varlen_cross_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
-                               const int* cu_k, int n_pairs, const float* add_mask, const void* o, const void* d_o,
+                               const int* cu_k, int n_pairs, const int* pair, const float* add_mask, const void* o, const void* d_o,
                                const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

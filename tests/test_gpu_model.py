@@ -1431,19 +1431,23 @@ def test_packed_step_replays_with_other_lengths(tiny, task):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("packed_side", ["q", "k"])
-def test_attention_varlen_cross_matches_per_pair_attention(packed_side):
+@pytest.mark.parametrize("packed_side,with_pair", [("q", False), ("k", False), ("q", True), ("k", True)])
+def test_attention_varlen_cross_matches_per_pair_attention(packed_side, with_pair):
     """hamt_attn_varlen_cross_fwd / _bwd -- ONE side packed back to back, the other at a fixed stride with an additive key mask --
-    against fp64 attention of each (query sequence, key sequence) pair: outputs, lse, dq / dk / dv; the filler query sequences behind
-    `n_pairs` give zero outputs and zero dq, and touch no dk / dv."""
+    against fp64 attention of each (query sequence, key sequence) pair: outputs, lse, dq / dk / dv; the filler query sequences (behind
+    `n_pairs`, or named -1 by a `pair` map that also permutes who attends to whom) give zero outputs and zero dq, and touch no dk / dv."""
     import ctypes as C
     from vln_hamt_amd import _lib as L, ops
     heads, H, Sf = 2, 128, 11                    # fixed-stride side: 11 rows per sample, the last rows masked for some samples
-    lens = [5, 37, 1, 80, 16]                    # packed side
-    fill = [30, 7] if packed_side == "q" else [9]   # filler sequences behind the real ones (bucketed row count)
-    n = len(lens)
-    Sp = max(lens + fill)
-    cu = torch.tensor([0] + list(np.cumsum(lens + fill)), dtype=torch.int32, device=DEV)
+    n = 5
+    if with_pair:     # packed sequences in this order; -1 = a filler; the numbers = the fixed-stride sample each one belongs to
+        owner = [2, -1, 0, 4, -1, 1, 3] if packed_side == "q" else [3, -1, 0, 2, 4, -1, 1]
+        plens = [5, 30, 37, 1, 7, 80, 16] if packed_side == "q" else [16, 9, 5, 80, 1, 0, 37]
+    else:
+        owner = [0, 1, 2, 3, 4] + ([-1, -1] if packed_side == "q" else [-1])
+        plens = [5, 37, 1, 80, 16] + ([30, 7] if packed_side == "q" else [9])
+    Sp = max(plens)
+    cu = torch.tensor([0] + list(np.cumsum(plens)), dtype=torch.int32, device=DEV)
     Mp, Mf = int(cu[-1]), n * Sf
     g = torch.Generator(device=DEV).manual_seed(9)
     valid_f = [11, 4, 11, 7, 1]
@@ -1451,49 +1455,57 @@ def test_attention_varlen_cross_matches_per_pair_attention(packed_side):
     for b, m in enumerate(valid_f):
         mask[b, m:] = -10000.0
     lib, p, rng = L.load(), ops._p, ops.rng_state(torch.device(DEV))
+    seq_of = {o: i for i, o in enumerate(owner) if o >= 0}         # fixed-stride sample -> its packed sequence
     if packed_side == "q":
         q = torch.randn(Mp, H, device=DEV, generator=g).to(torch.bfloat16)
         kv = torch.randn(Mf, 2 * H, device=DEV, generator=g).to(torch.bfloat16)
-        nseq, Sq, Sk, cu_q, cu_k, am = n + len(fill), Sp, Sf, cu, None, mask
+        nseq, Sq, Sk, cu_q, cu_k, am = len(plens), Sp, Sf, cu, None, mask
+        pair = torch.tensor(owner, dtype=torch.int32, device=DEV) if with_pair else None
     else:
         q = torch.randn(Mf, H, device=DEV, generator=g).to(torch.bfloat16)
         kv = torch.randn(Mp, 2 * H, device=DEV, generator=g).to(torch.bfloat16)
         nseq, Sq, Sk, cu_q, cu_k, am = n, Sf, Sp, None, cu, None
+        pair = torch.tensor([seq_of[b] for b in range(n)], dtype=torch.int32, device=DEV) if with_pair else None
     Mq = q.shape[0]
     do = torch.randn(Mq, H, device=DEV, generator=g).to(torch.bfloat16)
     d = L.AttnDesc(nseq, heads, Sq, Sk, 64, H, 2 * H, 2 * H, H, L.HAMT_BF16, L.HAMT_BF16, 0.125, 0.0, 13, L.PREC_BF16)
     o = torch.full((Mq, H), float("nan"), device=DEV, dtype=torch.bfloat16)
     lse = torch.full((nseq * heads * Sq,), float("nan"), device=DEV)
-    L.check(lib.hamt_attn_varlen_cross_fwd(C.byref(d), p(q), p(kv[:, :H]), p(kv[:, H:]), p(cu_q), p(cu_k), n, p(am), p(o), p(lse), p(rng),
+    L.check(lib.hamt_attn_varlen_cross_fwd(C.byref(d), p(q), p(kv[:, :H]), p(kv[:, H:]), p(cu_q), p(cu_k), n, p(pair), p(am), p(o), p(lse), p(rng),
                                            ops._stream()), "hamt_attn_varlen_cross_fwd")
     dq = torch.full((Mq, H), float("nan"), device=DEV, dtype=torch.bfloat16)
     dkv = torch.full_like(kv, 7.0)                                 # (rows no sample owns must stay untouched)
-    L.check(lib.hamt_attn_varlen_cross_bwd(C.byref(d), p(q), p(kv[:, :H]), p(kv[:, H:]), p(cu_q), p(cu_k), n, p(am), p(o), p(do), p(lse),
+    L.check(lib.hamt_attn_varlen_cross_bwd(C.byref(d), p(q), p(kv[:, :H]), p(kv[:, H:]), p(cu_q), p(cu_k), n, p(pair), p(am), p(o), p(do), p(lse),
                                            p(dq), p(dkv[:, :H]), p(dkv[:, H:]), p(rng), ops._stream()), "hamt_attn_varlen_cross_bwd")
     torch.cuda.synchronize()
     assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(dq).all())
     hv = lambda t, m: t.float().view(m, heads, 64).transpose(0, 1).double()
-    for b in range(n):
+    for b in range(n):             # b = the fixed-stride sample, sq = its packed sequence
+        sq = seq_of[b]
         if packed_side == "q":
-            q0, nq, k0, nk, add = int(cu[b]), lens[b], b * Sf, Sf, mask[b].double()
+            qi, q0, nq, k0, nk, add = sq, int(cu[sq]), plens[sq], b * Sf, Sf, mask[b].double()
         else:
-            q0, nq, k0, nk, add = b * Sf, Sf, int(cu[b]), lens[b], torch.zeros(lens[b], device=DEV, dtype=torch.float64)
+            qi, q0, nq, k0, nk, add = b, b * Sf, Sf, int(cu[sq]), plens[sq], torch.zeros(plens[sq], device=DEV, dtype=torch.float64)
         qq = hv(q[q0:q0 + nq], nq).requires_grad_()
         kk = hv(kv[k0:k0 + nk, :H], nk).requires_grad_()
         vv = hv(kv[k0:k0 + nk, H:], nk).requires_grad_()
         sc = qq @ kk.transpose(-1, -2) * 0.125 + add
         out = torch.softmax(sc, -1) @ vv
         out.backward(hv(do[q0:q0 + nq], nq))
-        close(o[q0:q0 + nq].float(), out.transpose(0, 1).reshape(nq, H), 1e-2, f"cross varlen ({packed_side}) output pair {b}")
-        close(lse.view(nseq, heads, Sq)[b, :, :nq], torch.logsumexp(sc, -1), 1e-3, f"cross varlen ({packed_side}) lse pair {b}")
-        close(dq[q0:q0 + nq].float(), qq.grad.transpose(0, 1).reshape(nq, H), 2e-2, f"cross varlen ({packed_side}) dq pair {b}")
-        close(dkv[k0:k0 + nk, :H].float(), kk.grad.transpose(0, 1).reshape(nk, H), 2e-2, f"cross varlen ({packed_side}) dk pair {b}")
-        close(dkv[k0:k0 + nk, H:].float(), vv.grad.transpose(0, 1).reshape(nk, H), 2e-2, f"cross varlen ({packed_side}) dv pair {b}")
-    r_end = int(cu[n])
-    if packed_side == "q":      # the filler query sequences: zeros out, zero dq
-        assert float(o[r_end:].float().abs().max()) == 0.0 and float(dq[r_end:].float().abs().max()) == 0.0
-    else:                       # the filler key rows: not written
-        assert bool((dkv[r_end:] == 7.0).all())
+        tag = f"cross varlen ({packed_side}, pair map {with_pair})"
+        close(o[q0:q0 + nq].float(), out.transpose(0, 1).reshape(nq, H), 1e-2, f"{tag} output pair {b}")
+        close(lse.view(nseq, heads, Sq)[qi, :, :nq], torch.logsumexp(sc, -1), 1e-3, f"{tag} lse pair {b}")
+        close(dq[q0:q0 + nq].float(), qq.grad.transpose(0, 1).reshape(nq, H), 2e-2, f"{tag} dq pair {b}")
+        close(dkv[k0:k0 + nk, :H].float(), kk.grad.transpose(0, 1).reshape(nk, H), 2e-2, f"{tag} dk pair {b}")
+        close(dkv[k0:k0 + nk, H:].float(), vv.grad.transpose(0, 1).reshape(nk, H), 2e-2, f"{tag} dv pair {b}")
+    for i, ow in enumerate(owner):
+        if ow >= 0 or plens[i] == 0:
+            continue
+        r0, r1 = int(cu[i]), int(cu[i + 1])
+        if packed_side == "q":      # a filler query sequence: zeros out, zero dq
+            assert float(o[r0:r1].float().abs().max()) == 0.0 and float(dq[r0:r1].float().abs().max()) == 0.0
+        else:                       # filler key rows: not written
+            assert bool((dkv[r0:r1] == 7.0).all())
 
 
 # ------------------------------------------------------------------------------------------- two ranks on one GPU

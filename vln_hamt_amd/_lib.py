@@ -79,8 +79,8 @@ SIGNATURES = {
     "hamt_attn_small_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_attn_varlen_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_attn_varlen_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "hamt_attn_varlen_cross_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp],
-    "hamt_attn_varlen_cross_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_attn_varlen_cross_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp],
+    "hamt_attn_varlen_cross_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_gemm_ln_fwd": [C.POINTER(GemmLnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

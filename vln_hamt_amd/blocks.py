@@ -261,10 +261,11 @@ class KvProjFn(torch.autograd.Function):
 class CrossAttnBlockFn(torch.autograd.Function):
     """`seq_q` / `seq_k` (at most one; SelfAttnBlockFn's `seq` = (cu_seqlens, sequences, S_max)): the queries x [M, H], or the context
     behind kv16, are a PACKED batch (the instruction tokens of a ragged batch in the x-layers) -- hamt_attn_varlen_cross_*.  `pairs` =
-    the number of samples (= the fixed-stride side's batch): packed query sequences behind it are fillers without keys."""
+    the number of samples (= the fixed-stride side's batch): packed query sequences behind it are fillers without keys.  `pair` (int32
+    device tensor, optional) names each query sequence's key side instead (hamt.h: packed copies of a batch, fillers between them)."""
 
     @staticmethod
-    def forward(ctx, x, kv16, Sk, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wo, bo, gamma, beta, seq_q=None, seq_k=None, pairs=0):
+    def forward(ctx, x, kv16, Sk, add_mask, heads, p_attn, p_hidden, eps, wq, bq, wo, bo, gamma, beta, seq_q=None, seq_k=None, pairs=0, pair=None):
         if seq_q is not None:
             cu, B, Sq = seq_q
             Mq, H = x.shape
@@ -273,7 +274,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
             B, Sq, H = x.shape
             Mq, Mk = B * Sq, B * Sk
             if seq_k is not None:
-                assert add_mask is None and pairs == B
+                assert add_mask is None and (pairs == B or pair is not None)
                 Sk = seq_k[2]
                 Mk = -1                  # (a packed context: its row count is kv16's business)
         dev = x.device
@@ -292,7 +293,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         cu_q = seq_q[0] if seq_q is not None else None
         cu_k = seq_k[0] if seq_k is not None else None
         if cu_q is not None or cu_k is not None:
-            L.check(L.load().hamt_attn_varlen_cross_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(cu_q), _p(cu_k), pairs,
+            L.check(L.load().hamt_attn_varlen_cross_fwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(cu_q), _p(cu_k), pairs, _p(pair),
                                                         _p(mask2), _p(ctx16), _p(lse), _p(rng_state(dev)), _stream()),
                     "hamt_attn_varlen_cross_fwd")
         else:
@@ -304,7 +305,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma)
         ctx.ln_params = (gamma, beta, bo)
         ctx.meta = (B, Sq, Sk, H, heads, float(p_attn), float(p_hidden), float(eps), cid, cid_ln, Mq, Mk, pairs)
-        ctx.cu_q, ctx.cu_k = cu_q, cu_k
+        ctx.cu_q, ctx.cu_k, ctx.pair = cu_q, cu_k, pair
         ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)     # else autograd zero-fills a bf16 [Mp,H] "gradient" of y16 per backward
         return y.view(x.shape), y16
@@ -312,7 +313,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _unused=None):
         if dy is None:
-            return (None,) * 17
+            return (None,) * 18
         x16, q16, kv16, ctx16, lse, mask2, z, mean, rstd, wq, bq, wo, bo, gamma = ctx.saved_tensors
         B, Sq, Sk, H, heads, p_attn, p_hidden, eps, cid, cid_ln, Mq, Mk, pairs = ctx.meta
         Mqp, Mkp = x16.shape[0], kv16.shape[0]
@@ -327,7 +328,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
         if ctx.cu_q is not None or ctx.cu_k is not None:
             # packed keys: the filler rows behind the last real sequence belong to no sample -- nobody writes their dK / dV
             dkv16 = torch.zeros(Mkp, 2 * H, dtype=torch.bfloat16, device=dev) if ctx.cu_k is not None else _zeros_or_empty(Mkp, Mk, 2 * H, dev)
-            L.check(L.load().hamt_attn_varlen_cross_bwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(ctx.cu_q), _p(ctx.cu_k), pairs,
+            L.check(L.load().hamt_attn_varlen_cross_bwd(C.byref(d), _p(q16), _p(kv16[:, :H]), _p(kv16[:, H:]), _p(ctx.cu_q), _p(ctx.cu_k), pairs, _p(ctx.pair),
                                                         _p(mask2), _p(ctx16), _p(dctx16), _p(lse), _p(dq16), _p(dkv16[:, :H]), _p(dkv16[:, H:]),
                                                         _p(rng_state(dev)), _stream()), "hamt_attn_varlen_cross_bwd")
         else:
@@ -337,7 +338,7 @@ class CrossAttnBlockFn(torch.autograd.Function):
                     "hamt_attn_small_bwd")
         dx, dwqs, dbqs = _proj_bwd(dq16, Mq, x16, (wq,), (bq,), dx_accum_into=dz)
         return (dx.view(dy.shape), dkv16 if ctx.needs_input_grad[1] else None, None, None, None, None, None, None,
-                dwqs[0], dbqs[0], dwo, dbo, dgamma, dbeta, None, None, None)
+                dwqs[0], dbqs[0], dwo, dbo, dgamma, dbeta, None, None, None, None)
 
 
 class XBidirBlockFn(torch.autograd.Function):
@@ -527,6 +528,8 @@ def self_attn_block(x, add_mask, att_self, att_out, training):
     y = _tag(y, y16)
     if seq is not None:
         y._hamt_seq = seq
+        if getattr(x, "_hamt_pair", None) is not None:
+            y._hamt_pair = x._hamt_pair
     return y
 
 
@@ -540,13 +543,18 @@ def cross_attn_block(x, c, add_mask, att, att_out, training):
         kv16 = KvProjFn.apply(c, att.key.weight, att.key.bias, att.value.weight, att.value.bias)
     seq_q, seq_k = getattr(x, "_hamt_seq", None), getattr(c, "_hamt_seq", None)     # one side packed: see CrossAttnBlockFn
     pairs = c.shape[0] if seq_q is not None else (x.shape[0] if seq_k is not None else 0)
+    # packed COPIES of a batch (forward_itm): (key sample of each packed sequence, packed sequence of each fixed-stride sample)
+    pm = getattr(x if seq_q is not None else c, "_hamt_pair", None) if (seq_q is not None or seq_k is not None) else None
+    pair = None if pm is None else (pm[0] if seq_q is not None else pm[1])
     y, y16 = CrossAttnBlockFn.apply(x, kv16, seq_k[2] if seq_k is not None else c.shape[1], None if seq_k is not None else add_mask,
                                     att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
                                     att.query.weight, att.query.bias, att_out.dense.weight, att_out.dense.bias,
-                                    att_out.LayerNorm.weight, att_out.LayerNorm.bias, seq_q, seq_k, pairs)
+                                    att_out.LayerNorm.weight, att_out.LayerNorm.bias, seq_q, seq_k, pairs, pair)
     y = _tag(y, y16)
     if seq_q is not None:
         y._hamt_seq = seq_q
+        if pm is not None:
+            y._hamt_pair = pm
     return y
 
 
@@ -558,4 +566,6 @@ def ffn_block(x, inter, out, training):
     seq = getattr(x, "_hamt_seq", None)
     if seq is not None:
         y._hamt_seq = seq
+        if getattr(x, "_hamt_pair", None) is not None:
+            y._hamt_pair = x._hamt_pair
     return y

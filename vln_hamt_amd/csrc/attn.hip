@@ -332,10 +332,10 @@ int check_desc(const hamt_attn_desc* d, const char* who) {
 
 void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
                             float* lse, const uint64_t* rng, hipStream_t s, const int* cu_q = nullptr, const int* cu_k = nullptr,
-                            int n_pairs = 0);
+                            int n_pairs = 0, const int* pair = nullptr);
 void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
                             const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s,
-                            const int* cu_q = nullptr, const int* cu_k = nullptr, int n_pairs = 0);
+                            const int* cu_q = nullptr, const int* cu_k = nullptr, int n_pairs = 0, const int* pair = nullptr);
 
 // Packed ("varlen") self-attention: the B sequences lie back to back, sample b owns rows [cu[b], cu[b + 1]) of q / k / v / o (every
 // one of its keys is real: no mask), at most d->Sq = d->Sk <= 128 rows each; lse is [B, heads, d->Sq].  What BertSelfAttention
@@ -373,33 +373,35 @@ extern "C" int hamt_attn_varlen_bwd(const hamt_attn_desc* d, const void* q, cons
 // the visual stream keeps its fixed stride): cu_q != NULL: query sequence b = rows [cu_q[b], cu_q[b + 1]) of q / o / d_o / dq, its keys
 // rows [b * Sk, (b + 1) * Sk) of k / v under add_mask [B, Sk]; query sequences b >= n_pairs (fillers of a bucketed row count) have
 // no keys: zero output / zero dq.  cu_k != NULL: queries at fixed stride Sq, sample b's keys = rows [cu_k[b], cu_k[b + 1]), all real.
-static int check_varlen_cross(const hamt_attn_desc* d, const int* cu_q, const int* cu_k, int n_pairs, const char* who) {
+// `pair` (optional, [B] on the device) replaces "b pairs with b": the key sample (cu_q form) or the entry of cu_k (cu_k form) of query
+// sequence b, negative = a filler -- packed copies of a batch whose fillers lie between the copies (ITM's replicated text).
+static int check_varlen_cross(const hamt_attn_desc* d, const int* cu_q, const int* cu_k, int n_pairs, const int* pair, const char* who) {
   int rc = check_desc(d, who);
   if (rc) return rc;
   HAMT_CHECK_ARG((cu_q != nullptr) != (cu_k != nullptr), "%s: exactly one of cu_q / cu_k must be given", who);
   HAMT_CHECK_ARG(d->prec == HAMT_PREC_BF16 && d->Sq <= 128 && d->Sk <= 128, "%s: packed attention is built for the bf16 path, <= 128 tokens per sequence (Sq %d, Sk %d)", who, d->Sq, d->Sk);
-  HAMT_CHECK_ARG(n_pairs >= 0 && n_pairs <= d->B && (cu_k == nullptr || n_pairs == d->B), "%s: n_pairs = %d outside [0, B = %d] (packed keys: every query sample has keys)", who, n_pairs, d->B);
+  HAMT_CHECK_ARG(pair != nullptr || (n_pairs >= 0 && n_pairs <= d->B && (cu_k == nullptr || n_pairs == d->B)), "%s: n_pairs = %d outside [0, B = %d] (packed keys: every query sample has keys)", who, n_pairs, d->B);
   return HAMT_OK;
 }
 extern "C" int hamt_attn_varlen_cross_fwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
-                                          const int* cu_k, int n_pairs, const float* add_mask, void* o, float* lse,
+                                          const int* cu_k, int n_pairs, const int* pair, const float* add_mask, void* o, float* lse,
                                           const uint64_t* rng, void* stream) {
-  int rc = check_varlen_cross(d, cu_q, cu_k, n_pairs, "hamt_attn_varlen_cross_fwd");
+  int rc = check_varlen_cross(d, cu_q, cu_k, n_pairs, pair, "hamt_attn_varlen_cross_fwd");
   if (rc) return rc;
   HAMT_CHECK_ARG(q && k && v && o && lse, "hamt_attn_varlen_cross_fwd: null pointer");
   if (d->B == 0) return HAMT_OK;
-  hamt_attn16_fwd_launch(d, q, k, v, cu_k ? nullptr : add_mask, o, lse, rng, as_stream(stream), cu_q, cu_k, n_pairs);
+  hamt_attn16_fwd_launch(d, q, k, v, cu_k ? nullptr : add_mask, o, lse, rng, as_stream(stream), cu_q, cu_k, n_pairs, pair);
   HAMT_CHECK_LAUNCH("hamt_attn_varlen_cross_fwd");
   return HAMT_OK;
 }
 extern "C" int hamt_attn_varlen_cross_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
-                                          const int* cu_k, int n_pairs, const float* add_mask, const void* o, const void* d_o,
+                                          const int* cu_k, int n_pairs, const int* pair, const float* add_mask, const void* o, const void* d_o,
                                           const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, void* stream) {
-  int rc = check_varlen_cross(d, cu_q, cu_k, n_pairs, "hamt_attn_varlen_cross_bwd");
+  int rc = check_varlen_cross(d, cu_q, cu_k, n_pairs, pair, "hamt_attn_varlen_cross_bwd");
   if (rc) return rc;
   HAMT_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv, "hamt_attn_varlen_cross_bwd: null pointer");
   if (d->B == 0) return HAMT_OK;
-  hamt_attn16_bwd_launch(d, q, k, v, cu_k ? nullptr : add_mask, o, d_o, lse, dq, dk, dv, rng, as_stream(stream), cu_q, cu_k, n_pairs);
+  hamt_attn16_bwd_launch(d, q, k, v, cu_k ? nullptr : add_mask, o, d_o, lse, dq, dk, dv, rng, as_stream(stream), cu_q, cu_k, n_pairs, pair);
   HAMT_CHECK_LAUNCH("hamt_attn_varlen_cross_bwd");
   return HAMT_OK;
 }

@@ -37,6 +37,8 @@ struct Attn16Args {
   const int* cu_q;
   const int* cu_k;
   int n_pairs;
+  const int* pair;   // optional [B]: the key-side index of query sequence b (the key sample at a fixed stride, or the entry of cu_k), < 0 = a
+                     // filler; nullptr: b itself, fillers = the sequences behind n_pairs
 };
 
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&f)[8]);
@@ -456,8 +458,13 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
   size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
   if (a.cu_q) { const int c0 = a.cu_q[b]; Sq = a.cu_q[b + 1] - c0; qrow0 = (size_t)c0; }
   if (Sq <= 0) return;                                 // (whole workgroup: an empty slot of a bucketed batch)
-  if (a.cu_k) { const int c0 = a.cu_k[b]; Sk = a.cu_k[b + 1] - c0; krow0 = (size_t)c0; }
-  if (((a.cu_q || a.cu_k) && b >= a.n_pairs) || Sk <= 0) {   // a filler query sequence (or an empty key sequence): no keys -> zero output rows, lse 0
+  const int kb_ = a.pair ? a.pair[b] : b;              // the key side of this query sequence
+  const bool filler = a.pair ? kb_ < 0 : ((a.cu_q || a.cu_k) && b >= a.n_pairs);
+  if (!filler) {
+    krow0 = (size_t)kb_ * d.Sk;
+    if (a.cu_k) { const int c0 = a.cu_k[kb_]; Sk = a.cu_k[kb_ + 1] - c0; krow0 = (size_t)c0; }
+  }
+  if (filler || Sk <= 0) {   // a filler query sequence (or an empty key sequence): no keys -> zero output rows, lse 0
     TO* O0 = (TO*)a.out + qrow0 * d.ldo + h * 64;
     for (int i = t; i < Sq * 8; i += nt) st4<TO>(O0 + (size_t)(i >> 3) * d.ldo + (i & 7) * 8, 0.f, 0.f, 0.f, 0.f), st4<TO>(O0 + (size_t)(i >> 3) * d.ldo + (i & 7) * 8 + 4, 0.f, 0.f, 0.f, 0.f);
     for (int i = t; i < Sq; i += nt) a.lse[((size_t)b * d.heads + h) * d.Sq + i] = 0.f;
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(512) void attn_s128_fwd_kernel(Attn16Args a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s)   // clamped, not branched (rows >= Sq are never stored)
     qf[s] = gfrag<TI>(Q + (size_t)(qok ? qrow : Sq - 1) * d.ldq + 32 * s + 8 * g);
-  stage_mask(a.cu_k ? nullptr : a.mask, b, Sk, SKP, mk_s, t, nt);
+  stage_mask(a.cu_k ? nullptr : a.mask, kb_, Sk, SKP, mk_s, t, nt);
   rows_store<TI, IT>(rk, SKP, Ks, t, nt);
   rows_store<TI, IT>(rv, SKP, Vs, t, nt);
   __syncthreads();
@@ -544,8 +551,13 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
   size_t qrow0 = (size_t)b * d.Sq, krow0 = (size_t)b * d.Sk;
   if (a.cu_q) { const int c0 = a.cu_q[b]; Sq = a.cu_q[b + 1] - c0; qrow0 = (size_t)c0; }
   if (Sq <= 0) return;
-  if (a.cu_k) { const int c0 = a.cu_k[b]; Sk = a.cu_k[b + 1] - c0; krow0 = (size_t)c0; }
-  if (((a.cu_q || a.cu_k) && b >= a.n_pairs) || Sk <= 0) {   // a filler query sequence: zero query gradients, no keys to give gradients to
+  const int kb_ = a.pair ? a.pair[b] : b;              // the key side of this query sequence
+  const bool filler = a.pair ? kb_ < 0 : ((a.cu_q || a.cu_k) && b >= a.n_pairs);
+  if (!filler) {
+    krow0 = (size_t)kb_ * d.Sk;
+    if (a.cu_k) { const int c0 = a.cu_k[kb_]; Sk = a.cu_k[kb_ + 1] - c0; krow0 = (size_t)c0; }
+  }
+  if (filler || Sk <= 0) {   // a filler query sequence: zero query gradients, no keys to give gradients to
     TI* dQ0 = (TI*)a.dq + qrow0 * d.ldq + h * 64;
     for (int i = t; i < Sq * 8; i += nt) { st4<TI>(dQ0 + (size_t)(i >> 3) * d.ldq + (i & 7) * 8, 0.f, 0.f, 0.f, 0.f); st4<TI>(dQ0 + (size_t)(i >> 3) * d.ldq + (i & 7) * 8 + 4, 0.f, 0.f, 0.f, 0.f); }
     return;
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(512) void attn_s128_bwd_kernel(Attn16Args a) {
     rows_load<TO, 2>(O, d.ldo, Sq, t, nt, ro);
     rows_load<TI, 2>(K, d.ldk, Sk, t, nt, rk);
     rows_load<TI, 2>(V, d.ldv, Sk, t, nt, rv);
-    stage_mask(a.cu_k ? nullptr : a.mask, b, Sk, sk16, mk_s, t, nt);
+    stage_mask(a.cu_k ? nullptr : a.mask, kb_, Sk, sk16, mk_s, t, nt);
     for (int i = t; i < sk16 * PST / 8; i += nt) { ((uint4*)Pt)[i] = make_uint4(0, 0, 0, 0); ((uint4*)dSt)[i] = make_uint4(0, 0, 0, 0); }
     rows_store<TI, 2>(rq, sq16, Qs, t, nt);
     rows_store<TO, 2>(rdo, sq16, dOs, t, nt);
@@ -941,8 +953,8 @@ bool use_wide_bwd(const hamt_attn_desc* d) {     // 129 .. 224 tokens on a side 
 }  // namespace
 
 void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, void* o,
-                            float* lse, const uint64_t* rng, hipStream_t s, const int* cu_q, const int* cu_k, int n_pairs) {
-  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng, cu_q, cu_k, n_pairs};
+                            float* lse, const uint64_t* rng, hipStream_t s, const int* cu_q, const int* cu_k, int n_pairs, const int* pair) {
+  Attn16Args a{*d, q, k, v, nullptr, nullptr, mask, o, nullptr, nullptr, nullptr, lse, rng, cu_q, cu_k, n_pairs, pair};
   const int* cu = cu_q ? cu_q : cu_k;
   dim3 grid((d->Sq + T64 - 1) / T64, d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;
@@ -961,8 +973,8 @@ void hamt_attn16_fwd_launch(const hamt_attn_desc* d, const void* q, const void* 
 
 void hamt_attn16_bwd_launch(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const float* mask, const void* o,
                             const void* d_o, const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, hipStream_t s,
-                            const int* cu_q, const int* cu_k, int n_pairs) {
-  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng, cu_q, cu_k, n_pairs};
+                            const int* cu_q, const int* cu_k, int n_pairs, const int* pair) {
+  Attn16Args a{*d, q, k, v, o, d_o, mask, nullptr, dq, dk, dv, const_cast<float*>(lse), rng, cu_q, cu_k, n_pairs, pair};
   const int* cu = cu_q ? cu_q : cu_k;
   dim3 grid(d->heads, d->B), block(256);
   const bool ib = d->dtype_qkv == HAMT_BF16, ob = d->dtype_o == HAMT_BF16;

@@ -647,8 +647,25 @@ class NavPreTrainedModel(BertPreTrainedModel):
         txt_m1 = self._extend(txt_masks)
         hist_m = self._extend(hist_masks)
 
+        cls_rows = [None]
+
         def text_side():
-            txt = self._text(txt_ids, txt_m1)
+            txt = self._text(txt_ids, txt_m1, keep_packed=True)
+            if txt.dim() == 2:
+                # PACKED text [Mb, H] (a ragged batch): n_rep copies back to back, each with the plan's sequences -- real ones and
+                # fillers -- so the fillers lie BETWEEN the copies: the cross attentions get the pairing explicitly (`_hamt_pair`:
+                # packed sequence r n + j <-> candidate sample r B + j for j < B, no keys for the fillers); everything else is row-wise.
+                # Only the [CLS] row of each real sequence is read behind the last layer.
+                cu, n, _ = txt._hamt_seq
+                Mb, H = txt.shape
+                r = torch.arange(n_rep, device=dev, dtype=torch.int32)[:, None]
+                j = torch.arange(n, device=dev, dtype=torch.int32)[None]
+                rep = txt[None].expand(n_rep, Mb, H).reshape(n_rep * Mb, H)      # (broadcast: the backward sums the copies in a fixed order)
+                rep._hamt_seq = (torch.cat([(cu[:-1][None] + r * Mb).reshape(-1), cu[-1:] + (n_rep - 1) * Mb]), n_rep * n, txt._hamt_seq[2])
+                rep._hamt_pair = (torch.where(j < B, r * B + j, torch.full_like(j, -1)).reshape(-1).contiguous(),
+                                  (r * n + j[:, :B]).reshape(-1).contiguous())
+                cls_rows[0] = (cu[:B][None] + r * Mb).reshape(-1).long()
+                return rep, txt_m1.repeat(n_rep, 1, 1, 1)
             L, H = txt.shape[1:]
             # n_rep copies by broadcast: the backward is a sum over the copies in a fixed order (a gather of repeated row indices
             # would scatter-add them with atomics in whatever order they land)
@@ -706,5 +723,6 @@ class NavPreTrainedModel(BertPreTrainedModel):
         H = txt.shape[-1]
         for layer in self.encoder.x_layers:
             txt, vis = layer(txt, txt_m, vis, vis_m)
-        fused = ops.mul_bcast(txt[:, :1].contiguous(), vis[:, 0])        # txt[:,0] * hist[:,0]
+        cls = ops.gather_rows(txt, cls_rows[0]).view(n_rep * B, 1, H) if cls_rows[0] is not None else txt[:, :1].contiguous()
+        fused = ops.mul_bcast(cls, vis[:, 0])                            # txt[:,0] * hist[:,0]
         return fused.view(n_rep, B, H).transpose(0, 1)                   # == stack(split(fused, B), 1)
