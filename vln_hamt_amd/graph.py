@@ -14,7 +14,7 @@ import time
 
 import torch
 
-from . import ops
+from . import ops, streams
 
 
 class GraphedTrainStep:
@@ -55,7 +55,8 @@ class GraphedTrainStep:
         # HAMT_MAIN_PRIORITY=1 (measurement switch): the capture stream -- the text-side critical path -- at high priority, so that
         # the second compute stream's kernels only take what it leaves.  Measured: 16.4 ms per B = 64 step instead of 9.9 (a
         # non-default priority on EITHER stream costs 60 %: the two streams no longer overlap) -- off
-        self.stream = torch.cuda.Stream(priority=-1) if os.environ.get("HAMT_MAIN_PRIORITY") == "1" else torch.cuda.Stream()
+        # (one capture stream per process: see streams.role_stream -- it must never coincide with the second compute stream or an update stream)
+        self.stream = streams.role_stream(torch.cuda.current_device(), "capture", -1 if os.environ.get("HAMT_MAIN_PRIORITY") == "1" else None)
         # (the warm-up step before each capture runs on that stream while the parameters' AccumulateGrad nodes may date
         # from an earlier pass on the caller's stream: intended, and synchronised by wait_stream on both sides)
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -263,7 +264,7 @@ class GraphedInference:
         self.fn = fn
         self.graphs = {}
         self.pool = None
-        self.stream = torch.cuda.Stream()
+        self.stream = streams.role_stream(torch.cuda.current_device(), "capture")
 
     @torch.no_grad()
     def __call__(self, key, *tensors):

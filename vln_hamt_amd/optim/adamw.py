@@ -48,7 +48,8 @@ class _Overlap:
 
     def __init__(self, opt, model, chunk_elems):
         self.opt, self.model = opt, model
-        self.stream = torch.cuda.Stream(device=opt._flat_p.device)
+        from .. import streams
+        self.stream = streams.role_stream(opt._flat_p.device, "update")      # (one stream per role and process: streams.role_stream)
         # chunk 0: the fp32-read region (biases, LayerNorm, embedding tables: the first kernels of a forward pass read those);
         # then the GEMM-weight region in arena (= registration = use) order, cut at parameter boundaries
         n_a, n = opt._n_shadow_only, opt._n

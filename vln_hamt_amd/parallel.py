@@ -184,8 +184,10 @@ class OverlappedGradSync:
     def __init__(self, optimizer, n_groups: int = 4, wire: str = "fp32"):
         from . import wgrad
         self.opt, self.n_groups, self.wire = optimizer, n_groups, wire
-        self.comm = torch.cuda.Stream()
-        self.lanes = [torch.cuda.Stream() for _ in range(int(os.environ.get("HAMT_SYNC_LANES", 2)))]
+        from . import streams
+        dev = optimizer._flat_p.device if getattr(optimizer, "_flat_p", None) is not None else torch.cuda.current_device()
+        self.comm = streams.role_stream(dev, "comm")      # (one stream per role and process: streams.role_stream)
+        self.lanes = [streams.role_stream(dev, f"lane{i}") for i in range(int(os.environ.get("HAMT_SYNC_LANES", 2)))]
         self.alternate = os.environ.get("HAMT_SYNC_ONE_LANE") is None
         self._stage_cache: dict = {}        # this object's bf16 wire mirrors (no module-level state)
         self.mode = "eager"                # "eager": run at flush; "plan": only build the plan (graph capture)

@@ -26,13 +26,36 @@ def set_two_stream(flag: bool):
     _ENABLED[0] = bool(flag)
 
 
+_roles: dict = {}
+
+
+def role_stream(device, role: str, priority=None) -> torch.cuda.Stream:
+    """THE stream of a role ("side", "capture", "update", "comm", "lane0", ...) on `device`: created once per process and DISTINCT from
+    the stream of every other role.  torch.cuda.Stream() hands out a pool of 32 HIP streams per priority round-robin, so a process
+    that builds many short-lived owners (a test suite: one capture stream per GraphedTrainStep, one update stream per attached
+    optimizer) would sooner or later give two roles of one training step the SAME HIP stream -- e.g. the capture stream and the
+    second compute stream -- and the fork / join events between them become self-dependencies inside a capture (seen as a
+    segmentation fault in hipGraph instantiation, depending on how many streams the process had created before)."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    s = _roles.get((dev, role))
+    if s is None:
+        taken = {st.cuda_stream for (d_, _), st in _roles.items() if d_ == dev}
+        for _ in range(64):
+            s = torch.cuda.Stream(device=dev, priority=int(priority)) if priority is not None else torch.cuda.Stream(device=dev)
+            if s.cuda_stream not in taken:
+                break
+        else:
+            raise RuntimeError(f"no free HIP stream for role {role!r} on device {dev}")
+        _roles[(dev, role)] = s
+    return s
+
+
 def side_stream(device) -> torch.cuda.Stream:
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     s = _side.get(key)
     if s is None:
         # HAMT_SIDE_PRIORITY = -1 / 0: measurement switch (default stream priority otherwise)
-        pr = os.environ.get("HAMT_SIDE_PRIORITY")
-        s = _side[key] = torch.cuda.Stream(device=key, priority=int(pr)) if pr is not None else torch.cuda.Stream(device=key)
+        s = _side[key] = role_stream(key, "side", os.environ.get("HAMT_SIDE_PRIORITY"))
     return s
 
 
