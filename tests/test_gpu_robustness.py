@@ -380,3 +380,19 @@ def test_two_rank_bench_with_probes_finishes(tmp_path, sharded):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["state_finite_after_timed_region"] is True, line[:600]
+
+
+def test_role_streams_are_pairwise_distinct():
+    """streams.role_stream: one HIP stream per role, whatever else the process creates in between -- torch.cuda.Stream() cycles through a
+    pool of 32, and two roles of one captured step on the same HIP stream ended in a segmentation fault inside hipGraph instantiation
+    (first seen when the GPU suite had created enough streams for the capture stream to come round to the second compute stream)."""
+    from vln_hamt_amd import streams
+    seen = {}
+    for role in ["side", "capture", "update", "comm", "lane0", "lane1", "test_a", "test_b", "test_c"]:
+        for _ in range(13):
+            torch.cuda.Stream()                     # move torch's round-robin index (13 is coprime to 32: every slot comes up)
+        s = streams.role_stream(torch.cuda.current_device(), role)
+        assert streams.role_stream(torch.cuda.current_device(), role) is s
+        seen[role] = s.cuda_stream
+    assert len(set(seen.values())) == len(seen), seen
+    assert streams.side_stream(torch.cuda.current_device()).cuda_stream == seen["side"]
