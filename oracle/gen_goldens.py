@@ -12,6 +12,8 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
   canon_pretrain.npz  R2R-canon full config (B=2, L=80, T=5): per-task logits/losses + probes
   canon_multi.npz     R2R-canon over two more weight seeds and at per-GPU batch 16: losses, trunk probes, gradient norms / probes,
                       single-candidate-logit gradients for ITM
+  canon_multi_sar.npz the SAR gradient of the canon_multi draws term by term (single regression outputs)
+  canon_ragged.npz    R2R-canon on RAGGED batches (L ~ U[20, 80], T ~ U[0, 7], B = 16): what the packed text path is compared with
   optim_tiny.npz      3 steps of clip(5.0) + reference AdamW + warmup schedule on the tiny model
   tiny_finetune.npz   NavCMT language / history / visual modes (incl. no_lang_ca)
   vit.npz             ViT backbone features / gradients from the reference's VisionTransformer class
@@ -586,6 +588,100 @@ def gen_canon_multi():
     print("canon_multi.npz:", len(store), "arrays")
 
 
+def gen_canon_multi_sar():
+    """SAR on the CANON_MULTI draws, term by term: the loss gradient is sum_{b,k} (2 r_bk / 3B) d pred_bk, a sum over samples and the
+    three regression outputs whose residuals r have both signs -- on one B = 16 draw it cancels far enough that bf16 rounding of the
+    TERMS shows in the cosine of the SUM.  Stored: the reference's predictions, targets and the gradients of the three single-output
+    means d(mean_b pred[b, k]) (65-point probes + norms), which tests/ gate like every other gradient."""
+    torch.set_num_threads(8)
+    store = {"meta/cases": np.asarray(CANON_MULTI)}
+    cfg = OracleConfig()
+    models = {}
+    for ci, (wseed, bseed, B) in enumerate(CANON_MULTI):
+        if wseed not in models:
+            models[wseed] = build_ref_pretrain(cfg, make_state_dict(pretrain_param_shapes(cfg), seed=wseed))
+        model, vil = models[wseed]
+        batch = make_batch("sar", B, cfg, seed=bseed + 2, txt_len=80, hist_len=5)       # (gen_canon_multi: seed = bseed + task index)
+        pre = f"c{ci}/sar/"
+        for k in range(3):
+            model.zero_grad(set_to_none=True)
+            pred = model(batch, "sar", False)
+            store[pre + "logits"] = pred.detach().numpy()
+            (pred[:, k].sum() / pred.shape[0]).backward()
+            store.update(grads_packed_n(model.named_parameters(), pre + f"out{k}/", MULTI_PROBE))
+        store[pre + "targets"] = torch.cat([batch["ob_action_angles"], batch["ob_progress"].unsqueeze(1)], 1).numpy()
+        model.zero_grad(set_to_none=True)
+        print(f"  [canon multi sar terms c{ci} w{wseed} B{B}]", flush=True)
+    np.savez_compressed(os.path.join(OUT, "canon_multi_sar.npz"), **store)
+    print("canon_multi_sar.npz:", len(store), "arrays")
+
+
+# ------------------------------------------------------------------------------------------------ ragged batches (the packed text path)
+# (weight seed, batch seed, per-GPU batch): SURVEY 8d's ragged variant -- L ~ U[20, 80], T ~ U[0, 7] -- at the reference's per-GPU batch.
+# make_batch(ragged=True) also emits the text packing plan (txt_pack_idx / txt_cu / txt_unpack_idx); the reference ignores those keys,
+# the HIP model under test consumes them, so tests/ compare the PACKED computation with the reference directly.
+CANON_RAGGED = [(2024, 1100, 16), (7, 1300, 16)]
+RAGGED_L, RAGGED_T = 80, 7
+
+
+def gen_canon_ragged():
+    """R2R-canon on ragged batches: per task the loss, the text embeddings (every 24th channel of every token + the per-token norms; tests
+    compare them at the REAL positions), history / observation probes, per-parameter gradient norms + 65-point probes from the REFERENCE's
+    forward and autograd, the ITM draws made inside forward_itm and the gradients of single candidate logits."""
+    torch.set_num_threads(8)
+    store = {"meta/cases": np.asarray(CANON_RAGGED), "meta/txt_len": np.array(RAGGED_L), "meta/hist_len": np.array(RAGGED_T)}
+    cfg = OracleConfig()
+    for ci, (wseed, bseed, B) in enumerate(CANON_RAGGED):
+        sd = make_state_dict(pretrain_param_shapes(cfg), seed=wseed)
+        model, vil = build_ref_pretrain(cfg, sd)
+        for i, task in enumerate(("mlm", "sap", "sar", "sprel", "mrc", "itm")):
+            batch = make_batch(task, B if task != "itm" else 2 * B, cfg, seed=bseed + i, txt_len=RAGGED_L, hist_len=RAGGED_T, ragged=True)
+            assert "txt_pack_idx" in batch, "this draw has (almost) no padding: pick another seed"
+            pre = f"c{ci}/{task}/"
+            store[pre + "txt_lens"] = batch["txt_masks"].sum(1).numpy()
+            store[pre + "hist_lens"] = (batch["hist_masks"].sum(1) - 1).numpy()
+            with torch.no_grad():
+                if task == "itm":
+                    np.random.seed(4400 + ci)
+                    torch.manual_seed(4400 + ci)
+                    with RngRecorder(vil) as rec:
+                        loss = model(batch, task, True)
+                    store.update(to_np(itm_rng_from_record(rec, batch), pre + "rng/"))
+                else:
+                    loss = model(batch, task, True)
+                    g = lambda k: batch.get(k)
+                    t, h, o = model.bert(g("txt_ids"), g("txt_masks"), g("hist_img_fts"), g("hist_ang_fts"), g("hist_pano_img_fts"),
+                                         g("hist_pano_ang_fts"), g("hist_masks"), g("ob_img_fts"), g("ob_ang_fts"), g("ob_nav_types"), g("ob_masks"))
+                    store[pre + "txt_sel"] = t[:, :, ::24].numpy().copy()
+                    store[pre + "txt_norm"] = t.norm(dim=-1).numpy()
+                    store[pre + "hist_sel"] = h[:, :, ::4].numpy().copy()
+                    if o is not None:
+                        store[pre + "ob_probe"] = o[:, :, :16].numpy().copy()
+            store[pre + "loss"] = loss.numpy()
+            model.zero_grad(set_to_none=True)
+            if task == "itm":
+                np.random.seed(4400 + ci)
+                torch.manual_seed(4400 + ci)
+            model(batch, task, True).mean().backward()
+            store.update(grads_packed_n(model.named_parameters(), pre, MULTI_PROBE))
+            if task == "itm":
+                for k in (0, 3):
+                    model.zero_grad(set_to_none=True)
+                    np.random.seed(4400 + ci)
+                    torch.manual_seed(4400 + ci)
+                    lg = model(batch, task, False)
+                    lg = lg[0] if isinstance(lg, tuple) else lg
+                    store[pre + "logits"] = lg.detach().numpy()
+                    (lg[:, k].sum() / lg.shape[0]).backward()
+                    store.update(grads_packed_n(model.named_parameters(), pre + f"logit{k}/", MULTI_PROBE))
+            model.zero_grad(set_to_none=True)
+            print(f"  [canon ragged c{ci} w{wseed} B{B} {task}] loss {loss.mean().item():.4f}  text rows {int(batch['txt_masks'].sum())} of "
+                  f"{batch['txt_masks'].numel()} (packed {batch['txt_pack_idx'].numel()})", flush=True)
+        del model
+    np.savez_compressed(os.path.join(OUT, "canon_ragged.npz"), **store)
+    print("canon_ragged.npz:", len(store), "arrays")
+
+
 # ------------------------------------------------------------------------------------------------ N4: readers + loaders
 R2R_TINY = os.path.join(OUT, "r2r_tiny")
 R2R_DIMS = dict(image_feat_size=16, image_prob_size=10, angle_feat_size=4)
@@ -779,7 +875,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi", "canon_multi_sar", "canon_ragged"]
     for w in which:
         {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
-         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi}[w]()
+         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi, "canon_ragged": gen_canon_ragged, "canon_multi_sar": gen_canon_multi_sar}[w]()

@@ -906,14 +906,17 @@ def test_losses():
     ref.backward(gw.double())
     close(xg.grad, xr.grad, 1e-5, "ce bwd")
     assert float(loss[7]) == 0.0 and float(xg.grad[7].abs().max()) == 0.0
-    # any other label outside [0, C) is an ignored row too (never an out-of-bounds read)
+    # any other NEGATIVE label is an ignored row too; a label >= C (a corrupted input: torch raises on it) gives a NaN loss and a NaN
+    # gradient row -- detectable, never an out-of-bounds read, never a silent zero
     lab2 = lab.clone(); lab2[3], lab2[4] = -1, Cc
     xg2 = buf[:, :Cc].detach().requires_grad_(True)
     loss2 = ops.cross_entropy(xg2, lab2.to(DEV))
     loss2.backward(gw.to(DEV))
-    assert float(loss2[3]) == 0.0 and float(loss2[4]) == 0.0 and float(xg2.grad[3:5].abs().max()) == 0.0
+    assert float(loss2[3]) == 0.0 and float(xg2.grad[3].abs().max()) == 0.0
+    assert math.isnan(float(loss2[4])) and bool(torch.isnan(xg2.grad[4]).all())
     keep = [i for i in range(R) if i not in (3, 4)]
     close(loss2[keep], ref.detach()[keep], 1e-5, "ce with ignored rows")
+    assert bool(torch.isfinite(xg2.grad[keep]).all())
     a, t = rnd(7, 36, 2, seed=4), rnd(7, 36, 2, seed=5)
     ag = a.to(DEV).requires_grad_(True)
     l2 = ops.mse_loss(ag, t.to(DEV))

@@ -39,10 +39,14 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int C, const float* __restr
   const int r = blockIdx.x;
   const float* xr = x + (size_t)r * ldx;
   const float l = row_lse(xr, C, red);
-  if (threadIdx.x == 0) {      // a label outside [0, C) is an ignored row (F.cross_entropy's ignore_index = -100, pretrain_cmt.py:181): loss 0
+  if (threadIdx.x == 0) {
+    // a NEGATIVE label is an ignored row (F.cross_entropy's ignore_index = -100; the reference's -1 "no label" never reaches a loss,
+    // r2r_tasks.py:46 + pretrain_cmt.py:161-165): loss 0, zero gradient.  A label >= C is a corrupted input -- torch raises on it;
+    // a kernel cannot, so the row's loss and gradient are NaN (never an out-of-bounds read, never a silent zero): the step's
+    // loss goes NaN where a debugger can see it instead of training on.
     const int64_t lab = label[r];
     lse[r] = l;
-    loss[r] = (lab >= 0 && lab < C) ? l - xr[lab] : 0.f;
+    loss[r] = lab < 0 ? 0.f : (lab < C ? l - xr[lab] : __builtin_nanf(""));
   }
 }
 __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, const float* __restrict__ x, int ldx, const int64_t* __restrict__ label,
@@ -53,9 +57,10 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, const float* __restr
   float* dr = dx + (size_t)r * lddx;
   const float l = lse[r], gr = g[r];
   const int64_t lab64 = label[r];
-  const bool ignored = lab64 < 0 || lab64 >= C;      // (an ignored row: zero gradient)
+  const bool ignored = lab64 < 0;                    // (an ignored row: zero gradient)
+  const float bad = lab64 >= C ? __builtin_nanf("") : 0.f;      // (a label behind the last class: NaN, see ce_fwd_kernel)
   const int lab = (int)lab64;
-  for (int c = threadIdx.x; c < C; c += 256) dr[c] = ignored ? 0.f : gr * (expf(xr[c] - l) - (c == lab ? 1.0f : 0.0f));
+  for (int c = threadIdx.x; c < C; c += 256) dr[c] = ignored ? 0.f : gr * (expf(xr[c] - l) - (c == lab ? 1.0f : 0.0f)) + bad;
 }
 __global__ void mse_fwd_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ loss) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

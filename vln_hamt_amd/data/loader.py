@@ -118,7 +118,11 @@ class PrefetchLoader:
         self.loader = loader
         self.text_pack = text_pack
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        # (one HIP stream per role and process, distinct from the capture / side / update / exchange streams: streams.role_stream)
+        self.stream = None
+        if self.device.type == "cuda":
+            from .. import streams
+            self.stream = streams.role_stream(self.device, "h2d")
 
     def __iter__(self):
         loader_it = iter(self.loader)

@@ -307,6 +307,7 @@ XBIDIR = os.environ.get("HAMT_XBIDIR") == "1"
 # HAMT_NO_X_PACK=1: a packed text stream (ragged batches, NavPreTrainedModel._text) is scattered back to [B, L, H] BEFORE the
 # cross-modal layers instead of behind them (measurement switch)
 X_PACK = os.environ.get("HAMT_NO_X_PACK") != "1"
+PACK_MAX_LEN = 128      # longest sequence hamt_attn_varlen_* / hamt_attn_varlen_cross_* serve (include/hamt.h)
 
 
 class LXRTXLayer(nn.Module):
@@ -434,6 +435,11 @@ class LxmertEncoder(nn.Module):
         else:
             vis = torch.cat([hist_embeds, img_embeds], 1)
             vis_masks = torch.cat([extended_hist_masks, extended_img_masks], -1)
+        if unpack is not None and vis.size(1) > PACK_MAX_LEN:
+            # more visual tokens than the packed cross attention holds per sample (candidate views on top of the panorama): back to the
+            # padded layout in front of the cross-modal layers
+            txt_embeds = ops.gather_rows(txt_embeds, unpack[0]).view(unpack[1], unpack[2], -1)
+            unpack = None
         for layer in self.x_layers:
             txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks)
         if unpack is not None:
@@ -577,7 +583,9 @@ class NavPreTrainedModel(BertPreTrainedModel):
         keys and nothing reads what they produce as queries (the reference computes them and throws them away)."""
         pack = getattr(txt_ids, "_hamt_pack", None)
         H = self.config.hidden_size      # (no parameter is touched here: optim.AdamW.attach's read gates sit in the child modules)
-        if pack is None or not (blocks.ENABLED and precision_of(self.config) == "bf16" and txt_ids.is_cuda and H % 64 == 0):
+        # (the packed attention kernels hold one sequence per workgroup: instructions of up to 128 tokens -- R2R's 80; RxR pretraining
+        # pads to 250, config/pretrain_rxr.json: such batches take the padded kernels, which serve up to 256 keys)
+        if pack is None or txt_ids.shape[1] > PACK_MAX_LEN or not (blocks.ENABLED and precision_of(self.config) == "bf16" and txt_ids.is_cuda and H % 64 == 0):
             return self.encoder.text_layers(self.embeddings(txt_ids), txt_m)
         pack_idx, cu, unpack_idx = pack
         B, L = txt_ids.shape

@@ -190,6 +190,7 @@ class OverlappedGradSync:
         self.lanes = [streams.role_stream(dev, f"lane{i}") for i in range(int(os.environ.get("HAMT_SYNC_LANES", 2)))]
         self.alternate = os.environ.get("HAMT_SYNC_ONE_LANE") is None
         self._stage_cache: dict = {}        # this object's bf16 wire mirrors (no module-level state)
+        self._ar_ranges = None             # static all-reduce ranges (see _static_ranges)
         self.mode = "eager"                # "eager": run at flush; "plan": only build the plan (graph capture)
         self.plan = None
         self.done = False
@@ -232,17 +233,43 @@ class OverlappedGradSync:
         else:
             wgrad.launch_group(plan, g)
 
-    def run(self, plan):
-        """Launch the plan's groups with the arena all-reduces on the communication stream.  Consecutive groups go to two
+    def _static_ranges(self):
+        """The arena ranges of the all-reduce exchange: a function of the arena layout only (`shard_cuts` with world = 1), like the
+        sharded exchange's.  A plan's own range bounds follow the step's launch-group cuts, i.e. whatever parameters THIS rank
+        queued -- collectives sized by them would not match between ranks."""
+        if self._ar_ranges is None:
+            o = self.opt.materialize()
+            cuts = shard_cuts(o._n, o._n_shadow_only, 1, int(os.environ.get("HAMT_SHARD_PARTS", 4)))
+            self._ar_ranges = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
+        return self._ar_ranges
+
+    def _exchange(self, lo, hi, plan, first):
+        """one static range on the communication stream (the caller has made it wait for the range's producers)"""
+        if self.log is not None:
+            self.log.append((lo, hi))
+        allreduce_mean_(self.opt._flat_g[lo:hi], wire=self.wire, stage_cache=self._stage_cache)
+
+    log = None      # tests: a list that receives the (lo, hi) of every range exchange in issue order
+
+    def run(self, plan, sumsq=False):
+        """Launch the plan's groups with the arena exchanges on the communication stream.  Consecutive groups go to two
         alternating compute streams: group g+1's tiles fill the CUs that group g's last round leaves idle (a quarter of
         the tiles per launch is ~1.5 rounds of the chip: run back to back the four launches cost 40 % more than one),
-        while range g's all-reduce still starts as soon as group g itself has finished."""
-        from . import wgrad
-        flat = self.opt._flat_g
-        main = torch.cuda.current_stream()
-        pending = sorted(plan.ranges, key=lambda r: r[2])
-        k = 0
+        while a range's exchange still starts as soon as every group that writes into it has finished.
 
+        The SEQUENCE of collectives is rank-invariant by construction: the static ranges (arena layout and world size only) in
+        arena order, every step, whatever the task, the batch shape or the parameters this rank happened to queue.  The plan
+        (rank-local: its launch groups follow what was queued) only decides which events a range's exchange waits for and after
+        which launch the host enqueues it -- a range is enqueued once its predecessors in arena order are and every group that
+        touches it has been launched.  (ordering the ranges by the plan's `after` let two ranks with different
+        padded row counts reduce-scatter different ranges against each other.)"""
+        from . import wgrad
+        main = torch.cuda.current_stream()
+        rng = getattr(plan, "_static_rng", None)
+        if rng is None or rng[0] is not self:
+            rng = plan._static_rng = (self, range_finality(self._static_ranges(), plan.ranges))
+        pending = rng[1]                   # arena order
+        k = 0
         done = []
 
         def reduce_ready(after):
@@ -255,7 +282,7 @@ class OverlappedGradSync:
                 else:
                     self.comm.wait_stream(main)
                 with torch.cuda.stream(self.comm):
-                    allreduce_mean_(flat[lo:hi], wire=self.wire, stage_cache=self._stage_cache)
+                    self._exchange(lo, hi, plan, (k == 0) if sumsq else None)
                 k += 1
 
         reduce_ready(-1)
@@ -381,6 +408,7 @@ class ShardedGradSync(OverlappedGradSync):
         self._own32 = torch.empty(o._n // self.world + 8, dtype=torch.float32, device=o._flat_g.device)
         self._gsq = torch.zeros(1, dtype=torch.float32, device=o._flat_g.device)
         self._upd = None                   # (norm graph, update graph, max_norm) once graph.GraphedTrainStep captured them
+        self._unconsumed = False           # an exchange has run and update() has not consumed it yet
 
     def close(self):
         super().close()
@@ -462,56 +490,39 @@ class ShardedGradSync(OverlappedGradSync):
             L.check(L.load().hamt_sumsq_table(f, c, _p(o._flat_g[f:f + c]), _p(o._ends), _p(o._hyp), len(o._params), _p(self._gsq), int(not sumsq),
                                               _p(o._ws), _stream()), "hamt_sumsq_table")
 
+    def _static_ranges(self):
+        return self._ranges
+
+    def _exchange(self, lo, hi, plan, first):
+        """(parent.run) first: None = no norm share; True / False = this is / is not the step's first range (see _exchange_range)"""
+        if self.log is not None:
+            self.log.append((lo, hi))
+        self._exchange_range(lo, hi, plan, first)
+
+    def _once_per_update(self):
+        """The sharded exchange runs ONCE per optimizer step: afterwards a range holds the rank mean in the owned chunk only (zeros, or
+        with the direct bf16 wire stale local values, elsewhere), so a second micro-batch's gradients (gradient_accumulation_steps >
+        1, main_r2r.py:244-251) would be added to, and exchanged on top of, something that is no longer this rank's local sum.  The
+        reference's R2R / RxR configurations accumulate over 1 step (pretrain_r2r.json:11); anything else must accumulate locally
+        and exchange on the last micro-batch -- refuse rather than drop gradients silently.  One rank is exempt: its
+        owned chunk is the whole range, so accumulation is exact there."""
+        if self._unconsumed and self.world > 1:
+            from ._lib import HamtError
+            raise HamtError("ShardedGradSync: a second gradient exchange before update() consumed the first (gradient accumulation over "
+                            "several backward passes): not supported by the sharded exchange -- accumulate locally with the exchange "
+                            "detached and attach it for the last micro-batch, or use OverlappedGradSync (HAMT_SHARDED=0)")
+        self._unconsumed = True
+
     def run(self, plan, sumsq=False):
-        """The plan's groups with the reduce-scatters on the communication stream (same overlap structure as the parent).
-        sumsq: also reduce each range's owned chunk into the global squared norm as it arrives (see _exchange_range); `update`
-        is then called with have_sumsq=True."""
-        from . import wgrad
-        main = torch.cuda.current_stream()
-        n_done = [0]
-        rng = getattr(plan, "_shard_rng", None)
-        if rng is None:
-            rng = plan._shard_rng = range_finality(self._ranges, plan.ranges)
-        pending = sorted(rng, key=lambda r: r[2])
-        k, done = 0, []
-
-        def reduce_ready(after):
-            nonlocal k
-            while k < len(pending) and pending[k][2] <= after:
-                lo, hi, _, touched = pending[k]
-                if touched:
-                    for g in touched:
-                        self.comm.wait_event(done[g])
-                else:
-                    self.comm.wait_stream(main)
-                with torch.cuda.stream(self.comm):
-                    self._exchange_range(lo, hi, plan, (n_done[0] == 0) if sumsq else None)
-                n_done[0] += 1
-                k += 1
-
-        reduce_ready(-1)
-        lanes = self.lanes if self.alternate else [main]
-        for ln in lanes:
-            if ln is not main:
-                ln.wait_stream(main)
-        for g in range(len(plan.groups)):
-            ln = lanes[g % len(lanes)]
-            for d in plan.deps[g]:
-                ln.wait_event(done[d])
-            with torch.cuda.stream(ln):
-                self._launch_group(plan, g)
-            done.append(ln.record_event())
-            reduce_ready(g)
-        for ln in lanes:
-            if ln is not main:
-                main.wait_stream(ln)
-        main.wait_stream(self.comm)
+        self._once_per_update()
+        super().run(plan, sumsq)
 
     def __call__(self, optimizer):
         if self.done:
             self.done = False
             return
         # no queued GEMM gradients in this pass (fp32 mode / nothing deferred): exchange the arena range by range, same ownership
+        self._once_per_update()
         if not optimizer._packed:
             optimizer._pack_grads()
         for lo, hi in self._ranges:
@@ -589,6 +600,7 @@ class ShardedGradSync(OverlappedGradSync):
         if o._n > n_a:                                                # bf16 images of the >= 2-D fp32-read parameters (tied MLM decoder ...)
             L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
         o.mark_updated()
+        self._unconsumed = False
         o._shard_stale = self.world > 1
 
     @torch.no_grad()

@@ -422,7 +422,10 @@ def _build_plan(items, optimizer, n_groups, wire):
             return None
         probs.append((ow, ob, w, b, dy16, x16))
     probs.sort(key=lambda t: t[0])
-    flops = [2.0 * t[2].shape[0] * t[2].shape[1] * t[4].shape[0] for t in probs]
+    # cut weights: the parameters' sizes, NOT the operands' row counts -- those differ between the ranks of a data-parallel job
+    # (per-batch padding to the local longest instruction, the packed text's row bucket), and the launch groups decide when an
+    # arena range may be exchanged: the cuts must be the same on every rank that queued the same parameters
+    flops = [float(t[2].numel()) for t in probs]
     total, acc, cuts, gi = sum(flops), 0.0, [], 0
     group_of = []
     for f in flops:                         # equal-work cuts in arena order
