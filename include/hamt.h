@@ -419,6 +419,24 @@ int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, v
 /* rng[1] += 1 on the stream (new dropout epoch; call once per optimisation step) */
 int hamt_rng_advance(uint64_t* rng, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Running a captured step's parallel branches on separate streams (the reference has no counterpart: torch eager launches,
+ * main_r2r.py:237-281; here a whole step is a captured hipGraph, graph.py).  Measured on MI355X / ROCm 7.0: ONE replayed graph runs
+ * two independent chains of small kernels at 0.34x the rate of the same chains as two graphs on two streams (tools/
+ * graph_branch_probe.py) -- so the captured graph (a hipGraph_t) is cut into its maximal linear chains, each chain becomes a graph of
+ * its own on one of n_streams streams, and cross-chain dependencies become events.
+ *   hamt_graph_split:          hip_graph = hipGraph_t (kernel / memcpy / memset / empty nodes); it must outlive the handle.
+ *   hamt_graph_split_launch:   streams[0] = the caller's stream (the others wait for it first, it waits for them last: the call is
+ *                              stream-ordered on streams[0] like hipGraphLaunch); the streams must be pairwise distinct.
+ *   hamt_graph_split_info:     node / segment / cross-stream-dependency counts, nodes per stream.
+ *   hamt_graph_split_segments: per segment {stream, nodes, dependencies} into triples[3 * cap]; returns the number of segments. */
+typedef struct hamt_graph_exec hamt_graph_exec;
+int hamt_graph_split(void* hip_graph, int n_streams, hamt_graph_exec** out);
+int hamt_graph_split_launch(hamt_graph_exec* x, void* const* streams, int n_streams);
+int hamt_graph_split_info(const hamt_graph_exec* x, int* n_nodes, int* n_segments, int* n_cross, int* stream_nodes, int n_streams);
+int hamt_graph_split_segments(const hamt_graph_exec* x, int* triples, int cap);
+int hamt_graph_split_destroy(hamt_graph_exec* x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1763,7 +1763,9 @@ def _two_rank_batch(t, r, cfg, shapes):
 
 def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False, long_run=False):
     """One data-parallel rank (gloo carries the collectives of CUDA tensors, so two ranks can share the box's single
-    GPU): the product's multi-GPU step on this rank's own batches."""
+    GPU): the product's multi-GPU step on this rank's own batches.  use_graph == "wrapped": the reference's OWN loop lines
+    (main_r2r.py:150-156, 237-281) around `wrap_model` -- no exchange call, no optimizer argument to clip_grad_norm_, a plain
+    optimizer.step()."""
     import torch.distributed as dist
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
@@ -1784,6 +1786,47 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
     seq, shapes, hyp = _two_rank_schedule(long_run)
     o = AdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
                {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], betas=(0.9, 0.98), **hyp)
+    wrapped = use_graph == "wrapped"
+    if wrapped:
+        from vln_hamt_amd.utils.misc import wrap_model
+        os.environ["HAMT_SHARDED"] = "1" if sharded else "0"
+        os.environ["HAMT_GRAD_WIRE"] = wire
+        os.environ["HAMT_SYNC_GROUPS"] = "3"
+        if rank == 1:
+            with torch.no_grad():
+                for p_ in m.parameters():      # rank 1 starts from other weights: wrap_model must bring rank 0's (DDP's broadcast at wrap)
+                    p_.add_(0.01)
+        model = wrap_model(m, torch.device("cuda", 0), 0)
+        assert model is not m and model.module is m
+        named = list(model.named_parameters())      # (main_r2r.py builds the optimizer from the WRAPPED model: names gain `module.`)
+        o = AdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+                   {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], betas=(0.9, 0.98), **hyp)
+        o.zero_grad()
+        o.step()                                     # main_r2r.py:229-230
+        batches = {t: _two_rank_batch(t, rank, cfg, shapes) for t in set(seq)}
+        try:
+            for t in seq:
+                loss = model(batches[t], task=t, compute_loss=True)
+                loss = loss.mean()
+                loss.backward()
+                clip_grad_norm_(model.parameters(), 5.0)
+                o.step()
+                o.zero_grad()
+            sync = model.grad_sync
+            assert sync is not None and bool(getattr(sync, "sharded", False)) == bool(sharded), sync
+            torch.cuda.synchronize()
+            if sharded:
+                torch.save(o._flat_p16.detach().cpu(), os.path.join(out_dir, f"shadow{rank}.pt"))
+                torch.save(o._flat_p[o._n_shadow_only:].detach().cpu(), os.path.join(out_dir, f"fp32read{rank}.pt"))
+                sync.gather_state()
+            torch.cuda.synchronize()
+            torch.save([], os.path.join(out_dir, f"exchanges{rank}.pt"))
+            torch.save(o._flat_p.detach().cpu(), os.path.join(out_dir, f"params{rank}.pt"))
+            torch.save((o._flat_m.detach().cpu(), o._flat_v.detach().cpu()), os.path.join(out_dir, f"moments{rank}.pt"))
+        finally:
+            model.close()
+            dist.destroy_process_group()
+        return
     o.materialize()
     broadcast_params(o)
     sync = (ShardedGradSync if sharded else OverlappedGradSync)(o, n_groups=3, wire=wire)
@@ -1888,7 +1931,9 @@ def test_exchange_schedule_is_independent_of_the_batch(sharded):
 @pytest.mark.parametrize("wire,use_graph,sharded,long_run", [("fp32", False, False, False), ("fp32", True, False, False), ("bf16", False, False, False),
                                                              ("fp32", False, True, False), ("fp32", True, True, False), ("bf16", True, True, False),
                                                              ("fp32", True, True, True), ("fp32", False, True, True), ("bf16", True, True, True),
-                                                             ("fp32", True, False, True), ("bf16", True, False, True)])
+                                                             ("fp32", True, False, True), ("bf16", True, False, True),
+                                                             ("fp32", "wrapped", False, False), ("fp32", "wrapped", True, False),
+                                                             ("bf16", "wrapped", True, True), ("bf16", "wrapped", False, True)])
 def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph, sharded, long_run):
     """world_size = 2 for real: two processes, different batches, the product's overlapped exchange (gloo moves the
     CUDA tensors) -- against one process that computes both ranks' gradients on the same weights, averages them,
@@ -1912,7 +1957,7 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     p0, p1 = torch.load(os.path.join(str(tmp_path), "params0.pt")), torch.load(os.path.join(str(tmp_path), "params1.pt"))
     assert torch.equal(p0, p1), "ranks diverged"
     x0, x1 = torch.load(os.path.join(str(tmp_path), "exchanges0.pt")), torch.load(os.path.join(str(tmp_path), "exchanges1.pt"))
-    assert len(x0) > 0 and x0 == x1, "the ranks issued different sequences of range exchanges"
+    assert (len(x0) > 0 or use_graph == "wrapped") and x0 == x1, "the ranks issued different sequences of range exchanges"
     if sharded:
         for name in ("shadow", "fp32read"):
             a, b_ = torch.load(os.path.join(str(tmp_path), f"{name}0.pt")), torch.load(os.path.join(str(tmp_path), f"{name}1.pt"))

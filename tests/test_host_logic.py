@@ -68,3 +68,46 @@ def test_wgrad_queue_bookkeeping_cpu():
         q.reset()
     finally:
         W._flush_pass = orig
+
+
+def test_interleaved_issue_of_chains(monkeypatch):
+    """streams.interleave: the chains' units are issued alternately, the chain with the least accumulated cost first, every
+    unit under its own chain's stream, results in chain order; HAMT_INTERLEAVE=0 issues one chain after the other."""
+    import contextlib
+    from vln_hamt_amd import streams
+    entered = []
+    monkeypatch.setattr(torch.cuda, "stream", lambda st: (entered.append(st), contextlib.nullcontext())[1])
+    order = []
+
+    def chain(name, costs):
+        for c in costs:
+            order.append(name)
+            yield c
+        return name.upper()
+
+    monkeypatch.setattr(streams, "INTERLEAVE", True)
+    res = streams.interleave([("s1", chain("v", [10, 10, 10])), ("s0", chain("t", [5, 5, 5, 5, 5, 5]))])
+    assert res == ["V", "T"]
+    assert "".join(order) == "vttvttvtt", order           # v (tie, first), then t until it has caught up, ...
+    assert set(entered) == {"s0", "s1"}
+    order.clear()
+    monkeypatch.setattr(streams, "INTERLEAVE", False)
+    assert streams.interleave([("s1", chain("v", [1, 1])), ("s0", chain("t", [1, 1, 1]))]) == ["V", "T"]
+    assert "".join(order) == "vvttt"
+    assert streams.drive(chain("x", [])) == "X"
+
+
+def test_range_finality_and_static_cuts():
+    """parallel.range_finality maps a step's plan (rank-local) onto the STATIC ranges: a static range is final after the last
+    launch group that writes into any plan range overlapping it; the static ranges themselves depend on the layout only."""
+    from vln_hamt_amd.parallel import range_finality, shard_cuts
+    cuts = shard_cuts(4096 * 3, 4096 * 2, 2, parts=4)
+    assert cuts == sorted(set(cuts)) and cuts[0] == 0 and cuts[-1] == 4096 * 3 and 4096 * 2 in cuts
+    static = list(zip(cuts[:-1], cuts[1:]))
+    plan_a = [(0, 3000, 0, frozenset({0})), (3000, 9000, 2, frozenset({1, 2})), (9000, 4096 * 3, 3, frozenset({0, 1, 2, 3}))]
+    plan_b = [(0, 5000, 1, frozenset({0, 1})), (5000, 4096 * 3, 3, frozenset({2, 3}))]      # another rank: other cuts, other groups
+    fa, fb = range_finality(static, plan_a), range_finality(static, plan_b)
+    assert [(lo, hi) for lo, hi, _, _ in fa] == [(lo, hi) for lo, hi, _, _ in fb] == static
+    assert fa[0][2] == 0 and fa[-1][2] == 3 and fb[0][2] == 1
+    for lo, hi, after, touched in fa:
+        assert after == max(touched)

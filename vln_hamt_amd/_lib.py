@@ -127,6 +127,11 @@ SIGNATURES = {
     "hamt_adamw_table_range": [sz, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
     "hamt_clip_scale": [sz, vp, vp, f32, vp],
     "hamt_rng_advance": [vp, vp],
+    "hamt_graph_split": [vp, i32, C.POINTER(vp)],
+    "hamt_graph_split_launch": [vp, C.POINTER(vp), i32],
+    "hamt_graph_split_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32],
+    "hamt_graph_split_segments": [vp, C.POINTER(i32), i32],
+    "hamt_graph_split_destroy": [vp],
 }
 
 _lib = None

@@ -17,6 +17,70 @@ import torch
 from . import ops, streams
 
 
+# HAMT_GRAPH_SPLIT=0: replay the captured graph as ONE hipGraph (torch's CUDAGraph.replay) instead of chain by chain on separate streams
+SPLIT = os.environ.get("HAMT_GRAPH_SPLIT", "1") != "0"
+SPLIT_STREAMS = int(os.environ.get("HAMT_GRAPH_SPLIT_STREAMS", 2))
+
+
+class SplitGraph:
+    """A captured torch.cuda.CUDAGraph(keep_graph=True) replayed chain by chain: `hamt_graph_split` (csrc/graph_split.hip) cuts the
+    captured hipGraph into its maximal linear chains, instantiates each as a graph of its own and launches them on separate streams
+    with events for the dependencies that cross -- inside one replayed graph this runtime runs parallel branches one after the
+    other (and slower than a single chain), see tools/graph_branch_probe.py.  `replay()` is stream-ordered on torch's current stream
+    like CUDAGraph.replay().  The torch graph object stays alive (it owns the captured graph and the memory pool)."""
+
+    def __init__(self, torch_graph, n_streams: int = None):
+        import ctypes as C
+        from . import _lib as L
+        self.g = torch_graph
+        self.n = int(n_streams or SPLIT_STREAMS)
+        h = C.c_void_p()
+        L.check(L.load().hamt_graph_split(C.c_void_p(torch_graph.raw_cuda_graph()), self.n, C.byref(h)), "hamt_graph_split")
+        self.h = h
+        dev = torch.cuda.current_device()
+        self.branch = [streams.role_stream(dev, f"gbranch{i}") for i in range(1, self.n)]
+        self._arr = (C.c_void_p * self.n)()
+
+    def info(self):
+        import ctypes as C
+        from . import _lib as L
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        per = (C.c_int * self.n)()
+        L.check(L.load().hamt_graph_split_info(self.h, C.byref(a), C.byref(b), C.byref(c), per, self.n), "hamt_graph_split_info")
+        return {"nodes": a.value, "segments": b.value, "cross_stream_deps": c.value, "nodes_per_stream": list(per)}
+
+    def replay(self):
+        from . import _lib as L
+        cur = torch.cuda.current_stream()
+        self._arr[0] = cur.cuda_stream
+        for i, st in enumerate(self.branch):
+            if st.cuda_stream == cur.cuda_stream:
+                raise L.HamtError("SplitGraph.replay: the current stream is one of the split's branch streams")
+            self._arr[i + 1] = st.cuda_stream
+        L.check(L.load().hamt_graph_split_launch(self.h, self._arr, self.n), "hamt_graph_split_launch")
+
+    def __del__(self):
+        try:
+            from . import _lib as L
+            if getattr(self, "h", None):
+                L.load().hamt_graph_split_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _new_graph():
+    return torch.cuda.CUDAGraph(keep_graph=True) if SPLIT else torch.cuda.CUDAGraph()
+
+
+def _finish_graph(g):
+    """what to replay for a captured graph: the chain-by-chain split, or the graph itself"""
+    if not SPLIT:
+        return g
+    sg = SplitGraph(g)
+    return sg
+
+
 class GraphedTrainStep:
     """`grad_sync` (multi-GPU): a callable run between backward and the optimizer, e.g. parallel.allreduce_grads.  The
     step is then captured as TWO graphs -- forward/backward/packing per (task, shape) key, and one shared
@@ -142,7 +206,7 @@ class GraphedTrainStep:
             time.sleep(0.5)
         ops.invalidate_weight_caches()
         self.opt.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
+        g = _new_graph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         overl = getattr(self.grad_sync, "overlapped", False)
@@ -192,7 +256,7 @@ class GraphedTrainStep:
         self.opt._packed = False
         for p in self.opt._params:             # the captured gradient buffers stay alive inside the graph's pool
             p.grad = None
-        self.graphs[key] = (g, loss_c, active, plan, batch)
+        self.graphs[key] = (_finish_graph(g), loss_c, active, plan, batch)
         return loss
 
     @staticmethod
@@ -277,12 +341,12 @@ class GraphedInference:
                 self.fn(*static)                      # warm-up on the capture stream (allocator, lazy caches)
             cur.wait_stream(self.stream)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             if self.pool is None:
                 self.pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
                 out = self.fn(*static)
-            ent = self.graphs[key] = (g, static, out)
+            ent = self.graphs[key] = (_finish_graph(g), static, out)
         g, static, out = ent
         for s_, t in zip(static, tensors):
             if torch.is_tensor(t):

@@ -468,6 +468,14 @@ class AdamW(Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        sync = self._sharded_sync
+        if sync is not None and sync._unconsumed:
+            # the gradients of this step were reduce-scattered (parallel.ShardedGradSync, e.g. under parallel.ArenaDataParallel): the
+            # update is the owned-slice AdamW + the parameter all-gathers; the clip -- if clip_grad_norm_ ran -- is fused into it
+            self._ensure_table()
+            max_norm = self._pending_clip[1] if self._pending_clip is not None else 0.0
+            sync.update(max_norm, norm_reduced=sync._norm_reduced)
+            return loss
         if not self._packed:
             self._pack_grads()
         self._ensure_table()
@@ -555,7 +563,22 @@ def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, optimiz
     no host sync).  With `optimizer` (our AdamW) the scaling min(1, max_norm/(norm+1e-6)) is fused into the
     next ``optimizer.step()``; without it the gradients are scaled in place."""
     lib = L.load()
+    if optimizer is None:
+        # the reference's call has no optimizer argument (main_r2r.py:271-273): parameters that live in an AdamW arena name it
+        parameters = list(parameters)
+        for p in parameters:
+            r = getattr(p, "_hamt_opt", None)
+            if r is not None:
+                optimizer = r()
+                break
+        if optimizer is not None and not (optimizer._built and len(parameters) == len(optimizer._params)):
+            optimizer = None           # a subset of the optimizer's parameters: the generic path below
     if optimizer is not None:
+        sync = optimizer._sharded_sync
+        if sync is not None and sync._unconsumed:      # reduce-scattered gradients: the norm over the owned chunks, one 4-byte all-reduce
+            gn = sync.global_norm()
+            optimizer._pending_clip = (sync._gsq, float(max_norm))
+            return gn
         gsq = optimizer.global_grad_sumsq()
         optimizer._pending_clip = (gsq, float(max_norm))
         return gsq.sqrt()[0]

@@ -409,6 +409,7 @@ class ShardedGradSync(OverlappedGradSync):
         self._gsq = torch.zeros(1, dtype=torch.float32, device=o._flat_g.device)
         self._upd = None                   # (norm graph, update graph, max_norm) once graph.GraphedTrainStep captured them
         self._unconsumed = False           # an exchange has run and update() has not consumed it yet
+        self._norm_reduced = False         # global_norm() ran for the pending exchange
 
     def close(self):
         super().close()
@@ -571,22 +572,36 @@ class ShardedGradSync(OverlappedGradSync):
         self._upd = (g1, g2, float(max_norm))
 
     @torch.no_grad()
-    def update(self, max_norm: float, have_sumsq: bool = False):
+    def global_norm(self) -> torch.Tensor:
+        """The global gradient norm after the exchange (device scalar, the same on every rank): this rank's sum of squares over the
+        chunks it owns, one 4-byte all-reduce.  What `clip_grad_norm_` returns in a loop that keeps the reference's lines
+        (ArenaDataParallel); `update(..., norm_reduced=True)` then uses it as it is."""
+        self.opt._ensure_table()
+        self._launch_sumsq()
+        if dist.is_initialized() and not DRY[0]:
+            dist.all_reduce(self._gsq, op=dist.ReduceOp.SUM)
+        self._norm_reduced = True
+        return self._gsq.sqrt()[0]
+
+    @torch.no_grad()
+    def update(self, max_norm: float, have_sumsq: bool = False, norm_reduced: bool = False):
         """Global-norm clip + AdamW over the owned segments, then the all-gathers.  The host part (optimizer.prepare_step) must
         have run; replaces clip_grad_norm_ + optimizer.step() + zero_grad() of the unsharded loop.  have_sumsq: the exchange
-        (`run(plan, sumsq=True)`) already left this rank's sum of squares in self._gsq."""
+        (`run(plan, sumsq=True)`) already left this rank's sum of squares in self._gsq; norm_reduced: `global_norm()` already
+        reduced it over the ranks."""
         from . import _lib as L
         from .ops import _p, _stream
         o, lib = self.opt, L.load()
         graphs = self._upd if (self._upd is not None and self._upd[2] == float(max_norm)) else None
-        if have_sumsq:
+        if have_sumsq or norm_reduced:
             pass
         elif graphs is not None:
             graphs[0].replay()
         else:
             self._launch_sumsq()
-        if dist.is_initialized() and not DRY[0]:
+        if dist.is_initialized() and not DRY[0] and not norm_reduced:
             dist.all_reduce(self._gsq, op=dist.ReduceOp.SUM)          # 4 bytes: the global squared norm
+        self._norm_reduced = False
         if graphs is not None:
             graphs[1].replay()
         else:
@@ -617,6 +632,121 @@ class ShardedGradSync(OverlappedGradSync):
         o._shard_stale = False
 
     gather_masters = gather_state          # (round-2 name)
+
+
+class ArenaDataParallel(torch.nn.Module):
+    """What `wrap_model` returns in place of the reference's `DistributedDataParallel(model, device_ids=[local_rank],
+    find_unused_parameters=True)` (pretrain_src/utils/misc.py:52-65), so that main_r2r.py keeps its lines
+
+        model = wrap_model(model, device, opts.local_rank)
+        ...
+        loss = model(batch, task=task, compute_loss=True); loss.mean().backward()
+        grad_norm = clip_grad_norm_(model.parameters(), opts.grad_norm)      # vln_hamt_amd.optim's (the import swap)
+        optimizer.step(); optimizer.zero_grad()
+
+    in fp32 AND bf16 mode.  torch DDP cannot serve the bf16 path: its reducer is fed by per-parameter AccumulateGrad hooks, and the
+    GEMM weight gradients never pass one -- they are written into the optimizer's flat gradient arena by ONE grouped launch at the
+    end of backward (wgrad.py).  This wrapper does what DDP does, at that granularity:
+
+      * construction: parameters and buffers of rank 0 are broadcast (DDP's _sync_module_states);
+      * every forward arms an end-of-backward callback on its output (once per backward pass however many forwards fed it:
+        the finetune rollout calls the module ~2T + 2 times before one backward, agent_cmt.py:584-597);
+      * the callback runs the arena exchange of `make_grad_sync` -- reduce-scatter (or all-reduce) range by range behind the
+        launch groups of the deferred weight gradients, i.e. overlapped with the only part of backward that is off the critical
+        path -- created lazily the first time, when the optimizer that owns the parameters' arena is known (main_r2r.py builds it
+        AFTER wrap_model, :150-156);
+      * parameters without a gradient this step (the other tasks' heads) are exchanged as zeros and skipped by the update:
+        find_unused_parameters=True semantics;
+      * with the sharded exchange, `clip_grad_norm_` returns the global norm from the owned chunks + one 4-byte all-reduce, and
+        `optimizer.step()` runs the owned-slice AdamW and the parameter all-gathers (optim.AdamW.step sees `_sharded_sync`).
+
+    `.module` is the wrapped model (utils/save.py:36 `model.module if hasattr(model, 'module') else model`)."""
+
+    def __init__(self, module: torch.nn.Module, n_groups: int | None = None, wire: str | None = None, sharded: bool | None = None):
+        super().__init__()
+        self.module = module
+        self._cfg = (n_groups if n_groups is not None else int(os.environ.get("HAMT_SYNC_GROUPS", 4)), wire, sharded)
+        self.grad_sync = None
+        self._armed: set = set()
+        if dist.is_available() and dist.is_initialized():
+            with torch.no_grad():
+                ts = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
+                for dt in {t.dtype for t in ts}:
+                    same = [t for t in ts if t.dtype == dt]
+                    flat = torch.cat([t.detach().reshape(-1) for t in same])
+                    dist.broadcast(flat, 0)
+                    o = 0
+                    for t in same:
+                        t.copy_(flat[o:o + t.numel()].view(t.shape))
+                        o += t.numel()
+                opt = self._optimizer()
+                if opt is not None and opt._built:
+                    opt.refresh_shadow()
+
+    def _optimizer(self):
+        for p in self.module.parameters():
+            r = getattr(p, "_hamt_opt", None)
+            if r is not None and r() is not None:
+                return r()
+        return None
+
+    def _sync_for(self, opt):
+        if self.grad_sync is None or self.grad_sync.opt is not opt:
+            if self.grad_sync is not None:
+                self.grad_sync.close()
+            from .modeling import precision_of
+            cfg = getattr(self.module, "config", None)
+            prec = precision_of(cfg) if cfg is not None else "bf16"
+            n_groups, wire, sharded = self._cfg
+            self.grad_sync = make_grad_sync(opt, prec, n_groups=n_groups, wire=wire, sharded=sharded)
+        return self.grad_sync
+
+    def forward(self, *args, **kwargs):
+        out = self.module(*args, **kwargs)
+        if torch.is_grad_enabled() and dist.is_available() and dist.is_initialized():
+            t = out if torch.is_tensor(out) else next((x for x in (out if isinstance(out, (tuple, list)) else ()) if torch.is_tensor(x) and x.requires_grad), None)
+            if t is not None and t.requires_grad:
+                t.register_hook(self._arm)
+        return out
+
+    def _arm(self, _grad):
+        tid = torch._C._current_graph_task_id()
+        if tid not in self._armed:
+            self._armed.add(tid)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self._post_backward(tid))
+        return None
+
+    @torch.no_grad()
+    def _post_backward(self, tid):
+        self._armed.discard(tid)
+        opt = self._optimizer()
+        if opt is None:
+            raise RuntimeError("ArenaDataParallel: the wrapped model's parameters belong to no vln_hamt_amd.optim.AdamW yet -- build the optimizer "
+                               "(optim.misc.build_optimizer) before the first backward pass, as main_r2r.py does")
+        opt.materialize()
+        sync = self._sync_for(opt)
+        from . import wgrad
+        dev = opt._flat_p.device
+        # this callback was queued when the pass STARTED, i.e. in front of the weight-gradient queue's own end-of-pass flush: run that
+        # flush now (it hands the queued problems to the exchange, which launches them group by group with the collectives behind
+        # them); the queue's own callback then finds nothing left
+        wgrad.queue(dev).flush(tid)
+        sync(opt)                           # nothing queued in this pass (fp32 mode): the plain range-by-range exchange
+
+    def close(self):
+        if self.grad_sync is not None:
+            self.grad_sync.close()
+            self.grad_sync = None
+
+
+def wrap_model(model: torch.nn.Module, device: torch.device, local_rank: int) -> torch.nn.Module:
+    """pretrain_src/utils/misc.py:52-65 with the same signature: `model.to(device)`; distributed (local_rank != -1) -> the
+    arena-exchange wrapper instead of torch DDP (see ArenaDataParallel); a single process is returned as it is (the reference's
+    nn.DataParallel branch for several visible GPUs in ONE process is not built: one process per GPU)."""
+    model.to(device)
+    if local_rank != -1 and dist.is_available() and dist.is_initialized():
+        return ArenaDataParallel(model)
+    return model
 
 
 def broadcast_params(optimizer, src: int = 0) -> None:

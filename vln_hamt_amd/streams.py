@@ -110,3 +110,46 @@ def gate(*what):
         return
     for o in list(pending_updates):
         o._ov.gate(what)
+
+
+# ---------------------------------------------------------------------------------------------- interleaved issue of independent chains
+# A replayed hipGraph runs its parallel branches in roughly the order their nodes were CAPTURED (tools/graph_branch_probe.py): a long
+# branch captured completely in front of another one delays the second by most of its own length, in the forward pass and -- since
+# autograd replays nodes in reverse creation order -- in the backward pass too (the panorama encoder's backward used to start 1.4 ms
+# after its inputs were ready, behind all nine text layers' backward: profiles/r04_*).  `interleave` issues the chains' units
+# alternately, the chain with the least accumulated cost first, each under its own stream.
+INTERLEAVE = os.environ.get("HAMT_INTERLEAVE", "1") != "0"
+
+
+def drive(gen):
+    """run a chain generator to completion; its return value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
+def interleave(chains):
+    """chains: [(stream, generator)]; a generator issues one unit of work per `next` and yields that unit's cost (any positive
+    number: rows x relative width), and returns its result.  Returns the list of results.  HAMT_INTERLEAVE=0: one chain after the
+    other, in the given order (the capture order before round 4)."""
+    if not INTERLEAVE:
+        out = []
+        for st, g in chains:
+            with torch.cuda.stream(st):
+                out.append(drive(g))
+        return out
+    n = len(chains)
+    acc, res, live = [0.0] * n, [None] * n, set(range(n))
+    while live:
+        i = min(live, key=lambda k: (acc[k], k))
+        st, g = chains[i]
+        try:
+            with torch.cuda.stream(st):
+                c = next(g)
+            acc[i] += float(c) if c else 1.0
+        except StopIteration as e:
+            res[i] = e.value
+            live.discard(i)
+    return res
