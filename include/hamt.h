@@ -429,12 +429,15 @@ int hamt_rng_advance(uint64_t* rng, void* stream);
  *   hamt_graph_split_launch:   streams[0] = the caller's stream (the others wait for it first, it waits for them last: the call is
  *                              stream-ordered on streams[0] like hipGraphLaunch); the streams must be pairwise distinct.
  *   hamt_graph_split_info:     node / segment / cross-stream-dependency counts, nodes per stream.
- *   hamt_graph_split_segments: per segment {stream, nodes, dependencies} into triples[3 * cap]; returns the number of segments. */
+ *   hamt_graph_split_segments: per segment {stream, nodes, dependency mask (bit k: depends on segment s - 1 - k)} into triples[3 * cap];
+ *                              returns the number of segments. */
 typedef struct hamt_graph_exec hamt_graph_exec;
 int hamt_graph_split(void* hip_graph, int n_streams, hamt_graph_exec** out);
 int hamt_graph_split_launch(hamt_graph_exec* x, void* const* streams, int n_streams);
 int hamt_graph_split_info(const hamt_graph_exec* x, int* n_nodes, int* n_segments, int* n_cross, int* stream_nodes, int n_streams);
 int hamt_graph_split_segments(const hamt_graph_exec* x, int* triples, int cap);
+/* one token per node of segment `seg` (kernel name, M<bytes> memcpy, S memset, E empty), ';'-separated; returns the length written */
+int hamt_graph_split_describe(const hamt_graph_exec* x, int seg, char* buf, size_t n);
 int hamt_graph_split_destroy(hamt_graph_exec* x);
 
 #ifdef __cplusplus

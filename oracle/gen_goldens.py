@@ -16,6 +16,7 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
   canon_ragged.npz    R2R-canon on RAGGED batches (L ~ U[20, 80], T ~ U[0, 7], B = 16): what the packed text path is compared with
   optim_tiny.npz      3 steps of clip(5.0) + reference AdamW + warmup schedule on the tiny model
   tiny_finetune.npz   NavCMT language / history / visual modes (incl. no_lang_ca)
+  a2c.npz             the agent's A2C loss block (agent_cmt.py:473-515), its own statements run on scripted rollout lists
   vit.npz             ViT backbone features / gradients from the reference's VisionTransformer class
   collate.npz         outputs of the reference's six *_collate functions on seeded ragged samples
   r2r_tiny/ + r2r_data.npz   a tiny R2R-style dataset (data files) and what the reference's MultiStepNavData reads / builds from it
@@ -443,6 +444,80 @@ def gen_agent_models(store):
     store["critic/state"] = st.numpy()
     store["critic/value"] = val.numpy()
     store["critic/sd_seed"] = np.array(12)
+
+
+def _reference_a2c_block():
+    """The A2C statements of the agent's rollout (finetune_src/r2r/agent_cmt.py, from `rl_loss = 0.` to `self.loss += rl_loss`) as a
+    code object compiled FROM THE REFERENCE FILE at generation time -- the reference's own statements, not a restatement.  They sit
+    inline in a 280-line method that needs the Matterport simulator for everything in front of them; the block itself only reads the
+    rollout's per-step lists, which are scripted here."""
+    import textwrap
+    path = os.path.join(ref_shim.REF, "finetune_src", "r2r", "agent_cmt.py")
+    lines = open(path).read().split("\n")
+    lo = next(i for i, ln in enumerate(lines) if ln.strip() == "rl_loss = 0.")
+    hi = next(i for i, ln in enumerate(lines) if i > lo and ln.strip() == "self.loss += rl_loss")
+    src = textwrap.dedent("\n".join(lines[lo:hi + 1]))
+    assert "last_value__ = self.critic(last_h_).detach()" in src and "normalize_loss" in src, "agent_cmt.py changed"
+    return compile(src, f"{path}:{lo + 1}-{hi + 1}", "exec"), (lo + 1, hi + 1)
+
+
+def gen_a2c():
+    """The agent's A2C loss (agent_cmt.py:473-515) pinned: the reference's own statements (compiled from its file, `_reference_a2c_block`)
+    run on scripted rollout lists -- per-step policy log-probabilities, hidden states (through the reference's Critic), rewards, masks,
+    entropies, a last state, `ended` -- for the three normalisations and both feedback modes; stored: the inputs, rl_loss, the logged
+    sums and the gradients w.r.t. the log-probabilities, the hidden states, the entropies and every critic parameter."""
+    import types
+    from collections import defaultdict
+    _, mh = ref_shim.import_finetune_agent_models()
+    code, span = _reference_a2c_block()
+    store = {"meta/span": np.asarray(span)}
+    T, B, Hs = 6, 5, 768
+    critic = mh.Critic(types.SimpleNamespace(dropout=0.5))
+    csd = make_state_dict({"state2value.0.weight": (512, 768), "state2value.0.bias": (512,), "state2value.3.weight": (1, 512), "state2value.3.bias": (1,)}, seed=12)
+    critic.load_state_dict(csd, strict=True)
+    critic.eval()
+    store["meta/critic_seed"] = np.array(12)
+    rng = np.random.Generator(np.random.PCG64(77))
+    ended_at = np.array([3, 6, 8, 5, 9])                              # episodes 2 and 4 run past the rollout: not ended
+    masks = (np.arange(T)[:, None] < ended_at[None]).astype(np.float32)
+    rewards = (rng.standard_normal((T, B)).astype(np.float32) * 2.0) * masks
+    ended = ended_at <= T
+    base = {"logp": -rng.random((T, B), dtype=np.float32) * 3.0, "hidden": rng.standard_normal((T, B, Hs), dtype=np.float32) * 0.5,
+            "ent": rng.random((T, B), dtype=np.float32), "last_h": rng.standard_normal((B, Hs), dtype=np.float32) * 0.5}
+    store.update({"in/rewards": rewards, "in/masks": masks, "in/ended": ended, **{f"in/{k}": v for k, v in base.items()}})
+    for normalize in ("total", "batch", "none"):
+        for feedback in ("sample", "teacher"):
+            logp = torch.from_numpy(base["logp"]).requires_grad_(True)
+            hidden = torch.from_numpy(base["hidden"]).requires_grad_(True)
+            ent = torch.from_numpy(base["ent"]).requires_grad_(True)
+            critic.zero_grad(set_to_none=True)
+            me = types.SimpleNamespace(critic=critic, feedback=feedback, logs=defaultdict(list), loss=0.0,
+                                       args=types.SimpleNamespace(gamma=0.9, entropy_loss_weight=0.01, normalize_loss=normalize))
+            ns = {"self": me, "np": np, "torch": torch, "last_h_": torch.from_numpy(base["last_h"]), "batch_size": B, "ended": ended.copy(),
+                  "rewards": [rewards[t] for t in range(T)], "masks": [masks[t] for t in range(T)],
+                  "policy_log_probs": [logp[t] for t in range(T)], "hidden_states": [hidden[t] for t in range(T)],
+                  "entropys": [ent[t] for t in range(T)]}
+            with ref_shim.cuda_is_identity():
+                exec(code, ns)
+            loss = me.loss
+            loss.backward()
+            pre = f"{normalize}_{feedback}/"
+            store[pre + "rl_loss"] = np.float64(loss.item())
+            store[pre + "policy_sum"] = np.float64(sum(me.logs["policy_loss"]))
+            store[pre + "critic_sum"] = np.float64(sum(me.logs["critic_loss"]))
+            store[pre + "total"] = np.float64(me.logs["total"][0])
+            store[pre + "d_logp"] = logp.grad.numpy().copy()
+            store[pre + "d_hidden"] = hidden.grad.numpy().copy()
+            store[pre + "d_ent"] = ent.grad.numpy().copy() if ent.grad is not None else np.zeros((T, B), np.float32)
+            for k, p_ in critic.named_parameters():
+                if p_.numel() <= 4096:
+                    store[pre + "d_critic/" + k] = p_.grad.numpy().copy()
+                else:      # (the 512 x 768 weight: norm + 257-point probe, as for the model's large gradients)
+                    store[pre + "d_critic_norm/" + k] = np.float64(p_.grad.double().norm().item())
+                    store[pre + "d_critic_probe/" + k] = grad_probe(p_.grad)
+            print(f"  [a2c {normalize} {feedback}] rl_loss {loss.item():.6f}")
+    np.savez_compressed(os.path.join(OUT, "a2c.npz"), **store)
+    print(f"a2c.npz: {len(store)} arrays from agent_cmt.py:{span[0]}-{span[1]}")
 
 
 def gen_vit():
@@ -875,7 +950,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi", "canon_multi_sar", "canon_ragged"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi", "canon_multi_sar", "canon_ragged", "a2c"]
     for w in which:
         {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
-         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi, "canon_ragged": gen_canon_ragged, "canon_multi_sar": gen_canon_multi_sar}[w]()
+         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi, "canon_ragged": gen_canon_ragged, "canon_multi_sar": gen_canon_multi_sar, "a2c": gen_a2c}[w]()

@@ -1060,11 +1060,58 @@ def test_wire_unpack_sumsq():
     assert abs(float(out) - want) <= 1e-5 * want, (float(out), want)
 
 
+@pytest.mark.parametrize("normalize", ["total", "batch", "none"])
+@pytest.mark.parametrize("feedback", ["sample", "teacher"])
+def test_a2c_loss_vs_reference_goldens(normalize, feedback):
+    """ops.a2c_loss + models.model_HAMT.Critic (fp32 mode) against tests/golden/a2c.npz: the REFERENCE's own A2C statements
+    (agent_cmt.py:476-517, compiled from its file at generation time, oracle/gen_goldens.py a2c) on scripted rollout lists -- loss, logged
+    sums, gradients w.r.t. log-probabilities, hidden states (through the critic), entropies and the critic's parameters."""
+    import types
+    import numpy as np
+    from _util import grad_probe, load_npz, sub
+    from oracle.hamt_oracle import make_state_dict
+    from vln_hamt_amd import ops
+    from vln_hamt_amd.models.model_HAMT import Critic
+    store = load_npz("a2c.npz")
+    sd = make_state_dict({"state2value.0.weight": (512, 768), "state2value.0.bias": (512,), "state2value.3.weight": (1, 512),
+                          "state2value.3.bias": (1,)}, seed=int(store["meta/critic_seed"]))
+    critic = Critic(types.SimpleNamespace(dropout=0.5, hamt_precision="fp32"))
+    critic.load_state_dict(sd, strict=True)
+    critic = critic.to(DEV).eval()
+    T, B = store["in/logp"].shape
+    d = lambda a: torch.from_numpy(a).to(DEV).requires_grad_(True)
+    logp, hidden, ent = d(store["in/logp"]), d(store["in/hidden"]), d(store["in/ent"])
+    value = critic(hidden.reshape(T * B, -1)).view(T, B)
+    with torch.no_grad():
+        lv = critic(torch.from_numpy(store["in/last_h"]).to(DEV))
+        lv = torch.where(torch.from_numpy(store["in/ended"]).to(DEV), torch.zeros_like(lv), lv)      # agent_cmt.py:480-484
+    loss, parts = ops.a2c_loss(logp, value, torch.from_numpy(store["in/rewards"]).to(DEV), torch.from_numpy(store["in/masks"]).to(DEV), last_value=lv,
+                               entropy=ent if feedback == "sample" else None, gamma=0.9, entropy_weight=0.01, normalize=normalize)
+    loss.backward()
+    pre = f"{normalize}_{feedback}/"
+    ref = float(store[pre + "rl_loss"])
+    assert abs(float(loss) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(loss), ref)
+    assert abs(float(parts["policy"]) - float(store[pre + "policy_sum"])) <= 1e-4 * max(1.0, abs(float(store[pre + "policy_sum"])))
+    assert abs(float(parts["critic"]) - float(store[pre + "critic_sum"])) <= 1e-4 * max(1.0, abs(float(store[pre + "critic_sum"])))
+    close(logp.grad, torch.from_numpy(store[pre + "d_logp"]), 1e-5, "d logp")
+    close(hidden.grad, torch.from_numpy(store[pre + "d_hidden"]), 1e-4, "d hidden")
+    if feedback == "sample":
+        close(ent.grad, torch.from_numpy(store[pre + "d_ent"]), 1e-5, "d entropy")
+    named = dict(critic.named_parameters())
+    for k, v in sub(store, pre + "d_critic/").items():
+        close(named[k].grad, torch.from_numpy(v), 1e-4, k)
+    for k, v in sub(store, pre + "d_critic_norm/").items():
+        assert abs(float(named[k].grad.double().norm()) - float(v)) <= 1e-4 * float(v), k
+        pr = store[pre + "d_critic_probe/" + k]
+        assert float(np.abs(grad_probe(named[k].grad) - pr).max()) <= 1e-4 * max(1.0, float(np.abs(pr).max())), k
+
+
 @pytest.mark.parametrize("normalize,with_ent", [("total", True), ("batch", False), ("none", True)])
 def test_a2c_loss_vs_reference_restatement(normalize, with_ent):
     """ops.a2c_loss (one scan kernel over [T, B]) against the statement-by-statement restatement of the agent's loop
     (oracle.hamt_oracle.a2c_loss_ref <- finetune_src/r2r/agent_cmt.py:476-518): loss, logged sums and the gradients w.r.t. the
-    policy log-probabilities, the critic values and the entropies.  (The reference loop itself needs the simulator: unpinned.)"""
+    policy log-probabilities, the critic values and the entropies.  (The restatement itself is pinned against the reference's own
+    statements: tests/test_oracle_goldens.py::test_a2c_restatement_matches_the_reference_block.)"""
     import numpy as np
     from oracle.hamt_oracle import a2c_loss_ref
     from vln_hamt_amd import ops

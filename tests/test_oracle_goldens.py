@@ -263,6 +263,46 @@ def test_critic_matches_reference():
     np.testing.assert_allclose(val.numpy(), store["critic/value"], atol=2e-5)
 
 
+@pytest.mark.parametrize("normalize", ["total", "batch", "none"])
+@pytest.mark.parametrize("feedback", ["sample", "teacher"])
+def test_a2c_restatement_matches_the_reference_block(normalize, feedback):
+    """oracle.hamt_oracle.a2c_loss_ref against tests/golden/a2c.npz -- the REFERENCE's own A2C statements (agent_cmt.py:476-517, compiled
+    from its file by oracle/gen_goldens.py a2c and run on scripted rollout lists): rl_loss, the logged sums, and the gradients w.r.t. the
+    policy log-probabilities, the hidden states (through the critic), the entropies and the critic's parameters.  Pins the restatement
+    the HIP kernel is tested against (tests/test_gpu_ops.py)."""
+    from oracle.hamt_oracle import a2c_loss_ref
+    store = load_npz("a2c.npz")
+    sd = make_state_dict({"state2value.0.weight": (512, 768), "state2value.0.bias": (512,), "state2value.3.weight": (1, 512),
+                          "state2value.3.bias": (1,)}, seed=int(store["meta/critic_seed"]))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+    def critic(st):      # model_HAMT.py:258-269, eval mode (pinned by test_critic_matches_reference)
+        h = torch.relu(st @ sd["state2value.0.weight"].t() + sd["state2value.0.bias"])
+        return (h @ sd["state2value.3.weight"].t() + sd["state2value.3.bias"]).squeeze()
+    T = store["in/logp"].shape[0]
+    logp = torch.from_numpy(store["in/logp"]).requires_grad_(True)
+    hidden = torch.from_numpy(store["in/hidden"]).requires_grad_(True)
+    ent = torch.from_numpy(store["in/ent"]).requires_grad_(True)
+    last_value = critic(torch.from_numpy(store["in/last_h"])).detach()
+    loss, logs = a2c_loss_ref([logp[t] for t in range(T)], [critic(hidden[t]) for t in range(T)], [store["in/rewards"][t] for t in range(T)],
+                              [store["in/masks"][t] for t in range(T)], last_value, store["in/ended"],
+                              [ent[t] for t in range(T)] if feedback == "sample" else None, gamma=0.9, entropy_loss_weight=0.01, normalize_loss=normalize)
+    loss.backward()
+    pre = f"{normalize}_{feedback}/"
+    assert abs(float(loss) - float(store[pre + "rl_loss"])) <= 1e-6 * max(1.0, abs(float(store[pre + "rl_loss"])))
+    assert abs(sum(logs["policy_loss"]) - float(store[pre + "policy_sum"])) <= 1e-4 and abs(sum(logs["critic_loss"]) - float(store[pre + "critic_sum"])) <= 1e-4
+    np.testing.assert_allclose(logp.grad.numpy(), store[pre + "d_logp"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(hidden.grad.numpy(), store[pre + "d_hidden"], atol=1e-6, rtol=1e-4)
+    if feedback == "sample":
+        np.testing.assert_allclose(ent.grad.numpy(), store[pre + "d_ent"], atol=1e-7, rtol=1e-5)
+    else:
+        assert ent.grad is None and not store[pre + "d_ent"].any()
+    for k, v in sub(store, pre + "d_critic/").items():
+        np.testing.assert_allclose(sd[k].grad.numpy(), v, atol=1e-5, rtol=1e-4)
+    for k, v in sub(store, pre + "d_critic_norm/").items():
+        assert abs(float(sd[k].grad.double().norm()) - float(v)) <= 1e-5 * float(v)
+
+
 def test_get_vlnbert_models_checkpoint_rules(tmp_path):
     """get_vlnbert_models (vlnbert_init.py:13-70) is checkpoint-key plumbing, no arithmetic: `module.` prefixes are stripped
     (:25-26), `next_action.*` becomes `bert.next_action.*` (:29-30) so that loading a PRETRAIN checkpoint (keys `bert.<trunk>`,

@@ -130,7 +130,8 @@ SIGNATURES = {
     "hamt_graph_split": [vp, i32, C.POINTER(vp)],
     "hamt_graph_split_launch": [vp, C.POINTER(vp), i32],
     "hamt_graph_split_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32],
-    "hamt_graph_split_segments": [vp, C.POINTER(i32), i32],
+    "hamt_graph_split_segments": [vp, vp, i32],
+    "hamt_graph_split_describe": [vp, i32, C.c_char_p, sz],
     "hamt_graph_split_destroy": [vp],
 }
 

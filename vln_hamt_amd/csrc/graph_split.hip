@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <string.h>
 #include <vector>
 
 namespace {
@@ -33,6 +34,7 @@ struct Segment {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   hipEvent_t ev = nullptr;
+  uint32_t* sig = nullptr;           // 8 bytes of signal memory: the launch epoch once the segment has run (stream memory operations)
 };
 
 }  // namespace
@@ -44,6 +46,12 @@ struct hamt_graph_exec {
   std::vector<char> stream_used;
   hipEvent_t ev_start = nullptr;
   std::vector<hipEvent_t> ev_end;
+  std::vector<hipGraphNode_t> nodes;   // the captured graph's nodes (describe)
+  std::vector<int> order;              // launch order of the segments (a topological order)
+  bool use_values = true;              // cross-stream dependencies by hipStreamWriteValue32 / hipStreamWaitValue32 (else events)
+  uint32_t epoch = 0;
+  uint32_t* sig_start = nullptr;
+  std::vector<uint32_t*> sig_end;
 };
 
 #define HAMT_HIP_OK(call, what)                                                                      \
@@ -54,6 +62,27 @@ struct hamt_graph_exec {
       return HAMT_ERR_LAUNCH;                                                                        \
     }                                                                                                \
   } while (0)
+
+// A segment's graph as a CLONE of the captured graph with every other node destroyed: exact copies of the nodes whatever their
+// kind (a captured hipMemcpyAsync is a 1-D memcpy node whose parameters hipGraphMemcpyNodeGetParams does not return in a form
+// hipGraphAddMemcpyNode accepts on ROCm 7.0).  O(nodes) API calls per segment, at capture time only.
+static int clone_segment_graph(Segment& sg, hipGraph_t g, const std::vector<hipGraphNode_t>& nodes, const std::vector<int>& seg_of, int s) {
+  HAMT_HIP_OK(hipGraphClone(&sg.graph, g), "hipGraphClone");
+  for (size_t v = 0; v < nodes.size(); ++v) {
+    if (seg_of[v] == s) continue;
+    hipGraphNode_t cn = nullptr;
+    HAMT_HIP_OK(hipGraphNodeFindInClone(&cn, nodes[v], sg.graph), "hipGraphNodeFindInClone");
+    HAMT_HIP_OK(hipGraphDestroyNode(cn), "hipGraphDestroyNode");
+  }
+  size_t left = 0;
+  HAMT_HIP_OK(hipGraphGetNodes(sg.graph, nullptr, &left), "hipGraphGetNodes");
+  if (left != sg.nodes.size()) {
+    hamt_set_error("hamt_graph_split: a segment's clone kept %zu nodes instead of %zu", left, sg.nodes.size());
+    return HAMT_ERR_LAUNCH;
+  }
+  HAMT_HIP_OK(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+  return HAMT_OK;
+}
 
 static int build_segment_graph(Segment& sg, const std::vector<hipGraphNode_t>& nodes) {
   HAMT_HIP_OK(hipGraphCreate(&sg.graph, 0), "hipGraphCreate");
@@ -75,7 +104,14 @@ static int build_segment_graph(Segment& sg, const std::vector<hipGraphNode_t>& n
       case hipGraphNodeTypeMemcpy: {
         hipMemcpy3DParms p;
         HAMT_HIP_OK(hipGraphMemcpyNodeGetParams(nodes[v], &p), "hipGraphMemcpyNodeGetParams");
-        HAMT_HIP_OK(hipGraphAddMemcpyNode(&nn, sg.graph, dep, nd, &p), "hipGraphAddMemcpyNode");
+        if (!p.srcArray && !p.dstArray && p.extent.height <= 1 && p.extent.depth <= 1) {
+          // a linear copy (what hipMemcpyAsync captures as): the 3-D form of its own parameters is rejected on re-adding
+          // ("invalid pitch argument", ROCm 7.0), the 1-D node takes them
+          HAMT_HIP_OK(hipGraphAddMemcpyNode1D(&nn, sg.graph, dep, nd, (char*)p.dstPtr.ptr + p.dstPos.x, (const char*)p.srcPtr.ptr + p.srcPos.x,
+                                              p.extent.width, p.kind), "hipGraphAddMemcpyNode1D");
+        } else {
+          HAMT_HIP_OK(hipGraphAddMemcpyNode(&nn, sg.graph, dep, nd, &p), "hipGraphAddMemcpyNode");
+        }
         break;
       }
       case hipGraphNodeTypeMemset: {
@@ -103,7 +139,10 @@ extern "C" int hamt_graph_split_destroy(hamt_graph_exec* x) {
     if (s.exec) hipGraphExecDestroy(s.exec);
     if (s.graph) hipGraphDestroy(s.graph);
     if (s.ev) hipEventDestroy(s.ev);
+    if (s.sig) hipFree(s.sig);
   }
+  if (x->sig_start) hipFree(x->sig_start);
+  for (auto p : x->sig_end) if (p) hipFree(p);
   if (x->ev_start) hipEventDestroy(x->ev_start);
   for (auto e : x->ev_end) if (e) hipEventDestroy(e);
   delete x;
@@ -181,6 +220,7 @@ extern "C" int hamt_graph_split(void* hip_graph, int n_streams, hamt_graph_exec*
   auto* x = new hamt_graph_exec();
   x->n_streams = n_streams;
   x->n_nodes = N;
+  x->nodes = nodes;
   for (int v : topo) {
     if (pred[v].size() == 1 && succ[pred[v][0]].size() == 1) {
       seg_of[v] = seg_of[pred[v][0]];
@@ -223,6 +263,29 @@ extern "C" int hamt_graph_split(void* hip_graph, int n_streams, hamt_graph_exec*
     sg.stream = st;
     last_on[st] = s;
   }
+  // launch order: a topological order of the segments.  Default: creation order.  HAMT_GRAPH_SPLIT_SIDE_FIRST=1: among the segments
+  // whose dependencies have been launched, those on the branch streams go first (their launch then never queues behind a long
+  // stream-0 segment that became ready at the same time); same-stream order is kept.
+  {
+    static const bool side_first = getenv("HAMT_GRAPH_SPLIT_SIDE_FIRST") != nullptr;
+    std::vector<char> done(S, 0);
+    for (int n_done = 0; n_done < S; ++n_done) {
+      int pick = -1;
+      for (int s = 0; s < S; ++s) {
+        if (done[s]) continue;
+        bool ready = true;
+        for (int d : x->segs[s].deps) if (!done[d]) { ready = false; break; }
+        // same-stream FIFO: an earlier, not yet launched segment of the same stream goes first
+        for (int e = 0; e < s && ready; ++e) if (!done[e] && x->segs[e].stream == x->segs[s].stream) ready = false;
+        if (!ready) continue;
+        if (pick < 0) pick = s;
+        else if (side_first && x->segs[pick].stream == 0 && x->segs[s].stream != 0) pick = s;
+        if (!side_first) break;
+      }
+      done[pick] = 1;
+      x->order.push_back(pick);
+    }
+  }
   x->stream_nodes.assign(n_streams, 0);
   x->stream_used.assign(n_streams, 0);
   for (int s = 0; s < S; ++s) {
@@ -232,13 +295,37 @@ extern "C" int hamt_graph_split(void* hip_graph, int n_streams, hamt_graph_exec*
     for (int d : sg.deps)
       if (x->segs[d].stream != sg.stream) { x->segs[d].record = true; ++x->n_cross; }
   }
-  for (auto& sg : x->segs) {
-    const int rc = build_segment_graph(sg, nodes);
+  static const bool readd = getenv("HAMT_GRAPH_SPLIT_READD") != nullptr;      // (re-add nodes from their parameters instead of cloning: kernel / memset / empty nodes only)
+  for (int s = 0; s < S; ++s) {
+    Segment& sg = x->segs[s];
+    const int rc = readd ? build_segment_graph(sg, nodes) : clone_segment_graph(sg, g, nodes, seg_of, s);
     if (rc != HAMT_OK) { hamt_graph_split_destroy(x); return rc; }
     if (sg.record && hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming) != hipSuccess) {
       hamt_graph_split_destroy(x);
       hamt_set_error("hamt_graph_split: hipEventCreate failed");
       return HAMT_ERR_LAUNCH;
+    }
+  }
+  // Cross-stream dependencies as STREAM MEMORY OPERATIONS on signal memory: measured (tools/fork_probe.py: a prefix on s0, then A on
+  // s0 and B on s1, both ready at once, everything issued before the GPU gets there) an event wait that is still pending when it is
+  // issued lets B start only when A is half done (1.26 ms against 0.97 ideal / 1.55 serialized) -- whichever of the two was issued
+  // first runs first -- while hipStreamWriteValue32 behind the prefix + hipStreamWaitValue32 in front of B gives 1.05.
+  {
+    int can = 0;
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, devid);
+    x->use_values = can != 0 && getenv("HAMT_GRAPH_SPLIT_EVENTS") == nullptr;
+    if (x->use_values) {
+      auto alloc = [&](uint32_t** p) -> bool {
+        if (hipExtMallocWithFlags((void**)p, 8, hipMallocSignalMemory) != hipSuccess) return false;
+        return hipMemset(*p, 0, 8) == hipSuccess;
+      };
+      bool ok = alloc(&x->sig_start);
+      x->sig_end.assign(n_streams, nullptr);
+      for (int k = 1; k < n_streams && ok; ++k) if (x->stream_used[k]) ok = alloc(&x->sig_end[k]);
+      for (auto& sg : x->segs) if (sg.record && ok) ok = alloc(&sg.sig);
+      if (!ok || hipDeviceSynchronize() != hipSuccess) { hamt_graph_split_destroy(x); hamt_set_error("hamt_graph_split: signal memory allocation failed"); return HAMT_ERR_LAUNCH; }
     }
   }
   if (hipEventCreateWithFlags(&x->ev_start, hipEventDisableTiming) != hipSuccess) { hamt_graph_split_destroy(x); hamt_set_error("hamt_graph_split: hipEventCreate failed"); return HAMT_ERR_LAUNCH; }
@@ -258,11 +345,14 @@ extern "C" int hamt_graph_split_info(const hamt_graph_exec* x, int* n_nodes, int
   return HAMT_OK;
 }
 
-// per segment: {stream, number of nodes, number of dependencies}; returns the number of segments (<= cap are written)
+// per segment: {stream, number of nodes, bit mask of up to 30 dependencies RELATIVE to the segment (bit k: segment s - 1 - k)};
+// returns the number of segments (<= cap are written)
 extern "C" int hamt_graph_split_segments(const hamt_graph_exec* x, int* triples, int cap) {
   if (!x) return 0;
   for (int s = 0; s < (int)x->segs.size() && s < cap; ++s) {
-    triples[3 * s] = x->segs[s].stream; triples[3 * s + 1] = (int)x->segs[s].nodes.size(); triples[3 * s + 2] = (int)x->segs[s].deps.size();
+    int m = 0;
+    for (int d : x->segs[s].deps) if (s - 1 - d < 30) m |= 1 << (s - 1 - d);
+    triples[3 * s] = x->segs[s].stream; triples[3 * s + 1] = (int)x->segs[s].nodes.size(); triples[3 * s + 2] = m;
   }
   return (int)x->segs.size();
 }
@@ -274,12 +364,35 @@ extern "C" int hamt_graph_split_launch(hamt_graph_exec* x, void* const* streams,
   hipStream_t s0 = (hipStream_t)streams[0];
   bool any = false;
   for (int k = 1; k < x->n_streams; ++k) any = any || x->stream_used[k];
+  if (x->use_values) {
+    const uint32_t ep = ++x->epoch;
+    if (any) {
+      HAMT_HIP_OK(hipStreamWriteValue32(s0, x->sig_start, ep, 0), "hipStreamWriteValue32");
+      for (int k = 1; k < x->n_streams; ++k)
+        if (x->stream_used[k]) HAMT_HIP_OK(hipStreamWaitValue32((hipStream_t)streams[k], x->sig_start, ep, hipStreamWaitValueGte, 0xFFFFFFFFu), "hipStreamWaitValue32");
+    }
+    for (int s : x->order) {
+      Segment& sg = x->segs[s];
+      hipStream_t st = (hipStream_t)streams[sg.stream];
+      for (int d : sg.deps)
+        if (x->segs[d].stream != sg.stream) HAMT_HIP_OK(hipStreamWaitValue32(st, x->segs[d].sig, ep, hipStreamWaitValueGte, 0xFFFFFFFFu), "hipStreamWaitValue32");
+      HAMT_HIP_OK(hipGraphLaunch(sg.exec, st), "hipGraphLaunch");
+      if (sg.record) HAMT_HIP_OK(hipStreamWriteValue32(st, sg.sig, ep, 0), "hipStreamWriteValue32");
+    }
+    for (int k = 1; k < x->n_streams; ++k)
+      if (x->stream_used[k]) {
+        HAMT_HIP_OK(hipStreamWriteValue32((hipStream_t)streams[k], x->sig_end[k], ep, 0), "hipStreamWriteValue32");
+        HAMT_HIP_OK(hipStreamWaitValue32(s0, x->sig_end[k], ep, hipStreamWaitValueGte, 0xFFFFFFFFu), "hipStreamWaitValue32");
+      }
+    return HAMT_OK;
+  }
   if (any) {
     HAMT_HIP_OK(hipEventRecord(x->ev_start, s0), "hipEventRecord");
     for (int k = 1; k < x->n_streams; ++k)
       if (x->stream_used[k]) HAMT_HIP_OK(hipStreamWaitEvent((hipStream_t)streams[k], x->ev_start, 0), "hipStreamWaitEvent");
   }
-  for (auto& sg : x->segs) {
+  for (int s : x->order) {
+    Segment& sg = x->segs[s];
     hipStream_t st = (hipStream_t)streams[sg.stream];
     for (int d : sg.deps)
       if (x->segs[d].stream != sg.stream) HAMT_HIP_OK(hipStreamWaitEvent(st, x->segs[d].ev, 0), "hipStreamWaitEvent");
@@ -292,4 +405,33 @@ extern "C" int hamt_graph_split_launch(hamt_graph_exec* x, void* const* streams,
       HAMT_HIP_OK(hipStreamWaitEvent(s0, x->ev_end[k], 0), "hipStreamWaitEvent");
     }
   return HAMT_OK;
+}
+
+// text description of segment `seg`: one token per node -- kernel name (up to 40 characters), M<bytes> for a memcpy, S for a
+// memset, E for an empty node -- separated by ';' (debugging / profiles); returns the length written
+extern "C" int hamt_graph_split_describe(const hamt_graph_exec* x, int seg, char* buf, size_t n) {
+  if (!x || seg < 0 || seg >= (int)x->segs.size() || !buf || n == 0) return 0;
+  std::string out;
+  for (int v : x->segs[seg].nodes) {
+    hipGraphNodeType ty;
+    if (hipGraphNodeGetType(x->nodes[v], &ty) != hipSuccess) { out += "?;"; continue; }
+    if (ty == hipGraphNodeTypeKernel) {
+      hipKernelNodeParams p;
+      const char* nm = nullptr;
+      if (hipGraphKernelNodeGetParams(x->nodes[v], &p) == hipSuccess && p.func) nm = hipKernelNameRefByPtr(p.func, nullptr);
+      std::string t = nm ? nm : "kernel";
+      if (t.size() > 60) t.resize(60);
+      out += t + ";";
+    } else if (ty == hipGraphNodeTypeMemcpy) {
+      hipMemcpy3DParms p;
+      if (hipGraphMemcpyNodeGetParams(x->nodes[v], &p) == hipSuccess) out += "M" + std::to_string(p.extent.width * (p.extent.height ? p.extent.height : 1)) + ";";
+      else out += "M;";
+    } else if (ty == hipGraphNodeTypeMemset) out += "S;";
+    else if (ty == hipGraphNodeTypeEmpty) out += "E;";
+    else out += "T" + std::to_string((int)ty) + ";";
+  }
+  const size_t len = std::min(out.size(), n - 1);
+  memcpy(buf, out.data(), len);
+  buf[len] = 0;
+  return (int)len;
 }

@@ -17,9 +17,15 @@ import torch
 from . import ops, streams
 
 
-# HAMT_GRAPH_SPLIT=0: replay the captured graph as ONE hipGraph (torch's CUDAGraph.replay) instead of chain by chain on separate streams
-SPLIT = os.environ.get("HAMT_GRAPH_SPLIT", "1") != "0"
+# HAMT_GRAPH_SPLIT=1: replay a captured step chain by chain on separate streams (SplitGraph / csrc/graph_split.hip) instead of as ONE
+# hipGraph (torch's CUDAGraph.replay).  Built and measured in round 4: correct, halves the host time of a replay (0.6 vs
+# 1.3 ms), but the step is no faster -- two long chains that become ready at the same fork still run one after the other on this
+# runtime, separate graphs / streams / hardware queues or not -- so it stays an option.
+SPLIT = os.environ.get("HAMT_GRAPH_SPLIT", "0") == "1"
 SPLIT_STREAMS = int(os.environ.get("HAMT_GRAPH_SPLIT_STREAMS", 2))
+
+
+_skipped: list = []
 
 
 class SplitGraph:
@@ -38,6 +44,9 @@ class SplitGraph:
         L.check(L.load().hamt_graph_split(C.c_void_p(torch_graph.raw_cuda_graph()), self.n, C.byref(h)), "hamt_graph_split")
         self.h = h
         dev = torch.cuda.current_device()
+        global _skipped
+        if not _skipped:      # (experiment: HAMT_BRANCH_SKIP=k takes k HIP streams out of torch's pool first, i.e. another hardware queue for the branch)
+            _skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("HAMT_BRANCH_SKIP", 0)))] or [None]
         self.branch = [streams.role_stream(dev, f"gbranch{i}") for i in range(1, self.n)]
         self._arr = (C.c_void_p * self.n)()
 
@@ -48,6 +57,22 @@ class SplitGraph:
         per = (C.c_int * self.n)()
         L.check(L.load().hamt_graph_split_info(self.h, C.byref(a), C.byref(b), C.byref(c), per, self.n), "hamt_graph_split_info")
         return {"nodes": a.value, "segments": b.value, "cross_stream_deps": c.value, "nodes_per_stream": list(per)}
+
+    def segments(self):
+        import ctypes as C
+        from . import _lib as L
+        n = L.load().hamt_graph_split_segments(self.h, None, 0)
+        buf = (C.c_int * (3 * n))()
+        L.load().hamt_graph_split_segments(self.h, buf, n)
+        return [(buf[3 * i], buf[3 * i + 1], [i - 1 - k for k in range(30) if buf[3 * i + 2] >> k & 1]) for i in range(n)]
+
+    def describe(self, seg: int) -> list:
+        """the nodes of segment `seg`: kernel names, M<bytes> memcpy, S memset, E empty"""
+        import ctypes as C
+        from . import _lib as L
+        buf = C.create_string_buffer(1 << 16)
+        L.load().hamt_graph_split_describe(self.h, seg, buf, 1 << 16)
+        return [t for t in buf.value.decode(errors="replace").split(";") if t]
 
     def replay(self):
         from . import _lib as L
@@ -78,6 +103,13 @@ def _finish_graph(g):
     if not SPLIT:
         return g
     sg = SplitGraph(g)
+    if os.environ.get("HAMT_GRAPH_SPLIT_VERBOSE"):
+        import sys
+        print(f"[graph split] {sg.info()} segments (stream, nodes, deps): {sg.segments()}", file=sys.stderr, flush=True)
+        if os.environ.get("HAMT_GRAPH_SPLIT_VERBOSE") == "2":
+            short = lambda t: t.split("<")[0].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-28:]
+            for i, (st, n, deps) in enumerate(sg.segments()):
+                print(f"    seg {i} stream {st} deps {deps}: " + " ".join(short(t) for t in sg.describe(i)), file=sys.stderr, flush=True)
     return sg
 
 

@@ -113,12 +113,14 @@ def gate(*what):
 
 
 # ---------------------------------------------------------------------------------------------- interleaved issue of independent chains
-# A replayed hipGraph runs its parallel branches in roughly the order their nodes were CAPTURED (tools/graph_branch_probe.py): a long
-# branch captured completely in front of another one delays the second by most of its own length, in the forward pass and -- since
-# autograd replays nodes in reverse creation order -- in the backward pass too (the panorama encoder's backward used to start 1.4 ms
-# after its inputs were ready, behind all nine text layers' backward: profiles/r04_*).  `interleave` issues the chains' units
-# alternately, the chain with the least accumulated cost first, each under its own stream.
-INTERLEAVE = os.environ.get("HAMT_INTERLEAVE", "1") != "0"
+# `interleave` issues the units of independent chains alternately (the chain with the least accumulated cost first, each under its own
+# stream) instead of one whole chain after the other, so that capture order = a plausible execution order; autograd then replays the
+# backward nodes interleaved as well.  Built in round 4 to test whether the capture order is what makes a replayed hipGraph run the
+# panorama encoder's backward 1.4 ms late (behind all nine text layers' backward although its inputs are ready: profiles/
+# r04_queues_*.txt).  It is NOT: the same delay appears with the chains as separate graphs on separate streams, whichever is launched
+# first runs first -- and interleaved capture measured 1-3 % slower (B = 64: 9.96 vs 9.86 ms, B = 16: 5.61 vs 5.45 on one
+# box).  Off by default (HAMT_INTERLEAVE=1 turns it on).
+INTERLEAVE = os.environ.get("HAMT_INTERLEAVE", "0") == "1"
 
 
 def drive(gen):
