@@ -595,6 +595,16 @@ class NavPreTrainedModel(BertPreTrainedModel):
         self.encoder = LxmertEncoder(config)
         self.init_weights()
 
+    @staticmethod
+    def _early(x):
+        """behind the text embedder: in BACKWARD this point is reached when the text layers (and everything behind them on this
+        stream) are done and only the embedder's own backward is left -- the weight gradients queued on this stream are launched
+        here, next to the panorama encoder's backward on the second stream (wgrad.flush_current_stream)"""
+        from .. import wgrad
+        if x.is_cuda and streams.two_stream_enabled("trunk"):
+            return wgrad.early_flush_point(x)
+        return x
+
     def _text(self, txt_ids, txt_m, keep_packed=False):
         """Text embedder + the text-only layers (vilmodel.py:601, 441-443).  With a packing plan on `txt_ids` (`_hamt_pack` = (pack_idx
         [M], cu_seqlens int32 [n + 1], unpack_idx [B L]), put there by MultiStepNavCMTPreTraining.forward from the batch's `txt_pack_idx`
@@ -611,7 +621,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
         # (the packed attention kernels hold one sequence per workgroup: instructions of up to 128 tokens -- R2R's 80; RxR pretraining
         # pads to 250, config/pretrain_rxr.json: such batches take the padded kernels, which serve up to 256 keys)
         if pack is None or txt_ids.shape[1] > PACK_MAX_LEN or not (blocks.ENABLED and precision_of(self.config) == "bf16" and txt_ids.is_cuda and H % 64 == 0):
-            x = self.embeddings(txt_ids)
+            x = self._early(self.embeddings(txt_ids))
             yield txt_ids.numel() // 4
             for layer in self.encoder.layer:
                 x = (yield from layer.forward_units(x, txt_m))[0]
@@ -619,7 +629,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
         pack_idx, cu, unpack_idx = pack
         B, L = txt_ids.shape
         ids = txt_ids.reshape(-1)[pack_idx]
-        x = self.embeddings(ids[None], position_ids=(pack_idx % L)[None]).view(-1, H)
+        x = self._early(self.embeddings(ids[None], position_ids=(pack_idx % L)[None]).view(-1, H))
         x._hamt_seq = (cu, int(cu.shape[0]) - 1, L)
         yield x.shape[0] // 4
         for layer in self.encoder.layer:

@@ -314,19 +314,24 @@ class AdamW(Optimizer):
             L.check(lib.hamt_sumsq_table(0, self._n, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
                                          _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
         if self._fused is not None:         # the table (flag 3) skipped these: their tiles' sums of squares
-            ss = self._fused[0]
-            L.check(L.load().hamt_sumsq_partials(ss.numel(), _p(ss), _p(self._gnorm), 1, _stream()), "hamt_sumsq_partials")
+            for ss in self._fused[0]:
+                L.check(L.load().hamt_sumsq_partials(ss.numel(), _p(ss), _p(self._gnorm), 1, _stream()), "hamt_sumsq_partials")
         return self._gnorm
 
     # ---------------------------------------------------------------- step = host part + launches
-    def note_fused_sumsq(self, ss: torch.Tensor, params):
+    def note_fused_sumsq(self, ss: torch.Tensor, params, append: bool = False):
         """wgrad.py: the grouped weight-gradient launch of this pass left the sum of squares of these parameters' gradients in
-        `ss` (one float per output tile): the norm kernel skips them (table flag 3) and adds sum(ss) instead."""
+        `ss` (one float per output tile): the norm kernel skips them (table flag 3) and adds sum(ss) instead.  append: a second
+        launch of the same pass (wgrad.flush_current_stream) adds its tiles to the first one's."""
         if self._ov is not None:        # (update at the head of the next replay: the table describes the previous step, see attach())
             return
         # valid for as long as nothing else writes the gradient arena: any torch op on a gradient (averaging over micro-batches or
         # ranks, scaling, a copy) bumps the arena's version counter and global_grad_sumsq then reduces everything from memory
-        self._fused = (ss, np.asarray([self._index_of[id(p)] for p in params], dtype=np.int64), self._flat_g._version)
+        idx = np.asarray([self._index_of[id(p)] for p in params], dtype=np.int64)
+        if append and self._fused is not None:
+            self._fused = (self._fused[0] + [ss], np.concatenate([self._fused[1], idx]), self._flat_g._version)
+        else:
+            self._fused = ([ss], idx, self._flat_g._version)
 
     def clear_fused_sumsq(self):
         self._fused = None

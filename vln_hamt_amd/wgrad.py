@@ -37,12 +37,18 @@ stats = {"flushes": 0, "problems": 0, "dropped_stale": 0}
 
 class _Pass:
     """What one backward pass (one autograd graph task) has queued so far."""
-    __slots__ = ("items", "vecs", "lnred")
+    __slots__ = ("items", "vecs", "lnred", "targets", "seen", "launched", "cleared", "fused_ids")
 
     def __init__(self):
         self.items: List[tuple] = []     # (w, b, dy16, x16)
         self.vecs: List[tuple] = []      # (parameter, gradient tensor): published as .grad at flush
         self.lnred: List[tuple] = []     # (ws, red, M, H, want_dxsum): LayerNorm-backward partials, one grouped launch at flush
+        # state shared by the launches of one pass (flush_current_stream may launch a part of the queue early)
+        self.targets: dict = {}          # id(parameter) -> gradient buffer
+        self.seen: dict = {}             # id(buffer) -> writes launched so far
+        self.launched = 0                # launches so far
+        self.cleared = False             # the optimizers' tile sums of an EARLIER pass have been dropped
+        self.fused_ids = None            # buffers whose tile sums this pass's launches handed to the optimizer
 
 
 class WgradQueue:
@@ -156,6 +162,7 @@ def defer(w: torch.Tensor, b: Optional[torch.Tensor], dy16: torch.Tensor, x16: t
         b = None
     if rows is not None:
         dy16._hamt_rows = int(rows)          # rides on the operand: the queue entries stay (w, b, dy16, x16)
+    dy16._hamt_stream = torch.cuda.current_stream().cuda_stream      # the stream whose kernels produced the operands
     queue(dy16.device).current().items.append((w, b, dy16, x16))
 
 
@@ -294,11 +301,28 @@ def _flush_pass(ps: _Pass, handler):
         stats["problems"] += len(items)
         handler(items)
         return
-    targets: dict = {}
+    _launch_items(ps, items)
+
+
+def ps_fused_ids(ps: _Pass) -> set:
+    """ids of the gradient buffers whose tile sums of squares earlier launches of this pass handed to the optimizer"""
+    if ps.fused_ids is None:
+        ps.fused_ids = set()
+    return ps.fused_ids
+
+
+@torch.no_grad()
+def _launch_items(ps: _Pass, items, later=frozenset()):
+    """hamt_wgrad_grouped for `items` on the current stream and publication of the results as `.grad`.  May run more than once per
+    pass (flush_current_stream): `ps.targets` / `ps.seen` carry which buffers earlier launches of the pass wrote -- a later write to
+    the same buffer accumulates.  `later`: ids of parameters that still have queued problems (their gradients are not final after
+    this launch: no tile sums of squares for them)."""
+    targets, seen = ps.targets, ps.seen
     fresh: list = []
+    refused = False
     # Two problems that write the same buffer (a parameter used twice in the pass) must not share a launch: the k-th
     # write to a buffer goes into the k-th launch group, and groups run in stream order.
-    seen: dict = {}
+    base_seen = dict(seen)
     groups: List[list] = []
     for (w, b, dy16, x16) in items:
         tw, aw = _target(w, targets, fresh)
@@ -311,25 +335,36 @@ def _flush_pass(ps: _Pass, handler):
         seen[id(tw)] = k + 1
         if tb is not None:
             seen[id(tb)] = k + 1
-        while len(groups) <= k:
+        bk = max(base_seen.get(id(tw), 0), base_seen.get(id(tb), 0) if tb is not None else 0)
+        g = k - bk                               # writes to these buffers by earlier launches are complete (same stream): only this call's count
+        if bk > 0 and id(tw) in ps_fused_ids(ps):
+            refused = True                       # a weight an earlier launch of this pass left tile sums for is written again
+        while len(groups) <= g:
             groups.append([])
-        groups[k].append((w, dy16, x16, tw, aw or k > 0, tb, ab or k > 0))
+        groups[g].append((w, dy16, x16, tw, aw or k > 0, tb, ab or k > 0))
     lib = L.load()
     # Sum of squares of the gradients while their tiles are still in registers (hamt_wgrad_desc.ss): for every weight whose
     # gradient is STORED once in this pass straight into its gradient-arena slot -- the bulk of the parameters -- so that the
     # global-norm clip does not have to read them back (optim.AdamW.global_grad_sumsq adds the slots' total to the table norm).
     fused, ss_all, opt = [], None, None
-    for o in {id(r): r for r in (getattr(it[0], "_hamt_opt", None) for it in items) if r is not None}.values():
-        if o() is not None:
-            o().clear_fused_sumsq()            # whatever an earlier pass left (gradient accumulation: this pass adds on top)
-    if FUSE_SUMSQ and groups:
+    if not ps.cleared:
+        ps.cleared = True
+        for o in {id(r): r for r in (getattr(it[0], "_hamt_opt", None) for it in items) if r is not None}.values():
+            if o() is not None:
+                o().clear_fused_sumsq()            # whatever an earlier pass left (gradient accumulation: this pass adds on top)
+    if refused:      # (safe fallback: the norm kernel reads those gradients back from memory)
+        for o in {id(r): r for r in (getattr(it[0], "_hamt_opt", None) for it in items) if r is not None}.values():
+            if o() is not None:
+                o().clear_fused_sumsq()
+        ps.fused_ids = set()
+    if FUSE_SUMSQ and groups and not refused:
         slots_of = lambda w: ((w.shape[0] + 63) // 64) * ((w.shape[1] + 127) // 128)
         n_ss = 0
         for (w, dy16, x16, tw, aw, tb, ab) in groups[0]:
             o = getattr(w, "_hamt_opt", None)
             o = o() if o is not None else None
             slot = getattr(w, "_hamt_grad_slot", None)
-            if (o is not None and (opt is None or o is opt) and not aw and seen.get(id(tw), 0) == 1 and slot is not None
+            if (o is not None and (opt is None or o is opt) and not aw and seen.get(id(tw), 0) == 1 and id(w) not in later and slot is not None
                     and tw.data_ptr() == slot.data_ptr() and not getattr(w, "_hamt_slot_zeroed", True) and tw.stride(0) == w.shape[1]):
                 opt = o
                 fused.append((id(tw), w, n_ss))
@@ -349,7 +384,9 @@ def _flush_pass(ps: _Pass, handler):
             d.ss = (ss_all.data_ptr() + 4 * ss_of[id(tw)]) if (gi == 0 and id(tw) in ss_of) else None
         launch(descs, len(grp))
     if fused:
-        opt.note_fused_sumsq(ss_all, [w for (_k, w, _o) in fused])
+        opt.note_fused_sumsq(ss_all, [w for (_k, w, _o) in fused], append=ps.launched > 0 and bool(ps_fused_ids(ps)))
+        ps_fused_ids(ps).update(k for (k, _w, _o) in fused)
+    ps.launched += 1
     stats["flushes"] += 1
     stats["problems"] += len(items)
     for p, t in fresh:
@@ -357,6 +394,57 @@ def _flush_pass(ps: _Pass, handler):
             p.grad = t
         else:                                   # an existing gradient of another dtype / layout
             p.grad.add_(t.to(p.grad.dtype))
+
+
+class _EarlyFlushFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_current_stream(g.device)
+        return g
+
+
+def early_flush_point(x: torch.Tensor) -> torch.Tensor:
+    """Identity whose BACKWARD launches the weight-gradient problems queued so far on the current stream (flush_current_stream): put it
+    on a tensor whose gradient arrives when a long chain of backward nodes of this stream is done.  Keeps the bf16-image tag."""
+    if not (ENABLED and x.requires_grad and torch.is_grad_enabled()):
+        return x
+    y = _EarlyFlushFn.apply(x)
+    for k in ("_hamt_bf16", "_hamt_seq", "_hamt_pair", "_hamt_unpack"):
+        if hasattr(x, k):
+            setattr(y, k, getattr(x, k))
+    return y
+
+
+def flush_current_stream(device=None) -> int:
+    """From INSIDE a backward pass: launch NOW, on the current stream, the queued weight-gradient problems whose operands were
+    produced on that stream, instead of at the end of the pass.  model.vilmodel.NavPreTrainedModel puts such a point behind the
+    backward of the text layers: autograd issues the panorama encoder's backward (second stream) after them, and that chain then runs
+    NEXT TO this launch instead of in front of one launch of everything (profiles/r04_graph_branches.txt: 0.6 ms of every step were
+    the tail of that chain with nothing beside it).  No-op with a handler installed (the data-parallel exchange plans the whole pass)
+    or outside a pass.  Returns the number of problems launched.
+    Measured (round 4, tools/prof_ab.sh, alternating on one box): the overlap happens -- and buys nothing: the panorama backward takes
+    1.7 instead of 1.1 ms next to the MFMA-bound launch, B = 64 9.89 / 10.10 vs 9.90 / 10.00 ms, B = 16 5.49 / 5.62 vs 5.40 / 5.63: the
+    chip is throughput bound there, not idle.  Opt-in: HAMT_EARLY_WGRAD=1."""
+    if not ENABLED or os.environ.get("HAMT_EARLY_WGRAD") != "1":
+        return 0
+    q = queue(device)
+    tid = torch._C._current_graph_task_id()
+    ps = q.passes.get(tid) if tid >= 0 else None
+    if ps is None or q.handler is not None or not ps.items:
+        return 0
+    cur = torch.cuda.current_stream().cuda_stream
+    mine = [it for it in ps.items if getattr(it[2], "_hamt_stream", None) == cur]
+    if not mine:
+        return 0
+    from . import streams
+    streams.wait_pending_updates()
+    ps.items = [it for it in ps.items if getattr(it[2], "_hamt_stream", None) != cur]
+    _launch_items(ps, mine, later=frozenset(id(it[0]) for it in ps.items))
+    return len(mine)
 
 
 # ------------------------------------------------------------------------------------------ planned (arena) mode
