@@ -1053,6 +1053,10 @@ static int kg_variant(const hamt_gemm_desc* d) {
   const int nk = d->K / BK;
   if (nk < 12 || d->N > 1024) return 0;
   const long tn = (d->N + 127) / 128, t32 = (long)((d->M + 31) / 32) * tn, t64 = (long)((d->M + 63) / 64) * tn;
+  // a VERY long reduction over a small output (the MLM decoder's dgrad: 768 x 768 x 30 528 at B = 64): 144 workgroups walking 477
+  // k-tiles each took 157 us in the step (profiles/r04_*); split-K over the grid (10 slices of 128-row tiles, ~360 workgroups, the
+  // partial tiles are 24 MB) is the better form there -- when the caller can take it (plain / accumulate epilogue, fp32 C)
+  if (nk >= 192 && t64 <= 128 && !(d->epilogue & ~HAMT_EPI_ACCUM) && d->dtype_c == HAMT_F32 && d->ldc == d->N) return 0;
   if (t32 <= 256) return 3224;
   if (t64 <= 256 && nk >= 24) return 6432;
   // one 128-row tile per CU, two groups (B = 64 text / vision streams: 5120x768x3072 41.2 -> 35.3 us, 2752x768x2304 27.7 -> 24.2)
