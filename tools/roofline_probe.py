@@ -227,10 +227,10 @@ def kernel_table(model, opt, cycle, device, live=True):
 
 
 def traffic_of(kernel: str, batch: int):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/r03_traffic_b<batch>.json -- the newest round's, else r02's --, written by
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/rNN_traffic_b<batch>.json -- the newest round's --, written by
     tools/hbm_rates.py --json from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x 2 per the gfx950
     correction of MI355X_MICROARCH.md), or None when that kernel / batch was not collected."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_b{batch}.json") for r in (3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_b{batch}.json") for r in (9, 8, 7, 6, 5, 4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None, None
     tab = json.load(open(path))

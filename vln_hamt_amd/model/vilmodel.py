@@ -574,6 +574,7 @@ class HistoryEmbeddings(nn.Module):
                 pe = enc(pe, None)[0]
             else:
                 for layer in enc.layer:
+                    streams.gate(layer)
                     pe = (yield from layer.forward_units(pe, None))[0]
             e = ops.add3(e.view(B * T, H), ops.mean_mid(pe))
         e = e.view(B, T, H)
@@ -624,6 +625,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
             x = self._early(self.embeddings(txt_ids))
             yield txt_ids.numel() // 4
             for layer in self.encoder.layer:
+                streams.gate(layer)      # (forward_units is called directly: the module's forward pre-hooks -- optim.AdamW.attach -- do not fire)
                 x = (yield from layer.forward_units(x, txt_m))[0]
             return x
         pack_idx, cu, unpack_idx = pack
@@ -633,6 +635,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
         x._hamt_seq = (cu, int(cu.shape[0]) - 1, L)
         yield x.shape[0] // 4
         for layer in self.encoder.layer:
+            streams.gate(layer)
             x = (yield from layer.forward_units(x, None))[0]
         if keep_packed and X_PACK and not XBIDIR:      # (the cross-modal layers go on with the packed rows: LxmertEncoder.forward)
             x._hamt_unpack = (unpack_idx, B, L)
@@ -655,6 +658,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
             step_ids = None
             if hist_img_feats is not None:
                 step_ids = torch.arange(hist_img_feats.size(1), device=txt_ids.device)[None]
+            streams.gate(self.hist_embeddings)
             cls, steps = yield from self.hist_embeddings.forward_units(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
                                                                        step_ids, batch_size=B)
             hist = cls if steps is None else torch.cat([cls, steps], 1)
@@ -729,6 +733,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
             return streams.drive(vision_units(neg_idxs, shuffled_pos_ids))
 
         def vision_units(neg_idxs, shuffled_pos_ids):
+            streams.gate(self.hist_embeddings)
             cls, nopos = yield from self.hist_embeddings.forward_units(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
                                                                        pos_ids=None, batch_size=B)
             hist = torch.cat([cls, self.hist_embeddings.add_position(nopos, torch.arange(T, device=dev)[None])], 1)

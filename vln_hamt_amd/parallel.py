@@ -467,7 +467,10 @@ class ShardedGradSync(OverlappedGradSync):
                         L.check(lib.hamt_wire_pack_bf16(b - a, _p(self.opt._flat_g[a:b]), _p(self._stage[a:b]), 1.0 / self.world, _stream()), "hamt_wire_pack_bf16")
             else:
                 L.check(lib.hamt_wire_pack_bf16(hi - lo, _p(g), _p(st), 1.0 / self.world, _stream()), "hamt_wire_pack_bf16")
-            self._reduce_scatter(own, st)
+            if self.world == 1 and not self.gloo:
+                own = st                       # one rank: the reduce-scatter is the identity -- no staging copy of the whole range
+            else:
+                self._reduce_scatter(own, st)
             if not direct:
                 g.zero_()
             if sumsq is not None and c:      # widen the owned chunk and add its share of the global norm in the same pass
