@@ -279,7 +279,13 @@ def subblock_xattn(model, batch, device, L_txt=80, n_vis=43):
     # backward instead of 10 + 10): faster in isolation, slower inside the step where the two directions otherwise run side by side
     # on two streams (HAMT_XBIDIR)
     bidir = None
+    from vln_hamt_amd import wgrad as _wg
     try:
+        if _wg.get_handler(device) is not None:
+            # a data-parallel exchange is installed (bench.py --gpus N): its launch groups on two lanes inside THIS capture end in a
+            # segmentation fault in hipStreamEndCapture on ROCm 7.0 (wait chains between forked streams, DESIGN_HISTORY section 6) -- the
+            # one-node form is measured in single-process runs only
+            raise RuntimeError("skipped with a gradient exchange installed")
         xl_ = torch.randn(batch, L_txt, Hd, device=device, requires_grad=True)
         xv_ = torch.randn(batch, n_vis, Hd, device=device, requires_grad=True)
         ml, mv = torch.zeros(batch, 1, 1, L_txt, device=device), torch.zeros(batch, 1, 1, n_vis, device=device)

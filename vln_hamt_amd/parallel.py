@@ -510,6 +510,8 @@ class ShardedGradSync(OverlappedGradSync):
         reference's R2R / RxR configurations accumulate over 1 step (pretrain_r2r.json:11); anything else must accumulate locally
         and exchange on the last micro-batch -- refuse rather than drop gradients silently.  One rank is exempt: its
         owned chunk is the whole range, so accumulation is exact there."""
+        if DRY[0]:
+            return                         # (measurement passes with the collectives switched off: bench.py's probes)
         if self._unconsumed and self.world > 1:
             from ._lib import HamtError
             raise HamtError("ShardedGradSync: a second gradient exchange before update() consumed the first (gradient accumulation over "
