@@ -51,8 +51,9 @@ int hamt_last_kernel(char* buf, size_t n);
  *   HAMT_WS_LN_BWD       {M, H}     hamt_ln_bwd / hamt_ln_bwd_add `ws`
  *   HAMT_WS_WGRAD_TABLE  {M_0, M_1, ...}  (output rows of every problem) hamt_wgrad_grouped `table`
  *   HAMT_WS_LNRED_TABLE  {n}        hamt_ln_bwd_reduce_grouped `table`
+ *   HAMT_WS_VIS_EMBED_BWD {M, H}    hamt_vis_embed_bwd `ws`
  * returns the size in bytes, or 0 for an unknown op / malformed shape */
-enum { HAMT_WS_GEMM_SPLITK = 0, HAMT_WS_COLSUM = 1, HAMT_WS_SUMSQ = 2, HAMT_WS_LN_BWD = 3, HAMT_WS_WGRAD_TABLE = 4, HAMT_WS_LNRED_TABLE = 5 };
+enum { HAMT_WS_GEMM_SPLITK = 0, HAMT_WS_COLSUM = 1, HAMT_WS_SUMSQ = 2, HAMT_WS_LN_BWD = 3, HAMT_WS_WGRAD_TABLE = 4, HAMT_WS_LNRED_TABLE = 5, HAMT_WS_VIS_EMBED_BWD = 6 };
 size_t hamt_workspace_bytes(int op, const int* shape, int nshape);
 
 /* ------------------------------------------------------------------------------------------------
@@ -212,6 +213,33 @@ int hamt_attn_varlen_cross_fwd(const hamt_attn_desc* d, const void* q, const voi
 int hamt_attn_varlen_cross_bwd(const hamt_attn_desc* d, const void* q, const void* k, const void* v, const int* cu_q,
                                const int* cu_k, int n_pairs, const int* pair, const float* add_mask, const void* o, const void* d_o,
                                const float* lse, void* dq, void* dk, void* dv, const uint64_t* rng, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vis_embed: the two-stream visual embedding   e = LN_img(x1) + LN_ang(ang W_ang^T + b_ang)
+ *   ImageEmbeddings / HistoryEmbeddings (A10, A11): img_layer_norm(img_linear(img)) + ang_layer_norm(ang_linear(ang))
+ *   (vilmodel.py:498-500, 549-551, 557-558; finetune vilmodel_cmt.py:575-578, 585-586); x1 [M, H] = img_linear's output
+ *   (bf16 or fp32), ang [M, 4] fp32 with row stride ld_ang, w_ang [H, 4] / b_ang [H] = ang_linear's parameters.
+ * fwd: y [M, H] fp32, y16 (optional) its bf16 image [Mpad16, H] (rows [M, Mpad16) zero), stats [4][M] = mean / rstd of the image
+ *   stream, mean / rstd of the angle stream (for backward).
+ * bwd: dy [M, H] -> dx = d(x1) as fp32 [M, H] and / or dx16 = its bf16 image [Mpad16, H] (the operand of img_linear's weight
+ *   gradient; rows [M, Mpad16) zero); the gradients of both LayerNorms' gamma / beta, of b_ang and of w_ang are ADDED to the
+ *   six output vectors (dbeta_img or dbeta_ang may be NULL).  ws: HAMT_WS_VIS_EMBED_BWD {M, H} bytes of scratch.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int M, H;
+  int A;      /* angle features: 4 (the only size the reference uses and the only one built) */
+  int ld_ang; /* row stride of ang, in floats (a multiple of 4) */
+  float eps1, eps2;
+  int x_bf16; /* x1 is bf16 (else fp32) */
+  int Mpad16; /* rows of the optional bf16 images y16 / dx16 (0: none beyond M) */
+} hamt_vis_embed_desc;
+int hamt_vis_embed_fwd(const hamt_vis_embed_desc* d, const void* x1, const float* ang, const float* w_ang, const float* b_ang,
+                       const float* gamma_img, const float* beta_img, const float* gamma_ang, const float* beta_ang,
+                       float* y, void* y16, float* stats, void* stream);
+int hamt_vis_embed_bwd(const hamt_vis_embed_desc* d, const float* dy, const void* x1, const float* ang, const float* w_ang,
+                       const float* b_ang, const float* gamma_img, const float* gamma_ang, const float* stats, float* dx, void* dx16,
+                       float* dgamma_img, float* dbeta_img, float* dgamma_ang, float* dbeta_ang, float* db_ang, float* dw_ang,
+                       float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ln: y = dropout_post( LayerNorm( dropout_pre(x) + residual ) )      fp32 statistics

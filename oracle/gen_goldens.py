@@ -757,6 +757,60 @@ def gen_canon_ragged():
     print("canon_ragged.npz:", len(store), "arrays")
 
 
+# ------------------------------------------------------------------------------------------------ the reference's own bf16 error
+def gen_canon_autocast():
+    """The yardstick for the bf16 tolerances: the REFERENCE itself under torch.autocast(bfloat16) against its own fp32 forward, on the
+    CANON_MULTI and CANON_RAGGED draws -- max |bf16 - fp32| / max(1, max |fp32|) of the loss, the head outputs (logits / predictions; at the
+    finite positions) and the trunk probes the other goldens hold.  Head outputs of the reference's own bf16 path reach 1.6e-2 on these
+    draws (a LayerNorm + Linear on top of a 13-layer bf16 trunk amplifies), so tests/ gate the HIP model's head outputs at
+    max(1e-2, this) -- "1e-2, or no worse than the reference's own bf16 path on the same draw" -- and everything else at 1e-2."""
+    torch.set_num_threads(8)
+    cfg = OracleConfig()
+    store = {}
+
+    def rel(a, b):
+        a, b = a.float(), b.float()
+        return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+
+    for fam, cases, seed0, kw in (("multi", CANON_MULTI, 4321, dict(txt_len=80, hist_len=5)),
+                                  ("ragged", CANON_RAGGED, 4400, dict(txt_len=RAGGED_L, hist_len=RAGGED_T, ragged=True))):
+        for ci, (wseed, bseed, B) in enumerate(cases):
+            model, vil = build_ref_pretrain(cfg, make_state_dict(pretrain_param_shapes(cfg), seed=wseed))
+            for i, task in enumerate(("mlm", "sap", "sar", "sprel", "mrc", "itm")):
+                batch = make_batch(task, B if task != "itm" else 2 * B, cfg, seed=bseed + i, **kw)
+                outs = {}
+                for mode in ("fp32", "bf16"):
+                    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=mode == "bf16"):
+                        np.random.seed(seed0 + ci)
+                        torch.manual_seed(seed0 + ci)
+                        r = {"loss": model(batch, task, True)}
+                        np.random.seed(seed0 + ci)
+                        torch.manual_seed(seed0 + ci)
+                        lg = model(batch, task, False)
+                        r["logits"] = lg[0] if isinstance(lg, tuple) else lg
+                        if task != "itm":
+                            g = lambda k: batch.get(k)
+                            t, h, o = model.bert(g("txt_ids"), g("txt_masks"), g("hist_img_fts"), g("hist_ang_fts"), g("hist_pano_img_fts"),
+                                                 g("hist_pano_ang_fts"), g("hist_masks"), g("ob_img_fts"), g("ob_ang_fts"), g("ob_nav_types"), g("ob_masks"))
+                            r["txt"] = t * batch["txt_masks"].unsqueeze(-1)          # (the real positions: nothing reads the others)
+                            r["hist"] = h
+                            if o is not None:
+                                r["ob"] = o
+                    outs[mode] = r
+                errs = {}
+                for k, b in outs["fp32"].items():
+                    a = outs["bf16"][k]
+                    if k == "logits":
+                        fin = torch.isfinite(b)
+                        a, b = a[fin], b[fin]
+                    errs[k] = rel(a, b)
+                    store[f"{fam}/c{ci}/{task}/{k}"] = np.float32(errs[k])
+                print(f"  [reference autocast {fam} c{ci} w{wseed} B{B} {task}] " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()), flush=True)
+            del model
+    np.savez_compressed(os.path.join(OUT, "canon_autocast.npz"), **store)
+    print("canon_autocast.npz:", len(store), "arrays")
+
+
 # ------------------------------------------------------------------------------------------------ N4: readers + loaders
 R2R_TINY = os.path.join(OUT, "r2r_tiny")
 R2R_DIMS = dict(image_feat_size=16, image_prob_size=10, angle_feat_size=4)
@@ -950,7 +1004,8 @@ def gen_loader():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi", "canon_multi_sar", "canon_ragged", "a2c"]
+    which = sys.argv[1:] or ["tiny", "optim", "finetune", "canon", "vit", "collate", "r2r_data", "r2r_tasks", "loader", "canon_multi", "canon_multi_sar", "canon_ragged", "a2c", "canon_autocast"]
     for w in which:
         {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
-         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi, "canon_ragged": gen_canon_ragged, "canon_multi_sar": gen_canon_multi_sar, "a2c": gen_a2c}[w]()
+         "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi, "canon_ragged": gen_canon_ragged, "canon_multi_sar": gen_canon_multi_sar, "a2c": gen_a2c,
+         "canon_autocast": gen_canon_autocast}[w]()

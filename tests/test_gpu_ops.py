@@ -823,6 +823,84 @@ def test_ln_dropout_pre_post():
 
 
 # ------------------------------------------------------------------------------------------ gathers & co
+@pytest.mark.parametrize("M,K,H", [(320, 768, 768), (2368, 768, 768), (11520, 768, 768), (37, 64, 128), (1000, 512, 1024)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16-x16"])
+def test_vis_embed_fwd_bwd(M, K, H, prec, monkeypatch):
+    """hamt_vis_embed_fwd / _bwd (img_layer_norm(img_linear(img)) + ang_layer_norm(ang_linear(ang)), vilmodel.py:498-500) at the
+    step's row counts (history steps 320, observation tokens 2368, panorama views 11520 at B = 64) against fp64 autograd.  fp32 mode:
+    everything <= 2e-5 of scale.  bf16 mode: the fp64 reference is fed the kernel's own bf16 dense output (so the LayerNorm part is
+    checked tightly: 1e-4, the bf16 image to bf16 rounding) and the dense layer's gradients loosely (2e-2: bf16 operands)."""
+    ops = _ops()
+    nn = torch.nn
+    x16 = prec == "bf16-x16"         # the dense layer's output handed over in bf16 (HAMT_VIS_EMBED_X16=1; off by default)
+    prec = prec.split("-")[0]
+    monkeypatch.setattr(ops, "VIS_EMBED_X16", x16)
+    torch.manual_seed(M + H)
+    img_lin, ang_lin = nn.Linear(K, H), nn.Linear(4, H)
+    ln1, ln2 = nn.LayerNorm(H, eps=1e-12), nn.LayerNorm(H, eps=1e-12)
+    for ln in (ln1, ln2):
+        ln.weight.data = 1.0 + 0.3 * torch.randn(H)
+        ln.bias.data = 0.2 * torch.randn(H)
+    mods = nn.ModuleList([img_lin, ang_lin, ln1, ln2])
+    img, ang = rnd(M, K, seed=1), rnd(M, 4, seed=2)
+    gy = rnd(M, H, seed=3)
+    # fp64 reference
+    ref = nn.ModuleList([nn.Linear(K, H), nn.Linear(4, H), nn.LayerNorm(H, eps=1e-12), nn.LayerNorm(H, eps=1e-12)]).double()
+    ref.load_state_dict({k: v.double() for k, v in mods.state_dict().items()})
+    mods = mods.to(DEV)
+    x = img.to(DEV).requires_grad_(True)
+    assert ops.vis_embed_ok(x, ang.to(DEV), mods[0], mods[1])
+    y = ops.vis_embed(x, ang.to(DEV), mods[0], mods[2], mods[1], mods[3], prec, want16=True)
+    y16 = ops.shadow16(y)
+    assert y16 is not None and y16.shape == ((M + 63) // 64 * 64, H)
+    y.backward(gy.to(DEV))
+    xr = img.double().requires_grad_(True)
+    x1 = ref[0](xr)
+    if prec == "bf16":       # the dense layer's output as the kernel saw it: bf16 operands, bf16 result
+        with torch.no_grad():
+            x1q = bf16_round(img) @ bf16_round(mods[0].weight.detach().cpu()).t() + mods[0].bias.detach().cpu()
+            x1q = (x1q.to(torch.bfloat16) if x16 else x1q).double()
+        x1 = x1 + (x1q - x1).detach()
+    yr = ref[2](x1) + ref[3](ref[1](ang.double()))
+    yr.backward(gy.double())
+    tight = 2e-5 if prec == "fp32" else 1e-4
+    close(y, yr, 2e-3 if x16 else tight, "y")      # (x16: x1q above is torch's rounding of ITS sum, a few ulps of bf16 off the kernel's)
+    close(y16[:M], yr, 1e-2, "y16")
+    assert float(y16[M:].float().abs().max() if y16.shape[0] > M else 0.0) == 0.0
+    loose = 2e-5 if prec == "fp32" else 2e-2
+    for name, a, b in (("ln_img.weight", mods[2].weight.grad, ref[2].weight.grad), ("ln_img.bias", mods[2].bias.grad, ref[2].bias.grad),
+                       ("ln_ang.weight", mods[3].weight.grad, ref[3].weight.grad), ("ln_ang.bias", mods[3].bias.grad, ref[3].bias.grad),
+                       ("ang.weight", mods[1].weight.grad, ref[1].weight.grad), ("ang.bias", mods[1].bias.grad, ref[1].bias.grad)):
+        close(a, b, 2e-3 if (x16 and name.startswith("ln_img")) else tight, name)
+    close(mods[0].weight.grad, ref[0].weight.grad, loose, "img.weight")
+    close(mods[0].bias.grad, ref[0].bias.grad, loose, "img.bias")
+    close(x.grad, xr.grad, loose, "d img")
+
+
+def test_vis_embed_matches_the_four_launch_path(monkeypatch):
+    """the fused embedding against the path it replaces (dense, two LayerNorms, K = 4 dense, add) on the same modules, bf16 mode,
+    gradients into a real optimizer arena (slots) with the deferred weight gradients flushed"""
+    ops = _ops()
+    from vln_hamt_amd.model.vilmodel import _VisualLinears
+    nn = torch.nn
+    torch.manual_seed(0)
+    mods = nn.ModuleList([nn.Linear(768, 768), nn.Linear(4, 768), nn.LayerNorm(768, eps=1e-12), nn.LayerNorm(768, eps=1e-12)]).to(DEV)
+    img, ang, gy = rnd(640, 36, 768, seed=4).to(DEV), rnd(640, 36, 4, seed=5).to(DEV), rnd(640, 36, 768, seed=6).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "VIS_EMBED", fused)
+        for p in mods.parameters():
+            p.grad = None
+        y = _VisualLinears.two_stream(mods[0], mods[2], mods[1], mods[3], img, ang, "bf16")
+        y.backward(gy)
+        from vln_hamt_amd import wgrad
+        wgrad.flush()
+        res[fused] = (y.detach().clone(), [p.grad.detach().clone() for p in mods.parameters()])
+    close(res[True][0], res[False][0], 1e-2, "y")
+    for a, b, (n, _) in zip(res[True][1], res[False][1], mods.named_parameters()):
+        close(a, b, 2e-2, n)
+
+
 def test_embed_sum_and_gather_scatter_exact():
     ops = _ops()
     B, L, H, V = 3, 20, 128, 500

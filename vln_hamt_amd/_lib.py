@@ -47,6 +47,10 @@ class LnDesc(C.Structure):
     _fields_ = [("M", i32), ("H", i32), ("eps", f32), ("p_pre", f32), ("p_post", f32), ("call_id", u32), ("Mpad16", i32), ("io16", i32)]
 
 
+class VisEmbedDesc(C.Structure):
+    _fields_ = [("M", i32), ("H", i32), ("A", i32), ("ld_ang", i32), ("eps1", f32), ("eps2", f32), ("x_bf16", i32), ("Mpad16", i32)]
+
+
 class GemmLnDesc(C.Structure):
     _fields_ = [("M", i32), ("K", i32), ("H", i32), ("lda", i32), ("eps", f32), ("p_pre", f32), ("call_id", u32), ("Mpad16", i32), ("tile_rows", i32)]
 
@@ -81,6 +85,8 @@ SIGNATURES = {
     "hamt_attn_varlen_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_attn_varlen_cross_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp],
     "hamt_attn_varlen_cross_bwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_vis_embed_fwd": [C.POINTER(VisEmbedDesc)] + [vp] * 12,
+    "hamt_vis_embed_bwd": [C.POINTER(VisEmbedDesc)] + [vp] * 18,
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_gemm_ln_fwd": [C.POINTER(GemmLnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -179,7 +185,7 @@ def workspace_bytes(op: int, *shape) -> int:
     return int(load().hamt_workspace_bytes(op, arr, len(shape)))
 
 
-WS_GEMM_SPLITK, WS_COLSUM, WS_SUMSQ, WS_LN_BWD, WS_WGRAD_TABLE, WS_LNRED_TABLE = range(6)
+WS_GEMM_SPLITK, WS_COLSUM, WS_SUMSQ, WS_LN_BWD, WS_WGRAD_TABLE, WS_LNRED_TABLE, WS_VIS_EMBED_BWD = range(7)
 
 
 def check(rc: int, name: str):

@@ -38,6 +38,7 @@ extern "C" int hamt_last_kernel(char* buf, size_t n) {
 }
 
 extern "C" int hamt_gemm_ksplit(const hamt_gemm_desc* d);
+size_t hamt_vis_embed_ws_bytes(int M, int H);   // vis_embed.hip
 
 extern "C" size_t hamt_workspace_bytes(int op, const int* shape, int nshape) {
   switch (op) {
@@ -59,6 +60,7 @@ extern "C" size_t hamt_workspace_bytes(int op, const int* shape, int nshape) {
       return e * HAMT_WGRAD_TABLE_ENTRY;
     }
     case HAMT_WS_LNRED_TABLE: return nshape >= 1 && shape ? (size_t)shape[0] * HAMT_LNRED_TABLE_ENTRY : 0;
+    case HAMT_WS_VIS_EMBED_BWD: return nshape >= 2 && shape ? hamt_vis_embed_ws_bytes(shape[0], shape[1]) : 0;
     default: return 0;
   }
 }

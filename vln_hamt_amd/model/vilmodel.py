@@ -467,7 +467,9 @@ class _VisualLinears(nn.Module):
     """shared helper: LN(Linear(img)) + LN(Linear(ang)) used by both embedders."""
 
     @staticmethod
-    def two_stream(img_lin, img_ln, ang_lin, ang_ln, img, ang, prec):
+    def two_stream(img_lin, img_ln, ang_lin, ang_ln, img, ang, prec, want16=False):
+        if ops.vis_embed_ok(img, ang, img_lin, ang_lin):      # one launch behind the dense layer (csrc/vis_embed.hip)
+            return ops.vis_embed(img, ang, img_lin, img_ln, ang_lin, ang_ln, prec, want16)
         a = ops.layer_norm(ops.linear(img, img_lin.weight, img_lin.bias, ops.ACT_NONE, prec), None, img_ln)
         # K = angle_feat_size (4): exact fp32 contraction, it is 4 FMAs per output
         b = ops.layer_norm(ops.linear(ang, ang_lin.weight, ang_lin.bias, ops.ACT_NONE, "fp32"), None, ang_ln)
@@ -565,10 +567,11 @@ class HistoryEmbeddings(nn.Module):
             V = pano_img_feats.shape[2]
             pe = _VisualLinears.two_stream(self.pano_img_linear, self.pano_img_layer_norm, self.pano_ang_linear,
                                            self.pano_ang_layer_norm, pano_img_feats.reshape(B * T, V, -1),
-                                           pano_ang_feats.reshape(B * T, V, -1), self.prec)
+                                           pano_ang_feats.reshape(B * T, V, -1), self.prec, want16=self.prec == "bf16")
             yield B * T * V // 2
             # all 36 views exist: the reference's mask is all-zero (:560) == no mask
-            pe = pe.view(B * T, V, H)
+            if pe.shape != (B * T, V, H):
+                pe = pe.view(B * T, V, H)
             enc = self.pano_encoder
             if enc.output_hidden_states or enc.output_attentions:
                 pe = enc(pe, None)[0]

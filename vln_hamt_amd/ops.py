@@ -667,6 +667,110 @@ def layer_norm(x, residual, ln_module, p_pre=0.0, p_post=0.0, eps=None, want16=F
     return y
 
 
+# ------------------------------------------------------------------------------------------ two-stream visual embedding
+VIS_EMBED = os.environ.get("HAMT_VIS_EMBED", "1") == "1"
+# bf16 dense output in front of the fused kernel (-6 us per step at B = 64): OFF -- the history embedder is where ITM's candidates
+# differ, and its logits sit at 0.9 of the 1e-2 parity bound already (1.02e-2 on one canon_ragged draw with this on)
+VIS_EMBED_X16 = os.environ.get("HAMT_VIS_EMBED_X16", "0") == "1"
+
+
+def _grad_dst(p, shape, dev, in_pass):
+    """-> (tensor the kernel ADDS p's gradient to, what backward returns for p): p's slot in the optimizer's gradient arena (zero at
+    the start of a step; published as `.grad` at the end of the pass, as ops.GatherRowsFn does) or a fresh zero tensor."""
+    slot = getattr(p, "_hamt_grad_slot", None) if (in_pass and p is not None and p.is_leaf and p.requires_grad) else None
+    if (slot is not None and slot.shape == p.shape and slot.is_contiguous() and getattr(p, "_hamt_slot_zeroed", False)
+            and (p.grad is None or p.grad.data_ptr() == slot.data_ptr())):
+        return slot, None
+    t = torch.zeros(shape, dtype=torch.float32, device=dev)
+    return t, t
+
+
+class VisEmbedFn(torch.autograd.Function):
+    """e = img_layer_norm(img_linear(img)) + ang_layer_norm(ang_linear(ang))  (vilmodel.py:498-500, 549-551, 557-558): the dense
+    layer, then ONE launch for the K = 4 angle projection, both LayerNorms and the sum
+    (hamt_vis_embed_fwd; csrc/vis_embed.hip); backward one launch + a small reduction, the image stream's gradient leaving as
+    the bf16 image img_linear's queued weight gradient reads.  Second output: the bf16 image of e (or None)."""
+
+    @staticmethod
+    def forward(ctx, img, ang, w1, b1, g1, be1, w2, b2, g2, be2, eps1, eps2, prec, want16):
+        _chk(img, "VisEmbedFn")
+        K, H, A = img.shape[-1], w1.shape[0], ang.shape[-1]
+        x2 = img.reshape(-1, K)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        dev = img.device
+        a2 = ang.reshape(M, A).to(torch.float32).contiguous()
+        x16 = prep_x16(x2, prec)
+        x1 = torch.empty(M, H, dtype=torch.bfloat16 if (x16 is not None and VIS_EMBED_X16) else torch.float32, device=dev)
+        _linear_fwd(x2, w1, b1.detach() if b1 is not None else None, x1, ACT_NONE, prec, None, x16)
+        y = torch.empty(M, H, dtype=torch.float32, device=dev)
+        Mp = _rup(M) if want16 else 0
+        y16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want16 else None
+        stats = torch.empty(4, M, dtype=torch.float32, device=dev)
+        d = L.VisEmbedDesc(M, H, A, A, float(eps1), float(eps2), int(x1.dtype == torch.bfloat16), Mp)
+        L.check(L.load().hamt_vis_embed_fwd(C.byref(d), _p(x1), _p(a2), _p(w2.detach()), _p(b2.detach()), _p(g1.detach()), _p(be1.detach()),
+                                            _p(g2.detach()), _p(be2.detach()), _p(y), _p(y16), _p(stats), _stream()), "hamt_vis_embed_fwd")
+        ctx.save_for_backward(x2 if x16 is None else None, x16, x1, a2, stats, w1, g1, w2, b2, g2)
+        ctx.params = (g1, be1, g2, be2, b2, w2)
+        ctx.args = (float(eps1), float(eps2), prec, img.shape, b1 is not None)
+        ctx.bias_param = b1 if (b1 is not None and b1.is_leaf) else (None if b1 is None else False)
+        if y16 is not None:
+            ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)
+        return y.view(*img.shape[:-1], H), y16
+
+    @staticmethod
+    def backward(ctx, dy, _d16=None):
+        if dy is None:
+            return (None,) * 14
+        x2, x16, x1, a2, stats, w1, g1, w2, b2, g2 = ctx.saved_tensors
+        eps1, eps2, prec, ishape, has_b1 = ctx.args
+        M, H = x1.shape
+        A = a2.shape[1]
+        dev = dy.device
+        dy2 = dy.reshape(M, H).contiguous()
+        from . import wgrad
+        in_pass = wgrad.ENABLED and torch._C._current_graph_task_id() >= 0
+        fast = x16 is not None
+        Mp = _rup(M) if fast else 0
+        dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if fast else None
+        dx = None if fast else torch.empty(M, H, dtype=torch.float32, device=dev)
+        dst = [_grad_dst(p, p.shape, dev, in_pass) if ctx.needs_input_grad[i] else (None, None)
+               for p, i in zip(ctx.params, (4, 5, 8, 9, 7, 6))]          # gamma_img, beta_img, gamma_ang, beta_ang, b_ang, w_ang
+        scratch = [None if t is not None else torch.zeros(p.shape, dtype=torch.float32, device=dev) for (t, _), p in zip(dst, ctx.params)]
+        out = [t if t is not None else s_ for (t, _), s_ in zip(dst, scratch)]
+        if any(t is not None and r is None for t, r in dst):
+            wgrad.queue(dev).current()              # (opens the pass: orders this stream behind an overlapped optimizer update)
+        ws = torch.empty(L.workspace_bytes(L.WS_VIS_EMBED_BWD, M, H) // 4, dtype=torch.float32, device=dev)
+        d = L.VisEmbedDesc(M, H, A, A, eps1, eps2, int(x1.dtype == torch.bfloat16), Mp)
+        L.check(L.load().hamt_vis_embed_bwd(C.byref(d), _p(dy2), _p(x1), _p(a2), _p(w2.detach()), _p(b2.detach()), _p(g1.detach()), _p(g2.detach()),
+                                            _p(stats), _p(dx), _p(dx16), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _p(out[4]), _p(out[5]),
+                                            _p(ws), _stream()), "hamt_vis_embed_bwd")
+        for (t, r), p in zip(dst, ctx.params):
+            if t is not None and r is None:
+                wgrad.publish_slot_grad(p, t)
+        rets = [r for _, r in dst]
+        dimg, dw1, db1 = _linear_bwd(dx16[:M] if fast else dx, x2, x16, w1, prec, ctx.needs_input_grad[0], ctx.needs_input_grad[2],
+                                     has_b1 and ctx.needs_input_grad[3], dy16=dx16, bias_param=ctx.bias_param)
+        return ((dimg.view(ishape) if dimg is not None else None), None, dw1, db1, rets[0], rets[1], rets[5], rets[4], rets[2], rets[3],
+                None, None, None, None)
+
+
+def vis_embed_ok(img, ang, img_lin, ang_lin) -> bool:
+    H = img_lin.weight.shape[0]
+    return (VIS_EMBED and img.is_cuda and ang.shape[-1] == 4 and H % 64 == 0 and H <= 1024 and img.dtype == torch.float32
+            and ang_lin.bias is not None and img_lin.weight.dtype == torch.float32)
+
+
+def vis_embed(img, ang, img_lin, img_ln, ang_lin, ang_ln, prec, want16=False):
+    y, y16 = VisEmbedFn.apply(img, ang, img_lin.weight, img_lin.bias, img_ln.weight, img_ln.bias, ang_lin.weight, ang_lin.bias,
+                              ang_ln.weight, ang_ln.bias, img_ln.eps, ang_ln.eps, prec, want16)
+    if y16 is not None:
+        y._hamt_bf16 = (y16, y._version, y.data_ptr())
+    return y
+
+
 # ------------------------------------------------------------------------------------------ gathers / embeddings
 class EmbedSumFn(torch.autograd.Function):
     """word[ids] + position[:L] + token_type[0]  (vilmodel.py:62-66; int64 gather is bit exact)."""
