@@ -465,7 +465,7 @@ def precompute_cross_kv(c, att):
 # ================================================================================================= feed-forward block
 class FfnBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p_hidden, eps, w1, b1, w2, b2, gamma, beta):
+    def forward(ctx, x, p_hidden, eps, w1, b1, w2, b2, gamma, beta, grad_on=True):
         shp = x.shape
         H = shp[-1]
         x2 = x.reshape(-1, H)
@@ -477,8 +477,12 @@ class FfnBlockFn(torch.autograd.Function):
         x16 = _x16_of(x, x2)
         Mp = x16.shape[0]
         g16 = _zeros_or_empty(Mp, M, I, dev)
-        pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(W1 x + b1), from the same erf/exp as gelu
-        gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre)
+        if grad_on and any(ctx.needs_input_grad):
+            pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(W1 x + b1), from the same erf/exp as gelu
+            gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre)
+        else:        # inference (rollout, validation): nobody reads gelu' -- one M x 3072 image less to write
+            pre = None
+            gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU)
         o = torch.empty(M, H, dtype=O_DTYPE, device=dev)      # bf16: what a linear returns under autocast (ops._ln_fwd reads it as such)
         gemm(g16[:M], weight_operand(w2, "bf16"), o, bias=b2.detach())
         y, y16, z, mean, rstd, cid_ln = _ln_fwd(o, x2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
@@ -492,7 +496,7 @@ class FfnBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _unused=None):
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         x16, g16, pre, z, mean, rstd, w1, b1, w2, b2, gamma = ctx.saved_tensors
         shp, M, H, I, p_hidden, eps, cid_ln = ctx.meta
         dev = dy.device
@@ -504,7 +508,7 @@ class FfnBlockFn(torch.autograd.Function):
         dw2, _ = _wgrad(w2, None, dx16, g16, M)
         gemm(dh16[:M], weight_operand(w1, "bf16"), dz, b_kmajor=True, epilogue=L.EPI_ACCUM)                     # dx = dz + dH W1
         dw1, db1 = _wgrad(w1, b1, dh16, x16, M)
-        return dz.view(shp), None, None, dw1, db1, dw2, db2, dgamma, dbeta
+        return dz.view(shp), None, None, dw1, db1, dw2, db2, dgamma, dbeta, None
 
 
 # ================================================================================================= module-facing wrappers
@@ -561,7 +565,7 @@ def cross_attn_block(x, c, add_mask, att, att_out, training):
 def ffn_block(x, inter, out, training):
     ph = float(out.dropout.p) if training else 0.0
     y, y16 = FfnBlockFn.apply(x, ph, out.LayerNorm.eps, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias,
-                              out.LayerNorm.weight, out.LayerNorm.bias)
+                              out.LayerNorm.weight, out.LayerNorm.bias, torch.is_grad_enabled())
     y = _tag(y, y16)
     seq = getattr(x, "_hamt_seq", None)
     if seq is not None:

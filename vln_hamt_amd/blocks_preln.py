@@ -109,7 +109,7 @@ class PreLnAttnFn(torch.autograd.Function):
 
 class PreLnMlpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p_drop, eps, gamma, beta, w1, b1, w2, b2):
+    def forward(ctx, x, p_drop, eps, gamma, beta, w1, b1, w2, b2, grad_on=True):
         shp = x.shape
         D = shp[-1]
         x2 = x.reshape(-1, D)
@@ -121,7 +121,9 @@ class PreLnMlpFn(torch.autograd.Function):
         Mp = y16.shape[0]
         g16 = _zeros_or_empty(Mp, M, I, dev)
         cid1, cid2 = (next_call_id(), next_call_id()) if p_drop > 0.0 else (0, 0)
-        if any(ctx.needs_input_grad):
+        # (needs_input_grad reports the parameters' requires_grad whatever the caller's grad mode, and forward itself always runs
+        # with grad mode off: the caller passes its own torch.is_grad_enabled())
+        if grad_on and any(ctx.needs_input_grad):
             pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(fc1), from the same erf evaluation as gelu
             gemm(y16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre, drop=(p_drop, cid1))
         else:                                    # no-grad panorama pass (image_vilmodel.py:44-52): nobody reads gelu'
@@ -151,7 +153,7 @@ class PreLnMlpFn(torch.autograd.Function):
         gemm(dh16[:M], weight_operand(w1, "bf16"), dln, b_kmajor=True)
         dw1, db1 = _wgrad(w1, b1, dh16, y16, M)
         dx, dgamma, dbeta = _ln_bwd_add(dln, x2, mean, rstd, gamma.detach(), eps, dy2, params=ctx.ln_params)
-        return dx.view(shp), None, None, dgamma, dbeta, dw1, db1, dw2, db2
+        return dx.view(shp), None, None, dgamma, dbeta, dw1, db1, dw2, db2, None
 
 
 def usable(prec: str, x: torch.Tensor) -> bool:

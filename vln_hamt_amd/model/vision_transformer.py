@@ -98,7 +98,7 @@ class Block(nn.Module):
             x = blocks_preln.PreLnAttnFn.apply(x, a.num_heads, pa, pd, self.norm1.eps, self.norm1.weight, self.norm1.bias,
                                                a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias)
             return blocks_preln.PreLnMlpFn.apply(x, md, self.norm2.eps, self.norm2.weight, self.norm2.bias,
-                                                 m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+                                                 m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, torch.is_grad_enabled())
         x = self.attn(ops.layer_norm(x, None, self.norm1, want16=True), residual=x)
         return self.mlp(ops.layer_norm(x, None, self.norm2, want16=True), residual=x)
 
