@@ -742,7 +742,7 @@ def test_attention_dropout_properties(prec, S):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("M,H,res", [(37, 768, True), (130, 128, False), (5, 1024, True), (1000, 768, True)])
+@pytest.mark.parametrize("M,H,res", [(37, 768, True), (130, 128, False), (5, 1024, True), (1000, 768, True), (5120, 768, True), (4101, 768, False), (4608, 256, True)])
 def test_ln_fwd_bwd(M, H, res):
     ops = _ops()
     x, r = rnd(M, H, seed=1), rnd(M, H, seed=2) if res else None
