@@ -47,7 +47,11 @@ class SplitGraph:
         global _skipped
         if not _skipped:      # (experiment: HAMT_BRANCH_SKIP=k takes k HIP streams out of torch's pool first, i.e. another hardware queue for the branch)
             _skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("HAMT_BRANCH_SKIP", 0)))] or [None]
-        self.branch = [streams.role_stream(dev, f"gbranch{i}") for i in range(1, self.n)]
+        # (measurement switches: HAMT_BRANCH_PRIORITY = 0 / -1 for the branch streams, HAMT_SPLIT_MAIN_HI=1 replays the main chain on a
+        # high-priority stream of its own -- does the critical chain get the CUs first when both chains have work?)
+        bp = os.environ.get("HAMT_BRANCH_PRIORITY")
+        self.branch = [streams.role_stream(dev, f"gbranch{i}", bp) for i in range(1, self.n)]
+        self.main_hi = streams.role_stream(dev, "gmain_hi", -1) if os.environ.get("HAMT_SPLIT_MAIN_HI") == "1" else None
         self._arr = (C.c_void_p * self.n)()
 
     def info(self):
@@ -76,13 +80,18 @@ class SplitGraph:
 
     def replay(self):
         from . import _lib as L
-        cur = torch.cuda.current_stream()
+        cur = outer = torch.cuda.current_stream()
+        if self.main_hi is not None:
+            self.main_hi.wait_stream(outer)
+            cur = self.main_hi
         self._arr[0] = cur.cuda_stream
         for i, st in enumerate(self.branch):
             if st.cuda_stream == cur.cuda_stream:
                 raise L.HamtError("SplitGraph.replay: the current stream is one of the split's branch streams")
             self._arr[i + 1] = st.cuda_stream
         L.check(L.load().hamt_graph_split_launch(self.h, self._arr, self.n), "hamt_graph_split_launch")
+        if self.main_hi is not None:
+            outer.wait_stream(self.main_hi)
 
     def __del__(self):
         try:
