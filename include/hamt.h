@@ -323,9 +323,10 @@ int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, 
 /* BertEmbeddings sum (A1, vilmodel.py:62-66): z[b*L+l] = word[ids[b,l]] + pos[l] + type0 */
 int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* word, const float* pos,
                        const float* type_row, float* z, void* stream);
-/* backward: dword[ids] += dz (atomic), dpos[l] += sum_b dz, dtype_row += sum dz */
+/* backward: dword[ids] += dz (atomic), dpos[l] += sum_b dz, dtype_row += sum dz (any of the three may be NULL);
+ * ws: HAMT_WS_COLSUM {B * L, H} bytes of scratch, needed when dtype_row is given */
 int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword,
-                       float* dpos, float* dtype_row, void* stream);
+                       float* dpos, float* dtype_row, float* ws, void* stream);
 
 /* broadcast row ops over x[B, S, H]:
  *   mean over the middle axis  (A11 vilmodel.py:563-564):  y[b,:] = mean_s x[b,s,:]

@@ -934,6 +934,28 @@ def test_embed_sum_and_gather_scatter_exact():
     assert torch.equal(bg.grad.cpu(), go)
 
 
+@pytest.mark.parametrize("B,L,H,V", [(64, 80, 768, 30522), (5, 33, 1024, 100), (2, 7, 132, 50), (3, 9, 1028, 40)])
+def test_embed_sum_bwd_shapes(B, L, H, V):
+    """hamt_embed_sum_bwd (the text embedder's backward: word rows by atomic adds, position sums through the slice-sum kernel, the
+    token-type row through the column-sum kernels) at the step's shape, at wide / narrow / odd-multiple rows, against fp64 autograd;
+    gradients ADD to what the tables' gradients hold."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    ids[0, :3] = 1
+    word, pos, typ = rnd(V, H, seed=1), rnd(L + 3, H, seed=2), rnd(2, H, seed=3)
+    w, p_, t = (x.to(DEV).requires_grad_(True) for x in (word, pos, typ))
+    go = rnd(B, L, H, seed=4)
+    for rep in range(2):          # second pass: accumulation into existing .grad (autograd adds the fresh tensors)
+        ops.embed_sum(ids.to(DEV), w, p_, t).backward(go.to(DEV))
+    wr, pr, tr = (x.clone().double().requires_grad_(True) for x in (word, pos, typ))
+    (2 * ((wr[ids] + pr[:L][None]) + tr[0][None, None])).backward(go.double())
+    close(w.grad, wr.grad, 2e-5, "dword")
+    close(p_.grad, pr.grad, 2e-5, "dpos")
+    close(t.grad, tr.grad, 2e-5, "dtype")
+    assert float(p_.grad[L:].abs().max()) == 0.0 and float(t.grad[1].abs().max()) == 0.0
+
+
 def test_mean_mulbcast_fill_add():
     ops = _ops()
     B, S, H = 5, 36, 128

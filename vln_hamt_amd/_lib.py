@@ -96,7 +96,7 @@ SIGNATURES = {
     "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
     "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
     "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
-    "hamt_embed_sum_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "hamt_embed_sum_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "hamt_mean_mid_fwd": [i32, i32, i32, vp, vp, vp],
     "hamt_mean_mid_bwd": [i32, i32, i32, vp, vp, vp],
     "hamt_mul_bcast_fwd": [i32, i32, i32, vp, vp, i32, vp, vp],

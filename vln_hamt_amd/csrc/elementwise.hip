@@ -286,15 +286,21 @@ extern "C" int hamt_sum_rows(int B, int S, int H, const float* x, int mode, floa
   HAMT_CHECK_LAUNCH("hamt_sum_rows");
   return HAMT_OK;
 }
+extern "C" int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate, float* ws, void* stream);
 extern "C" int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword, float* dpos,
-                                  float* dtype_row, void* stream) {
+                                  float* dtype_row, float* ws, void* stream) {
+  // Three passes over dz (16 MB at the step's shape, L2 / MALL resident), each on the kernel built for it: the word rows by atomic adds
+  // over the whole grid (a one-pass kernel with one block per position was measured: 87 us -- 80 blocks cannot issue 3.9 M atomics as
+  // fast as 15 000 can -- against 26 here), the positions by the slice-sum kernel (dz = B slices of L * H), the token-type row by the
+  // column-sum kernels.  The last two replaced a serial loop per thread (26 + 35 us) at the tail of the backward chain.
   HAMT_CHECK_ARG(ids && dz, "hamt_embed_sum_bwd: null pointer");
+  HAMT_CHECK_ARG(!dtype_row || ws, "hamt_embed_sum_bwd: dtype_row needs ws (HAMT_WS_COLSUM {B * L, H} bytes)");
   if (B * L == 0) return HAMT_OK;
   hipStream_t s = as_stream(stream);
   if (dword) hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(nblocks((size_t)B * L * H)), dim3(256), 0, s, B, L, H, ids, dz, dword);
-  if (dpos) hipLaunchKernelGGL(sum_over_b_kernel, dim3((L * H + 255) / 256), dim3(256), 0, s, B, L * H, dz, dpos);
-  (void)dtype_row;  // callers use hamt_sum_rows(mode 0) for the type row (needs a workspace)
+  if (dpos) hamt_reduce_partials(B, L * H, dz, dpos, 1, s);
   HAMT_CHECK_LAUNCH("hamt_embed_sum_bwd");
+  if (dtype_row) return hamt_colsum(B * L, H, dz, H, HAMT_F32, dtype_row, 1, ws, stream);
   return HAMT_OK;
 }
 extern "C" int hamt_mean_mid_fwd(int B, int S, int H, const float* x, float* y, void* stream) {

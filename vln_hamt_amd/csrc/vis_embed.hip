@@ -199,23 +199,39 @@ __global__ __launch_bounds__(64 * NWV) void vis_embed_bwd_kernel(hamt_vis_embed_
 
 struct VeOut { float* p[6]; };    // dgamma_img, dbeta_img, dgamma_ang, dbeta_ang, db_ang [H each], dW_ang [H][4]
 
-// ws[nb][VE_V][H] -> the six gradients (ADDED to what is there).  block = 64 columns x 4 partial-row phases.
+// ws[nb][VE_V][H] -> the six gradients (ADDED to what is there).  block = 64 columns (16 float4 lanes) x 16 partial-row phases.
 __global__ __launch_bounds__(256) void vis_embed_reduce_kernel(int nb, int H, const float* __restrict__ ws, VeOut out) {
-  const int l = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int l16 = threadIdx.x & 15, ph = threadIdx.x >> 4;
   const int per = H / 64;                          // blocks per vector
-  const int v = blockIdx.x / per, col = (blockIdx.x % per) * 64 + l;
-  float t = 0.f;
-  for (int b = ph; b < nb; b += 4) t += ws[((size_t)b * VE_V + v) * H + col];
-  __shared__ float red[4][64];
-  red[ph][l] = t;
+  const int v = blockIdx.x / per, col = (blockIdx.x % per) * 64 + l16 * 4;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = ph; b0 < nb; b0 += 64) {           // 4 independent loads per trip
+    float4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + 16 * u;
+      q[u] = b < nb ? *(const float4*)(ws + ((size_t)b * VE_V + v) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { t.x += q[u].x; t.y += q[u].y; t.z += q[u].z; t.w += q[u].w; }
+  }
+  __shared__ float4 red[16][16];
+  red[ph][l16] = t;
   __syncthreads();
   if (ph == 0) {
-    t = red[0][l] + red[1][l] + red[2][l] + red[3][l];
-    if (v == 0) out.p[0][col] += t;
-    else if (v == 1) { if (out.p[1]) out.p[1][col] += t; if (out.p[3]) out.p[3][col] += t; }
-    else if (v == 2) out.p[2][col] += t;
-    else if (v == 3) out.p[4][col] += t;
-    else out.p[5][(size_t)col * VE_A + (v - 4)] += t;
+    t = red[0][l16];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { const float4 r = red[i][l16]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+    const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = col + k;
+      if (v == 0) out.p[0][c] += e[k];
+      else if (v == 1) { if (out.p[1]) out.p[1][c] += e[k]; if (out.p[3]) out.p[3][c] += e[k]; }
+      else if (v == 2) out.p[2][c] += e[k];
+      else if (v == 3) out.p[4][c] += e[k];
+      else out.p[5][(size_t)c * VE_A + (v - 4)] += e[k];
+    }
   }
 }
 

@@ -815,9 +815,9 @@ class EmbedSumFn(torch.autograd.Function):
         dword, dpos, dtyp = outs
         if any(r is None for r in rets):
             wgrad.queue(dev).current()              # (opens the pass: orders this stream behind an overlapped optimizer update)
-        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, _p(ids), _p(dz), _p(dword), _p(dpos), None, _stream()), "hamt_embed_sum_bwd")
-        ws = torch.empty(64 * H, dtype=torch.float32, device=dev)
-        L.check(L.load().hamt_sum_rows(B, Lq, H, _p(dz), 0, _p(dtyp), _p(ws), _stream()), "hamt_sum_rows")  # row 0 of the type table
+        ws = torch.empty(L.workspace_bytes(L.WS_COLSUM, B * Lq, H) // 4, dtype=torch.float32, device=dev)
+        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, _p(ids), _p(dz), _p(dword), _p(dpos), _p(dtyp), _p(ws), _stream()),
+                "hamt_embed_sum_bwd")      # (dtyp: row 0 of the type table)
         for p, r, o in zip(ctx.tables, rets, outs):
             if r is None:
                 wgrad.publish_slot_grad(p, o)
