@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
 // split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
-constexpr int WG_MAX = 48;                       // table entries carried by one kernarg block (80 bytes each, < 4 KiB)
+constexpr int WG_MAX = 256;                      // table entries carried by one kernarg block (80 bytes each: 20 KiB of kernarg, one launch for ~250 units)
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db; float* ss;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=, >> 8 = ss slots per 64-row band; tile_end = exclusive prefix end
@@ -1331,7 +1331,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
       WgradChunk ch;
       const int cnt = std::min(WG_MAX, cn - b0);
       for (int i = 0; i < cnt; ++i) ch.p[i] = flat[b0 + i];
-      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, ch, tab, off + b0, cnt);
+      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(WG_MAX), 0, s, ch, tab, off + b0, cnt);
     }
     const dim3 grid(8 * max_tiles);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
