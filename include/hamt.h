@@ -432,7 +432,10 @@ int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g, float* m,
  * parameters): for slots whose producer overwrites them (the grouped weight-gradient launch stores, it does not accumulate).
  * hamt_sumsq_table: sum(g^2) over the ACTIVE parameters of the arena elements [first, first + n) (g points at element `first`;
  * same `ends` / `hyp` tables): the global-norm reduction that goes with it -- slots of inactive parameters are not read,
- * whatever they hold (torch clip_grad_norm_ over the parameters that have a gradient, main_r2r.py:271-273).  ws: 1024 floats. */
+ * whatever they hold (torch clip_grad_norm_ over the parameters that have a gradient, main_r2r.py:271-273).  ws: 1024 floats.
+ * accumulate: bit 0 = add to *out; bit 1 (HAMT_SUMSQ_SPARSE) = most of the range is inactive / skipped: the active elements are
+ * spread evenly over the blocks (for a mostly active range the plain element ranges are faster). */
+#define HAMT_SUMSQ_SPARSE 2
 int hamt_sumsq_table(size_t first, size_t n, const float* g, const int* ends, const float* hyp, int nparams,
                      float* out, int accumulate, float* ws, void* stream);
 /* active == 3: like 2, and hamt_sumsq_table skips the parameter as well -- its sum of squares comes from the weight-gradient

@@ -1160,6 +1160,38 @@ def test_wire_unpack_sumsq():
     assert abs(float(out) - want) <= 1e-5 * want, (float(out), want)
 
 
+@pytest.mark.parametrize("sparse", [0, 2])
+@pytest.mark.parametrize("nparams", [5, 300, 1500])
+def test_sumsq_table_active_only(sparse, nparams):
+    """hamt_sumsq_table over an arena range that starts and ends inside parameters, with every kind of table flag (0 = no gradient: the
+    slot holds NaN; 1 / 2 active; 3 = accounted for by the weight-gradient tiles), plain element ranges and HAMT_SUMSQ_SPARSE (active
+    elements spread evenly over the blocks: the GEMM-weight region of a step) against fp64."""
+    from vln_hamt_amd import _lib as L
+    ops = _ops()
+    rs = np.random.RandomState(nparams)
+    sizes = (rs.randint(1, 2000, size=nparams) * 4).tolist()
+    flags = rs.choice([0.0, 1.0, 2.0, 3.0], size=nparams, p=[0.3, 0.1, 0.1, 0.5]).tolist()
+    ends = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device=DEV)
+    hyp = torch.zeros(nparams, 4, device=DEV)
+    hyp[:, 3] = torch.tensor(flags)
+    n_all = sum(sizes)
+    g = rnd(n_all, seed=5).to(DEV)
+    act = torch.cat([torch.full((sz,), f in (1.0, 2.0)) for sz, f in zip(sizes, flags)]).to(DEV)
+    dead = torch.cat([torch.full((sz,), f == 0.0) for sz, f in zip(sizes, flags)]).to(DEV)
+    g[dead] = float("nan")
+    first = (sizes[0] // 8) * 4
+    n = n_all - first - (sizes[-1] // 8) * 4
+    out = torch.full((1,), 2.0, device=DEV)
+    ws = torch.empty(1024, device=DEV)
+    L.check(L.load().hamt_sumsq_table(first, n, ops._p(g[first:first + n]), ops._p(ends), ops._p(hyp), nparams, ops._p(out), 1 | sparse,
+                                      ops._p(ws), ops._stream()), "hamt_sumsq_table")
+    want = 2.0 + float((g.double() ** 2)[first:first + n][act[first:first + n]].sum())
+    assert abs(float(out) - want) <= 1e-5 * want, (float(out), want)
+    L.check(L.load().hamt_sumsq_table(first, n, ops._p(g[first:first + n]), ops._p(ends), ops._p(hyp), nparams, ops._p(out), sparse,
+                                      ops._p(ws), ops._stream()), "hamt_sumsq_table")
+    assert abs(float(out) - (want - 2.0)) <= 1e-5 * want, (float(out), want - 2.0)
+
+
 @pytest.mark.parametrize("normalize", ["total", "batch", "none"])
 @pytest.mark.parametrize("feedback", ["sample", "teacher"])
 def test_a2c_loss_vs_reference_goldens(normalize, feedback):

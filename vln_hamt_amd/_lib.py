@@ -16,6 +16,7 @@ HAMT_F32, HAMT_BF16 = 0, 1
 PREC_BF16, PREC_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_ACCUM, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_GRAD, EPI_MUL_AUX, EPI_ADD_AUX, EPI_DROPOUT = 128, 256, 512, 1024
+SUMSQ_SPARSE = 2            # HAMT_SUMSQ_SPARSE (hamt_sumsq_table's `accumulate`, bit 1)
 
 vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 

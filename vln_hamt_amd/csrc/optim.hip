@@ -170,6 +170,74 @@ __global__ __launch_bounds__(256) void sumsq_table_partial_kernel(size_t n, cons
   __syncthreads();
   if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// The same sum with the ACTIVE elements spread evenly over the blocks.  When most of a range is skipped (the GEMM-weight region once the
+// weight-gradient tiles carry their own sums: what is left are the few weights written twice in a pass, ~6 % of the range in a handful
+// of places) the uniform element ranges above leave ~60 of 1024 blocks with all the reading: 42 us for 38 MB.  Here every block builds
+// the prefix sums of the active lengths (nparams <= SS_NP_MAX entries, LDS), takes an equal share of the active float4s and maps it
+// back to arena offsets.  Same determinism: a fixed partition for a given table, partials summed in block order.
+constexpr int SS_NP_MAX = 2048;
+__global__ __launch_bounds__(256) void sumsq_table_balanced_kernel(size_t n, const float* __restrict__ g, const int* __restrict__ ends,
+                                                                   const float4* __restrict__ hyp, int nparams, size_t first4,
+                                                                   float* __restrict__ ws) {
+  __shared__ unsigned pref[SS_NP_MAX + 1];      // pref[i] = active float4s of parameters [0, i) inside the range
+  __shared__ unsigned tsum[256];
+  const size_t n4 = n >> 2, r_lo = first4, r_hi = first4 + n4;
+  const int t = threadIdx.x, per = (nparams + 255) / 256;
+  unsigned loc = 0;
+  for (int k = 0; k < per; ++k) {
+    const int pi = t * per + k;
+    unsigned len = 0;
+    if (pi < nparams) {
+      const size_t a = pi ? (size_t)ends[pi - 1] >> 2 : 0, b = (size_t)ends[pi] >> 2;
+      const size_t lo = a > r_lo ? a : r_lo, hi = b < r_hi ? b : r_hi;
+      const float act = hyp[pi].w;
+      if (hi > lo && act != 0.f && act != 3.f) len = (unsigned)(hi - lo);
+      pref[pi + 1] = len;                       // (own length for now)
+    }
+    loc += len;
+  }
+  tsum[t] = loc;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {           // inclusive scan of the 256 thread sums
+    const unsigned v = t >= o ? tsum[t - o] : 0u;
+    __syncthreads();
+    tsum[t] += v;
+    __syncthreads();
+  }
+  unsigned run = t ? tsum[t - 1] : 0u;
+  if (t == 0) pref[0] = 0;
+  for (int k = 0; k < per; ++k) {
+    const int pi = t * per + k;
+    if (pi < nparams) { run += pref[pi + 1]; pref[pi + 1] = run; }
+  }
+  __syncthreads();
+  const unsigned total = pref[nparams];
+  const unsigned share = (total + gridDim.x - 1) / gridDim.x;
+  const unsigned lo = min(total, blockIdx.x * share), hi = min(total, lo + share);
+  float s = 0.f;
+  if (hi > lo) {
+    int a = 0, b = nparams - 1;                 // first parameter whose prefix end lies behind lo
+    while (a < b) { const int mid = (a + b) >> 1; if (pref[mid + 1] > lo) b = mid; else a = mid + 1; }
+    for (int pi = a; pi < nparams && pref[pi] < hi; ++pi) {
+      if (pref[pi + 1] == pref[pi]) continue;
+      const size_t pa = pi ? (size_t)ends[pi - 1] >> 2 : 0;
+      const size_t base = (pa > r_lo ? pa : r_lo) - r_lo;                 // float4 offset of the parameter's first in-range element in g
+      const unsigned o0 = max(lo, pref[pi]) - pref[pi], o1 = min(hi, pref[pi + 1]) - pref[pi];
+      for (size_t i = base + o0 + t; i < base + o1; i += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + (size_t)u * 256 < base + o1 ? ((const float4*)g)[i + (size_t)u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+      }
+    }
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 // The same walk fused with the widening of a reduce-scattered bf16 gradient chunk: g[i] = float(y16[i]) for EVERY element of the
 // chunk, sum of squares over the active parameters only -- one pass instead of hamt_wire_unpack_bf16 followed by hamt_sumsq_table
 // (the exchange of a data-parallel step runs this once per arena range, behind the range's reduce-scatter).
@@ -235,7 +303,14 @@ extern "C" int hamt_sumsq_table(size_t first, size_t n, const float* g, const in
   hipStream_t s = as_stream(stream);
   size_t b = (n / 4 + 1023) / 1024;
   int nb = (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
-  hipLaunchKernelGGL(sumsq_table_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ends, (const float4*)hyp, nparams, first / 4, ws);
+  static const bool balanced = getenv("HAMT_SUMSQ_UNBALANCED") == nullptr;
+  const bool sparse = (accumulate & HAMT_SUMSQ_SPARSE) != 0;
+  accumulate &= 1;
+  if (sparse && balanced && nparams <= SS_NP_MAX && n / 4 < ((size_t)1 << 32)) {
+    nb = nb < 512 ? nb : 512;
+    hipLaunchKernelGGL(sumsq_table_balanced_kernel, dim3(nb), dim3(256), 0, s, n, g, ends, (const float4*)hyp, nparams, first / 4, ws);
+  } else
+    hipLaunchKernelGGL(sumsq_table_partial_kernel, dim3(nb), dim3(256), 0, s, n, g, ends, (const float4*)hyp, nparams, first / 4, ws);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, nb, ws, out, accumulate);
   HAMT_CHECK_LAUNCH("hamt_sumsq_table");
   return HAMT_OK;

@@ -307,7 +307,7 @@ class AdamW(Optimizer):
         lib = L.load()
         if 0 < n_a < self._n:
             L.check(lib.hamt_sumsq_table(0, n_a, _p(self._flat_g), _p(self._ends), _p(self._hyp), len(self._params),
-                                         _p(self._gnorm), 0, _p(self._ws), _stream()), "hamt_sumsq_table")
+                                         _p(self._gnorm), L.SUMSQ_SPARSE if self._fused is not None else 0, _p(self._ws), _stream()), "hamt_sumsq_table")
             L.check(lib.hamt_sumsq_table(n_a, self._n - n_a, _p(self._flat_g[n_a:]), _p(self._ends), _p(self._hyp), len(self._params),
                                          _p(self._gnorm), 1, _p(self._ws), _stream()), "hamt_sumsq_table")
         else:
