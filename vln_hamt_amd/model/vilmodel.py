@@ -553,7 +553,7 @@ class HistoryEmbeddings(nn.Module):
         dev = self.device
         H = self.cls_token.shape[-1]
         zeros_b = torch.zeros(batch_size, dtype=torch.long, device=dev)
-        cls = ops.gather_rows(self.cls_token.view(1, H), zeros_b)
+        cls = ops.gather_rows(self.cls_token, zeros_b)        # (the parameter itself, [1, 1, H]: its gradient rows go straight into its arena slot)
         cls = ops.gather_rows(self.type_embedding.weight, zeros_b, base=cls)
         cls = ops.layer_norm(cls.view(batch_size, 1, H), None, self.layer_norm, p_post=_p(self.dropout, self))
         if img_feats is None:

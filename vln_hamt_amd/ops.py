@@ -324,6 +324,23 @@ def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=No
         if wgrad.eligible(weight, dy16[:, :N], x16):    # queued for the grouped end-of-pass launch (wgrad.py); db rides along
             wgrad.defer(weight, bias_param if need_db else None, dy16[:, :N], x16)
             return dx, None, None
+    slot_w = _accum_slot(weight) if (need_dw and not (K <= 8)) else None
+    if slot_w is not None:
+        # a parameter outside the grouped launch (the fp32 prediction heads) that owns a zero-at-the-start-of-a-step slot in the
+        # optimizer's gradient arena: ADD dW (and db) there -- no autograd tensor for optim.AdamW._pack_grads to copy in afterwards
+        from . import wgrad
+        wgrad.queue(dy2.device).current()
+        if fast:
+            gemm(dy16[:, :N], x16, slot_w, a_kmajor=True, b_kmajor=True, prec=prec, epilogue=L.EPI_ACCUM)
+        else:
+            gemm(dy2, x2 if x2 is not None else x16[:M], slot_w, a_kmajor=True, b_kmajor=True, prec=prec, epilogue=L.EPI_ACCUM)
+        wgrad.publish_slot_grad(weight, slot_w)
+        need_dw = False
+        slot_b = _accum_slot(bias_param) if (need_db and torch.is_tensor(bias_param)) else None
+        if slot_b is not None:
+            colsum(dy2, out=slot_b, accumulate=True)
+            wgrad.publish_slot_grad(bias_param, slot_b)
+            need_db = False
     if need_dw:
         dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
         if fast:
@@ -336,6 +353,22 @@ def _linear_bwd(dy2, x2, x16, weight, prec, need_dx, need_dw, need_db, dx_out=No
     if need_db:
         db = colsum(dy2)
     return dx, dw, db
+
+
+SLOT_ACCUM = os.environ.get("HAMT_NO_SLOT_ACCUM") is None
+
+
+def _accum_slot(p):
+    """p's slot in the optimizer's flat gradient arena if a producer may ADD into it during this backward pass (a leaf parameter
+    whose slot the update kernel leaves zero, inside a pass, .grad unset or already the slot), else None."""
+    if p is None or not torch.is_tensor(p) or not p.is_leaf or not p.requires_grad or not SLOT_ACCUM:
+        return None
+    from . import wgrad
+    slot = getattr(p, "_hamt_grad_slot", None)
+    if (slot is None or not wgrad.ENABLED or torch._C._current_graph_task_id() < 0 or slot.shape != p.shape or not slot.is_contiguous()
+            or not getattr(p, "_hamt_slot_zeroed", False) or not (p.grad is None or p.grad.data_ptr() == slot.data_ptr())):
+        return None
+    return slot
 
 
 # ------------------------------------------------------------------------------------------ Linear
@@ -674,10 +707,13 @@ VIS_EMBED = os.environ.get("HAMT_VIS_EMBED", "1") == "1"
 VIS_EMBED_X16 = os.environ.get("HAMT_VIS_EMBED_X16", "0") == "1"
 
 
+SLOT_ACCUM_VE = os.environ.get("HAMT_VIS_EMBED_NO_SLOT") is None
+
+
 def _grad_dst(p, shape, dev, in_pass):
     """-> (tensor the kernel ADDS p's gradient to, what backward returns for p): p's slot in the optimizer's gradient arena (zero at
     the start of a step; published as `.grad` at the end of the pass, as ops.GatherRowsFn does) or a fresh zero tensor."""
-    slot = getattr(p, "_hamt_grad_slot", None) if (in_pass and p is not None and p.is_leaf and p.requires_grad) else None
+    slot = getattr(p, "_hamt_grad_slot", None) if (in_pass and p is not None and p.is_leaf and p.requires_grad and SLOT_ACCUM_VE) else None
     if (slot is not None and slot.shape == p.shape and slot.is_contiguous() and getattr(p, "_hamt_slot_zeroed", False)
             and (p.grad is None or p.grad.data_ptr() == slot.data_ptr())):
         return slot, None
