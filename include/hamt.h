@@ -319,6 +319,10 @@ int hamt_gather_rows(int R, int W, const float* src, int ld_src, const int64_t* 
                      int ld_base, float* out, int ld_out, int col0, void* stream);
 int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
                           float* dst, int ld_dst, void* stream);
+/* the same for a CONTIGUOUS table dst[T][W] of T <= 8 rows (idx must be given): fixed-order sums instead of atomics -- the table's
+ * gradient is then bit-reproducible.  ws: 64 * T * W floats. */
+int hamt_scatter_add_rows_small(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, int T, float* dst,
+                                float* ws, void* stream);
 
 /* BertEmbeddings sum (A1, vilmodel.py:62-66): z[b*L+l] = word[ids[b,l]] + pos[l] + type0 */
 int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* word, const float* pos,

@@ -932,6 +932,22 @@ def test_embed_sum_and_gather_scatter_exact():
     (tr_[idx]).backward(go.double())
     close(tg.grad, tr_.grad, 1e-5, "gather dtab")
     assert torch.equal(bg.grad.cpu(), go)
+    # a table of a few rows gathered by many rows (token / navigability types): fixed-order sums, bit-reproducible
+    for T, R in ((3, 2368), (1, 64), (8, 5000)):
+        tab = rnd(T, H, seed=8)
+        idx = torch.randint(0, T, (R,), generator=g)
+        go = rnd(R, H, seed=9)
+        grads = []
+        for rep in range(3):
+            tg = tab.to(DEV).requires_grad_(True)
+            junk = torch.randn(1000 * (rep + 1), device=DEV)      # (another allocator state per repetition)
+            ops.gather_rows(tg, idx.to(DEV)).backward(go.to(DEV))
+            grads.append(tg.grad.clone())
+            del junk
+        tr_ = tab.clone().double().requires_grad_(True)
+        (tr_[idx]).backward(go.double())
+        close(grads[0], tr_.grad, 1e-5, f"small-table dtab T={T}")
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), "small-table scatter is not bit-reproducible"
 
 
 @pytest.mark.parametrize("B,L,H,V", [(64, 80, 768, 30522), (5, 33, 1024, 100), (2, 7, 132, 50), (3, 9, 1028, 40)])

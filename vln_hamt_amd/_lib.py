@@ -96,6 +96,7 @@ SIGNATURES = {
     "hamt_ln_bwd_reduce_grouped": [i32, vp, vp, sz, vp],
     "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
     "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
+    "hamt_scatter_add_rows_small": [i32, i32, vp, i32, i32, vp, i32, vp, vp, vp],
     "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "hamt_embed_sum_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "hamt_mean_mid_fwd": [i32, i32, i32, vp, vp, vp],

@@ -252,6 +252,46 @@ extern "C" int hamt_gather_rows(int R, int W, const float* src, int ld_src, cons
   HAMT_CHECK_LAUNCH("hamt_gather_rows");
   return HAMT_OK;
 }
+// A table of a few rows (token types, navigability types, a cls token: T <= 8) gathered by thousands of rows: the atomic scatter above
+// adds them in whatever order the hardware serves the collisions, i.e. the table's gradient differs in the last bit from run to run.
+// Here every block sums its chunk of source rows per table row in a fixed order (block = 64 columns x 4 row phases, T accumulators
+// per thread), and the chunks are summed in order by hamt_reduce_partials: deterministic, and no serialised atomics.
+constexpr int SCAT_T_MAX = 8;
+__global__ __launch_bounds__(256) void scatter_small_partial_kernel(int R, int W, int T, const float* __restrict__ src, int ld_src, int col0,
+                                                                    const int64_t* __restrict__ idx, float* __restrict__ ws, int rows_per_chunk) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float acc[SCAT_T_MAX];
+#pragma unroll
+  for (int t = 0; t < SCAT_T_MAX; ++t) acc[t] = 0.f;
+  if (col < W)
+    for (int r = r0 + ph; r < r1; r += 4) {
+      const int t_of = (int)idx[r];
+      const float v = src[(size_t)r * ld_src + col0 + col];
+#pragma unroll
+      for (int t = 0; t < SCAT_T_MAX; ++t) acc[t] += t == t_of ? v : 0.f;
+    }
+  __shared__ float red[4][64];
+  for (int t = 0; t < T; ++t) {
+    red[ph][threadIdx.x & 63] = acc[t];
+    __syncthreads();
+    if (ph == 0 && col < W)
+      ws[((size_t)blockIdx.y * T + t) * W + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+extern "C" int hamt_scatter_add_rows_small(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, int T, float* dst,
+                                           float* ws, void* stream) {
+  HAMT_CHECK_ARG(src && dst && idx && ws && T >= 1 && T <= SCAT_T_MAX, "hamt_scatter_add_rows_small: bad argument (1 <= T <= %d table rows)", SCAT_T_MAX);
+  if (R == 0) return HAMT_OK;
+  hipStream_t s = as_stream(stream);
+  int chunks = R >= 64 * 64 ? 64 : (R + 63) / 64;
+  const int rpc = (R + chunks - 1) / chunks;
+  hipLaunchKernelGGL(scatter_small_partial_kernel, dim3((W + 63) / 64, chunks), dim3(256), 0, s, R, W, T, src, ld_src, col0, idx, ws, rpc);
+  hamt_reduce_partials(chunks, T * W, ws, dst, 1, s);
+  HAMT_CHECK_LAUNCH("hamt_scatter_add_rows_small");
+  return HAMT_OK;
+}
 extern "C" int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst,
                                      int ld_dst, void* stream) {
   HAMT_CHECK_ARG(src && dst, "hamt_scatter_add_rows: null pointer");

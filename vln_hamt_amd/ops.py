@@ -860,6 +860,17 @@ class EmbedSumFn(torch.autograd.Function):
         return None, rets[0], rets[1], rets[2]
 
 
+def _scatter_add(R, W, dout, idx, table):
+    """table[idx[r]] += dout[r]: tables of a few rows (token / navigability types, the cls token) by fixed-order sums
+    (hamt_scatter_add_rows_small: bit-reproducible), anything else by atomics"""
+    T = table.numel() // W
+    if T <= 8 and table.is_contiguous():
+        ws = torch.empty(64 * T * W, dtype=torch.float32, device=dout.device)
+        L.check(L.load().hamt_scatter_add_rows_small(R, W, _p(dout), W, 0, _p(idx), T, _p(table), _p(ws), _stream()), "hamt_scatter_add_rows_small")
+    else:
+        L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(table), W, _stream()), "hamt_scatter_add_rows")
+
+
 class GatherRowsFn(torch.autograd.Function):
     """out[r] = (base[r] if base is not None else 0) + table[idx[r]]  over rows of width W.
     Serves embedding lookups, boolean-mask compaction, anchor gathers and slices (idx arithmetic)."""
@@ -898,11 +909,11 @@ class GatherRowsFn(torch.autograd.Function):
                 # there -- no 94 MB zero fill for the 30 522 x 768 word table, no copy into the arena afterwards; published as
                 # `.grad` at the end of the pass (the tied MLM decoder's queued weight gradient then accumulates on top)
                 wgrad.queue(slot.device).current()         # (opens the pass: orders this stream behind an overlapped optimizer update)
-                L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(slot), W, _stream()), "hamt_scatter_add_rows")
+                _scatter_add(R, W, dout, idx, slot)
                 wgrad.publish_slot_grad(p, slot)
             else:
                 dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
-                L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(dtab), W, _stream()), "hamt_scatter_add_rows")
+                _scatter_add(R, W, dout, idx, dtab)
         return dtab, None, (dout.view(ctx.bshape) if ctx.has_base else None)
 
 
