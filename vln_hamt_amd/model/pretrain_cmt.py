@@ -173,7 +173,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                                                        hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
                                                        ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
         B, L, H = txt_embeds.shape
-        cls_rows = torch.arange(B, device=txt_embeds.device) * L
+        cls_rows = ops.const_index("arange_mul", int(B), int(L), device=txt_embeds.device)
         prediction_scores = self.regress_action(ops.gather_rows(txt_embeds.reshape(B * L, H), cls_rows))
         if compute_loss:
             act_targets = torch.cat([ob_act_angles, ob_progress.unsqueeze(1)], dim=1)
@@ -188,13 +188,13 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                                                        ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
         B, S, H = ob_embeds.shape                                  # S = 37; the reference hard-codes 36 views (:211-212)
         flat = ob_embeds.reshape(B * S, H)
-        base = torch.arange(B, device=flat.device) * S
+        base = ops.const_index("arange_mul", int(B), int(S), device=flat.device)
         # the anchor view's embedding next to each of the 36 views (:211-214).  One row per sample is gathered and BROADCAST: the backward
         # is a sum over the 36 copies and one add per anchor row -- a gather of 36 repeated indices would scatter-add 36 atomics into
         # the same row in whatever order they land, and the bf16 images downstream re-round that noise into every weight gradient
         # (run-to-run differences of up to 5e-3 of a gradient's largest element at small batches: tools/determinism_check.py)
         anchor = ops.gather_rows(flat, base + sp_anchor_idxs)
-        rest = ops.gather_rows(flat, (base[:, None] + torch.arange(S - 1, device=flat.device)[None]).reshape(-1))
+        rest = ops.gather_rows(flat, ops.const_index("rows_but_last", int(B), int(S), device=flat.device))
         cat_ob_embeds = torch.cat([anchor[:, None].expand(B, S - 1, H), rest.view(B, S - 1, H)], -1)
         prediction_scores = self.sprel_head(cat_ob_embeds)
         if compute_loss:
@@ -226,7 +226,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                                              hist_pano_ang_fts, hist_masks, num_neg_trajs=num_neg_trajs,
                                              neg_idxs=neg_idxs, shuffled_pos_ids=shuffled_pos_ids)
         prediction_scores = self.itm_head(fused_embeds).squeeze(2)
-        itm_targets = torch.zeros(fused_embeds.size(0), dtype=torch.long, device=fused_embeds.device)
+        itm_targets = ops.const_index("zeros", int(fused_embeds.size(0)), device=fused_embeds.device)
         if compute_loss:
             return ops.cross_entropy(prediction_scores, itm_targets)
         return prediction_scores, itm_targets

@@ -460,7 +460,7 @@ class LxmertEncoder(nn.Module):
 
 def _bcast_rows(n_outer: int, n_inner: int, device):
     """row -> outer index map for broadcasting a (n_outer, H) table over n_inner rows each."""
-    return torch.arange(n_outer, device=device).repeat_interleave(n_inner)
+    return ops.const_index("bcast", int(n_outer), int(n_inner), device=device)
 
 
 class _VisualLinears(nn.Module):
@@ -552,7 +552,7 @@ class HistoryEmbeddings(nn.Module):
         """forward() as a chain of units for streams.interleave (yields each unit's cost, returns forward()'s result)"""
         dev = self.device
         H = self.cls_token.shape[-1]
-        zeros_b = torch.zeros(batch_size, dtype=torch.long, device=dev)
+        zeros_b = ops.const_index("zeros", int(batch_size), device=dev)
         cls = ops.gather_rows(self.cls_token, zeros_b)        # (the parameter itself, [1, 1, H]: its gradient rows go straight into its arena slot)
         cls = ops.gather_rows(self.type_embedding.weight, zeros_b, base=cls)
         cls = ops.layer_norm(cls.view(batch_size, 1, H), None, self.layer_norm, p_post=_p(self.dropout, self))
@@ -561,7 +561,7 @@ class HistoryEmbeddings(nn.Module):
         B, T = img_feats.shape[:2]
         e = _VisualLinears.two_stream(self.img_linear, self.img_layer_norm, self.ang_linear, self.ang_layer_norm,
                                       img_feats, ang_feats, self.prec)
-        e = ops.gather_rows(self.type_embedding.weight, torch.zeros(B * T, dtype=torch.long, device=dev), base=e)
+        e = ops.gather_rows(self.type_embedding.weight, ops.const_index("zeros", int(B * T), device=dev), base=e)
         yield B * T
         if self.pano_encoder is not None:
             V = pano_img_feats.shape[2]
@@ -660,14 +660,14 @@ class NavPreTrainedModel(BertPreTrainedModel):
         def vision_units():
             step_ids = None
             if hist_img_feats is not None:
-                step_ids = torch.arange(hist_img_feats.size(1), device=txt_ids.device)[None]
+                step_ids = ops.const_index("arange", int(hist_img_feats.size(1)), device=txt_ids.device)[None]
             streams.gate(self.hist_embeddings)
             cls, steps = yield from self.hist_embeddings.forward_units(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
                                                                        step_ids, batch_size=B)
             hist = cls if steps is None else torch.cat([cls, steps], 1)
             ob = None
             if ob_img_feats is not None:
-                ones = torch.ones(B, dtype=torch.long, device=txt_ids.device)
+                ones = ops.const_index("ones", int(B), device=txt_ids.device)
                 streams.gate(self.embeddings.token_type_embeddings.weight)
                 tt = ops.gather_rows(self.embeddings.token_type_embeddings.weight, ones).view(B, 1, -1)
                 ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)

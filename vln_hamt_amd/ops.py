@@ -921,6 +921,43 @@ def gather_rows(table, idx, base=None):
     return GatherRowsFn.apply(table, idx, base)
 
 
+_CONST_IDX: dict = {}
+
+
+def const_index(kind: str, *args, device) -> torch.Tensor:
+    """A constant int64 index tensor, built once per (kind, arguments, device) and never modified: `zeros` n / `ones` n / `arange` n
+    (0 .. n-1) / `arange_mul` (n, k) = arange(n) * k / `bcast` (n_outer, n_inner) = row -> outer index / `rows_but_last` (B, S) = b * S +
+    s for s < S - 1.  A forward pass used to rebuild these with 1-3 tiny fill / arange / multiply launches each, every step (and every
+    replay of a captured step)."""
+    key = (kind, args, str(torch.device(device)))
+    t = _CONST_IDX.get(key)
+    if t is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():      # (first use inside a capture: no persistent memory there)
+            return _build_const(kind, args, device)
+        with torch.no_grad():
+            t = _CONST_IDX[key] = _build_const(kind, args, device)
+        if t.is_cuda:       # (once per constant: whichever stream uses it next finds it written)
+            torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
+def _build_const(kind, args, device):
+    if kind == "zeros":
+        return torch.zeros(args[0], dtype=torch.long, device=device)
+    if kind == "ones":
+        return torch.ones(args[0], dtype=torch.long, device=device)
+    if kind == "arange":
+        return torch.arange(args[0], dtype=torch.long, device=device)
+    if kind == "arange_mul":
+        return torch.arange(args[0], dtype=torch.long, device=device) * args[1]
+    if kind == "bcast":
+        return torch.arange(args[0], device=device).repeat_interleave(args[1])
+    if kind == "rows_but_last":
+        B, S = args
+        return (torch.arange(B, device=device)[:, None] * S + torch.arange(S - 1, device=device)[None]).reshape(-1)
+    raise ValueError(kind)
+
+
 @torch.no_grad()
 def extend_mask(mask: torch.Tensor) -> torch.Tensor:
     """(B, S) bool keep-mask -> additive (B, 1, 1, S) fp32 = (1 - m) * -10000 (vilmodel.py:597-599) in one launch"""
