@@ -1243,7 +1243,11 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     long t256 = 0;
     for (int i : cls[0]) t256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
     // too few 256-square tiles to occupy half the chip: use the smaller tiles for everything
-    if (force == 128 || force == 64 || (t256 < 128 && force != 256)) { cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
+    const char* menv = getenv("HAMT_WGRAD_MIN256");     // tuning: fewest 256-square tiles for which the 256-square launch is used (read per call)
+    // (fewer than one tile per CU: the 64-row tiles fill the chip better -- the second use of the shared cross-attention weights in an ITM
+    // step, 144 tiles of 256 x 256 with reductions of up to 25 600 rows: 785 us against 496 with 64 x 128 tiles; 128 was the threshold before)
+    const long min256 = menv && atoi(menv) > 0 ? atoi(menv) : 256;
+    if (force == 128 || force == 64 || (t256 < min256 && force != 256)) { cls[1].insert(cls[1].end(), cls[0].begin(), cls[0].end()); cls[0].clear(); }
   }
   WgradProb* tab = (WgradProb*)table;
   int off = 0;
@@ -1257,7 +1261,8 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
       t256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
     }
     // 256-square tiles (one 8-wave workgroup per CU) when they still give every CU >= 3 tiles; else 128 / 64 rows
-    int bm = c == 0 ? 256 : (t128 >= 1024 ? 128 : 64);
+    const char* m128 = getenv("HAMT_WGRAD_MIN128");     // tuning: fewest 128-square tiles for which 128-row tiles are used (read per call)
+    int bm = c == 0 ? 256 : (t128 >= (m128 && atoi(m128) > 0 ? atoi(m128) : 1024) ? 128 : 64);
     if (force == 128 || force == 64) bm = force;
     const int bn = bm == 256 ? 256 : 128;
     // units: a problem, or rectangles of r x c tiles of a problem with many tiles (so that one XCD's share stays ~<= 12 tiles).  A unit's
