@@ -151,11 +151,18 @@ typedef struct {
                      * tile stores bf16(wire_scale * dW) -- the value a data-parallel gradient exchange puts on the wire (the stock DDP
                      * bf16_compress_hook's: divide by the world size, round to bf16), written straight from the accumulators instead
                      * of an fp32 store followed by a pack pass over the arena.  Store only (accum_dw must be 0), `ss` is ignored. */
+  /* Optional SECOND pair of operands reduced into the same dW / db in the same launch: dW (+)= dy^T x + dy2^T x2 (a parameter used
+   * twice in a pass -- the cross-attention weights LXRTXLayer shares between its two directions, vilmodel.py:401-412 -- as ONE problem
+   * instead of a second, accumulating launch behind the first).  dy2 == NULL: none.  Same requirements as dy / x (K2 % 64 == 0, ...);
+   * K_valid must be 0 or K (no ragged tail between the two reductions), K2_valid as K_valid; wire_scale must be 0. */
+  const void* dy2;
+  const void* x2;
+  int K2, ldy2, ldx2, K2_valid;
 } hamt_wgrad_desc;
 /* `table`: caller-provided DEVICE scratch (16-byte aligned) that holds the launch table: HAMT_WGRAD_TABLE_ENTRY bytes per
  * entry, at most sum over the problems of ceil(M_p / 64) entries (large problems are cut into bands of tile rows); it is filled by small kernels from kernarg data, so `probs` need not outlive the call and the whole sequence can
  * be captured in a hipGraph.  The table must stay untouched until the launches have run. */
-#define HAMT_WGRAD_TABLE_ENTRY 80
+#define HAMT_WGRAD_TABLE_ENTRY 112
 int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */

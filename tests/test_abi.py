@@ -59,8 +59,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.GemmDesc) == 18 * 4 + 4 + 4 + 8 and _lib.GemmDesc.p_drop.offset == 72 and _lib.GemmDesc.rng.offset == 80
     assert ctypes.sizeof(_lib.AttnDesc) == 15 * 4
     assert ctypes.sizeof(_lib.LnDesc) == 8 * 4 and _lib.LnDesc.io16.offset == 28
-    assert ctypes.sizeof(_lib.WgradDesc) == 4 * 8 + 8 * 4 + 8 + 2 * 4     # 4 pointers + 8 ints + the ss pointer + K_valid + reserved
-    assert _lib.WgradDesc.M.offset == 32 and _lib.WgradDesc.accum_db.offset == 60 and _lib.WgradDesc.ss.offset == 64 and _lib.WgradDesc.K_valid.offset == 72 and _lib.WGRAD_TABLE_ENTRY == 80
+    assert ctypes.sizeof(_lib.WgradDesc) == 4 * 8 + 8 * 4 + 8 + 2 * 4 + 2 * 8 + 4 * 4     # 4 pointers + 8 ints + the ss pointer + K_valid + wire_scale + the second operand pair
+    assert _lib.WgradDesc.M.offset == 32 and _lib.WgradDesc.accum_db.offset == 60 and _lib.WgradDesc.ss.offset == 64 and _lib.WgradDesc.K_valid.offset == 72 and _lib.WgradDesc.dy2.offset == 80 and _lib.WGRAD_TABLE_ENTRY == 112
     assert ctypes.sizeof(_lib.LnReduceDesc) == 4 * 8 + 4 * 4 and _lib.LnReduceDesc.M.offset == 32 and _lib.LnReduceDesc.atomic.offset == 40      # hamt_ln_reduce_desc (3 ints + tail padding)
 
 

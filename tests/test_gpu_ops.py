@@ -557,6 +557,123 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         L.check(lib.hamt_wgrad_grouped(1, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
 
 
+@pytest.mark.parametrize("tile", ["auto", "256", "128", "64"])
+def test_wgrad_grouped_second_operand_pair(tile, monkeypatch):
+    """hamt_wgrad_desc.dy2 / x2: dW (+)= dy^T x + dy2^T x2 and db (+)= colsum dy + colsum dy2 in ONE problem (a parameter used twice in a
+    pass: the cross-attention weights LXRTXLayer shares between its two directions), next to ordinary problems, on every tile class:
+    reductions of different lengths and row strides, a ragged (K2_valid, NaN padding) tail of the second pair, store and accumulate,
+    the tile sums of squares of the FINAL values, NaN behind every operand's last column."""
+    if tile != "auto":
+        monkeypatch.setenv("HAMT_WGRAD_TILE", tile)
+    from vln_hamt_amd import _lib as L
+    ops = _ops()
+    lib = L.load()
+    specs = [  # (K, K2 (0: none), K2_valid (0: all), M out, N in, accum_dw, with_db)
+        (5120, 2752, 0, 768, 768, 0, True), (2752, 5120, 0, 1536, 768, 0, True), (5120, 0, 0, 768, 3072, 0, True), (384, 5120, 5100, 768, 768, 1, True),
+        (5120, 384, 0, 768, 768, 0, False), (640, 640, 601, 256 + 58, 768, 0, True), (1280, 0, 0, 768, 768, 1, True), (25600, 13760, 0, 768, 768, 0, True),
+    ] * 5
+    keep, refs = [], []
+    descs = (L.WgradDesc * len(specs))()
+
+    def operand(K, C, seed, valid=0):
+        f = rnd(K, (max(C, 256) + 16 + 7) // 8 * 8, seed=seed, scale=0.5)
+        f[:, C:] = float("nan")
+        if valid:
+            f[valid:] = float("nan")
+        t = f.to(torch.bfloat16).to(DEV)
+        keep.append(t)
+        return t[:, :C]
+
+    for i, (K, K2, kv2, M, N, aw, wdb) in enumerate(specs):
+        dy, x = operand(K, M, 7 * i), operand(K, N, 7 * i + 1)
+        dw0, db0 = rnd(M, N, seed=7 * i + 2), rnd(M, seed=7 * i + 3)
+        dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
+        ss = torch.zeros(((M + 63) // 64) * ((N + 127) // 128), device=DEV)
+        keep += [dw, db, ss]
+        d = descs[i]
+        d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if wdb else None)
+        d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = M, N, K, dy.stride(0), x.stride(0), N, aw, aw
+        d.ss = ss.data_ptr()
+        rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
+        rb = dy.double().cpu().sum(0) + (db0.double() if aw else 0)
+        if K2:
+            dy2, x2 = operand(K2, M, 7 * i + 4, kv2), operand(K2, N, 7 * i + 5, kv2)
+            d.dy2, d.x2, d.K2, d.ldy2, d.ldx2, d.K2_valid = dy2.data_ptr(), x2.data_ptr(), K2, dy2.stride(0), x2.stride(0), kv2
+            kr = kv2 if kv2 else K2
+            rw = rw + dy2[:kr].double().cpu().t() @ x2[:kr].double().cpu()
+            rb = rb + dy2[:kr].double().cpu().sum(0)
+        refs.append((dw, db, rw, rb if wdb else db0.double(), ss))
+    tab = torch.empty(sum((sp[3] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
+    L.check(lib.hamt_debug_fill_lds(0x7FC07FC0, ops._stream()), "hamt_debug_fill_lds")
+    L.check(lib.hamt_wgrad_grouped(len(specs), descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
+    torch.cuda.synchronize()
+    for i, (dw, db, rw, rb, ss) in enumerate(refs):
+        close(dw, rw, 3e-5, f"dW[{i}] {specs[i]}")
+        close(db, rb, 3e-5, f"db[{i}] {specs[i]}")
+        want, got = float((rw ** 2).sum()), float(ss.double().sum())
+        assert abs(got - want) <= 2e-5 * want and bool(torch.isfinite(ss).all()), (i, specs[i], got, want)
+    descs[0].K_valid = 5000            # a ragged tail between the two reductions is refused, loudly
+    with pytest.raises(L.HamtError):
+        L.check(lib.hamt_wgrad_grouped(1, descs, tab.data_ptr(), tab.numel(), ops._stream()), "hamt_wgrad_grouped")
+
+
+def test_parameter_used_twice_is_one_weight_gradient_problem(monkeypatch):
+    """A linear layer applied to two inputs in one pass (what LXRTXLayer does with its shared cross-attention, vilmodel.py:401-412): the
+    queued weight gradient is ONE problem with two operand pairs -- one launch -- and equals the two-launch result and fp64."""
+    from vln_hamt_amd import wgrad
+    from vln_hamt_amd.optim import AdamW
+    ops = _ops()
+    if not wgrad.ENABLED:
+        pytest.skip("HAMT_NO_DEFER_WGRAD")
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(768, 768).to(DEV)
+    xa, xb = rnd(5120, 768, seed=1).to(DEV), rnd(2752, 768, seed=2).to(DEV)
+    ga, gb = rnd(5120, 768, seed=3).to(DEV), rnd(2752, 768, seed=4).to(DEV)
+    res = {}
+    for merged in (True, False):
+        monkeypatch.setattr(wgrad, "MERGE_PAIRS", merged)
+        o = AdamW([{"params": list(lin.parameters()), "weight_decay": 0.0}], lr=1e-3)
+        o.materialize()
+        o.zero_grad()
+        n0 = wgrad.stats["problems"]
+        with _CountLaunches("hamt_wgrad_grouped") as cnt:
+            ya, yb = ops.linear(xa, lin.weight, lin.bias, ops.ACT_NONE, "bf16"), ops.linear(xb, lin.weight, lin.bias, ops.ACT_NONE, "bf16")
+            torch.autograd.backward([ya, yb], [ga, gb])
+        torch.cuda.synchronize()
+        res[merged] = (lin.weight.grad.detach().clone(), lin.bias.grad.detach().clone(), cnt.n["hamt_wgrad_grouped"])
+        o.zero_grad()
+    assert res[True][2] == 1 and res[False][2] == 2, (res[True][2], res[False][2])
+    rw = bf16_round(ga.cpu()).double().t() @ bf16_round(xa.cpu()).double() + bf16_round(gb.cpu()).double().t() @ bf16_round(xb.cpu()).double()
+    rb = bf16_round(ga.cpu()).double().sum(0) + bf16_round(gb.cpu()).double().sum(0)
+    for merged in (True, False):
+        close(res[merged][0], rw, 3e-5, f"dW merged={merged}")
+        close(res[merged][1], rb, 3e-5, f"db merged={merged}")
+
+
+class _CountLaunches:
+    """counts calls of C entry points (patches the ctypes handles for the duration)"""
+
+    def __init__(self, *names):
+        self.names, self.n = names, {k: 0 for k in names}
+
+    def __enter__(self):
+        from vln_hamt_amd import _lib as L
+        self.lib, self.orig = L.load(), {}
+        for k in self.names:
+            f = getattr(self.lib, k)
+            self.orig[k] = f
+
+            def wrap(*a, _f=f, _k=k):
+                self.n[_k] += 1
+                return _f(*a)
+            setattr(self.lib, k, wrap)
+        return self
+
+    def __exit__(self, *a):
+        for k, f in self.orig.items():
+            setattr(self.lib, k, f)
+
+
 def test_wgrad_kernel_timing_aid():
     """hamt_debug_wgrad_timing / _times (bench.py's `roofline`): one bracket per grouped KERNEL launch, positive durations, and
     the library's own work count = sum 2 M N K over the k-tiles it multiplies (whole 64-row tiles up to K_valid)."""

@@ -57,13 +57,13 @@ class GemmLnDesc(C.Structure):
 
 
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
-WGRAD_TABLE_ENTRY = 80      # HAMT_WGRAD_TABLE_ENTRY
+WGRAD_TABLE_ENTRY = 112     # HAMT_WGRAD_TABLE_ENTRY
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32), ("ldy", i32),
                 ("ldx", i32), ("ldw", i32), ("accum_dw", i32), ("accum_db", i32), ("ss", vp), ("K_valid", i32),
-                ("wire_scale", f32)]
+                ("wire_scale", f32), ("dy2", vp), ("x2", vp), ("K2", i32), ("ldy2", i32), ("ldx2", i32), ("K2_valid", i32)]
 
 
 SIGNATURES = {

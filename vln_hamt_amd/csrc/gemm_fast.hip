@@ -47,6 +47,10 @@ struct GemmArgsF {
   const uint64_t* rng;
   float* ss;            // weight-gradient tiles: slot array for the sum of squares of each tile's FINAL values (or nullptr)
   int ss_ld;            // slots per 64-row band of `ss` (0: those of this N; a column band of a wider output passes the full width's)
+  // weight-gradient tiles only: a second pair of K-strided operands reduced into the same tile behind the first (K2 = 0: none)
+  const bf16_t* A2;
+  const bf16_t* B2;
+  int K2, lda2, ldb2, k2_max;
 };
 
 #ifdef HAMT_PROF   // cycle accounting of the main loop (tools/gemm_prof.py builds a private copy with -DHAMT_PROF)
@@ -528,12 +532,14 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
 // Up to WG_MAX independent problems dW_p[M_p,N_p] (+)= dY_p^T X_p (and db_p (+)= colsum dY_p) in ONE launch: the tile ids
 // of all problems are concatenated (longest reductions first), so 768x768 outputs that alone would fill 36 CUs (or need
 // split-K + a reduce pass) run as one chip-filling grid with full-length K loops.  Problem table by value in the kernarg.
-constexpr int WG_MAX = 256;                      // table entries carried by one kernarg block (80 bytes each: 20 KiB of kernarg, one launch for ~250 units)
+constexpr int WG_MAX = 192;                      // table entries carried by one kernarg block (112 bytes each: 21 KiB of kernarg, one launch for ~190 units)
 struct WgradProb {
   const bf16_t* dy; const bf16_t* x; float* dw; float* db; float* ss;
   int M, N, K, ldy, ldx, ldw, flags, tile_end;   // flags: 1 = dW +=, 2 = db +=, >> 8 = ss slots per 64-row band; tile_end = exclusive prefix end
   int kv;                                        // valid reduction rows (<= K): rows behind are padding of any content
   float wscale;                                  // != 0: dw is a bf16 array, the tile stores bf16(wscale * dW) (hamt_wgrad_desc.wire_scale)
+  const bf16_t* dy2; const bf16_t* x2;           // second reduction into the same tile (hamt_wgrad_desc.dy2), or null
+  int K2, ldy2, ldx2, kv2;
 };
 static_assert(sizeof(WgradProb) == HAMT_WGRAD_TABLE_ENTRY, "HAMT_WGRAD_TABLE_ENTRY");
 struct WgradChunk { WgradProb p[WG_MAX]; };
@@ -563,9 +569,14 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_grouped_kernel(const Wgrad
   const WgradProb q = tab[lo];
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + BNT - 1) / BNT;
-  GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0,
-              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss, q.flags >> 8};
-  gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, q.K / BK, 0, q.db, q.flags & 2);
+  const int nseg = q.dy2 ? 2 : 1;
+  for (int seg = 0; seg < nseg; ++seg) {          // (a second pair of operands: the same tile again, accumulating; the tile sums of squares by the last)
+    GemmArgsF g{q.M, q.N, seg ? q.K2 : q.K, seg ? q.ldy2 : q.ldy, seg ? q.ldx2 : q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0,
+                ((q.flags & 1) || seg) ? HAMT_EPI_ACCUM : 0, q.wscale != 0.f ? q.wscale : 1.0f, seg ? q.dy2 : q.dy, seg ? q.x2 : q.x, q.dw, nullptr, nullptr, 1,
+                nullptr, (seg ? q.kv2 : q.kv) - 1, (seg ? q.kv2 : q.kv) - 1, 0.f, 0u, nullptr, seg == nseg - 1 ? q.ss : nullptr, q.flags >> 8};
+    gemm_tile<BM, -2, true, true, 2, true, BNT, WM, WN>(g, (local / tiles_n) * BM, (local % tiles_n) * BNT, 0, g.K / BK, 0, q.db, (q.flags & 2) || seg);
+    if (nseg > 1) __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------- fp32/bf16 [R][C] -> bf16 [C][Rpad] (zero padded)
@@ -731,7 +742,10 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
   const bool do_cs = COLSUM && db != nullptr && n0 == 0;                   // workgroup-uniform
   f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-  const int nk = g.K / BK;
+  // COLSUM (= the weight-gradient instantiation): the reduction may run over TWO operand pairs back to back (GemmArgsF::A2): k-tiles
+  // [0, nk1) come from (A, B), [nk1, nk) from (A2, B2) -- base pointer, row stride and row clamp are scalar selects at issue time
+  const int nk1 = g.K / BK;
+  const int nk = COLSUM ? nk1 + g.K2 / BK : nk1;
   const unsigned lds0 = lds_base_of(lds);
 
   f32x4 acc[8][NB];
@@ -747,8 +761,18 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   constexpr int BGS = B_KM ? 7 : 5;
   p8_src_init<B_KM, BGS, H1B>(sb, g.ldb, n0, g.N - 1, w, lane);
   auto slot = [&](int kt, int ty) { return lds0 + (unsigned)(((kt & 1) * P8_BUF + ty * P8_UNIT) * 2); };
-  auto issue_x = [&](int kt, int h) { p8_issue<A_KM>(sa, g.A, g.lda, kt, g.ka_max, slot(kt, h ? 3 : 0), h, w); };
-  auto issue_y = [&](int kt, int h) { p8_issue<B_KM, H1B>(sb, g.B, g.ldb, kt, g.kb_max, slot(kt, 1 + h), h, w); };
+  auto issue_x = [&](int kt, int h) {
+    if constexpr (COLSUM) {
+      const bool s2 = kt >= nk1;
+      p8_issue<A_KM>(sa, s2 ? g.A2 : g.A, s2 ? g.lda2 : g.lda, s2 ? kt - nk1 : kt, s2 ? g.k2_max : g.ka_max, slot(kt, h ? 3 : 0), h, w);
+    } else p8_issue<A_KM>(sa, g.A, g.lda, kt, g.ka_max, slot(kt, h ? 3 : 0), h, w);
+  };
+  auto issue_y = [&](int kt, int h) {
+    if constexpr (COLSUM) {
+      const bool s2 = kt >= nk1;
+      p8_issue<B_KM, H1B>(sb, s2 ? g.B2 : g.B, s2 ? g.ldb2 : g.ldb, s2 ? kt - nk1 : kt, s2 ? g.k2_max : g.kb_max, slot(kt, 1 + h), h, w);
+    } else p8_issue<B_KM, H1B>(sb, g.B, g.ldb, kt, g.kb_max, slot(kt, 1 + h), h, w);
+  };
   // prologue: k-tile 0 and X0, Y0 of k-tile 1; phase A(0) reads X0, Y0, Y1 of k-tile 0 (three younger units may be in flight)
   issue_x(0, 0); issue_y(0, 0); issue_y(0, 1); issue_x(0, 1); issue_x(1, 0); issue_y(1, 0);
   p8_wait<6>();
@@ -785,11 +809,14 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
         for (int i = 0; i < 4; ++i) af[i][s] = frag<A_KM, 128>(buf + 3 * P8_UNIT, 64 * wr + i * 16, s, lane);
     }
     if constexpr (A_KM && MODE == 2) {        // (the launcher shrinks K to the 64-row tile that holds the last valid row: only the
-      if (kt * BK + BK > g.ka_max + 1) {       // LAST k-tile can cross it -- masking code in every phase instance spilled registers)
+      // LAST k-tile can cross it -- masking code in every phase instance spilled registers; with a second operand pair the last k-tile
+      // is ITS last one, and the first pair has no ragged tail: hamt_wgrad_desc)
+      const int ktl = (COLSUM && g.K2 > 0) ? kt - nk1 : kt, kend = ((COLSUM && g.K2 > 0) ? g.k2_max : g.ka_max) + 1;
+      if (ktl * BK + BK > kend) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[i][s] = mask_k_tail(af[i][s], kt * BK + 32 * s, lane, g.ka_max + 1);
+          for (int i = 0; i < 4; ++i) af[i][s] = mask_k_tail(af[i][s], ktl * BK + 32 * s, lane, kend);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -952,7 +979,8 @@ __global__ __launch_bounds__(512) void wgrad_grouped_p8_kernel(const WgradProb* 
   const int local = idx - (lo > first ? tab[lo - 1].tile_end : 0);
   const int tiles_n = (q.N + 255) / 256;
   GemmArgsF g{q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, 0, q.wscale != 0.f ? HAMT_BF16 : HAMT_F32, 0, (q.flags & 1) ? HAMT_EPI_ACCUM : 0,
-              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss, q.flags >> 8};
+              q.wscale != 0.f ? q.wscale : 1.0f, q.dy, q.x, q.dw, nullptr, nullptr, 1, nullptr, q.kv - 1, q.kv - 1, 0.f, 0u, nullptr, q.ss, q.flags >> 8,
+              q.dy2, q.x2, q.dy2 ? q.K2 : 0, q.ldy2, q.ldx2, q.kv2 - 1};       // (a second operand pair: the tile's reduction simply goes on over it)
   p8_tile<-2, true, true, true>(g, (local / tiles_n) * 256, (local % tiles_n) * 256, q.db, q.flags & 2);
 }
 
@@ -1183,6 +1211,9 @@ extern "C" int hamt_cast_transpose(int R, int C, const void* x, int ldx, int dty
 
 static inline int kv_of(const hamt_wgrad_desc& d) { return (d.K_valid > 0 && d.K_valid < d.K) ? d.K_valid : d.K; }
 static inline int keff(const hamt_wgrad_desc& d) { return (kv_of(d) + 63) / 64 * 64; }   // reduction rows actually multiplied
+static inline int kv2_of(const hamt_wgrad_desc& d) { return !d.dy2 ? 0 : ((d.K2_valid > 0 && d.K2_valid < d.K2) ? d.K2_valid : d.K2); }
+static inline int keff2(const hamt_wgrad_desc& d) { return (kv2_of(d) + 63) / 64 * 64; }  // ... of the second pair of operands (0: none)
+static inline int kall(const hamt_wgrad_desc& d) { return keff(d) + keff2(d); }
 
 // Measurement aid for bench.py's `roofline` object: per-launch durations of the grouped weight-gradient kernels, taken with HIP
 // events recorded on the launch stream right around each kernel (not around the whole call: the table writes and the other tile
@@ -1222,6 +1253,13 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     HAMT_CHECK_ARG(d.K_valid >= 0 && d.K_valid <= d.K, "hamt_wgrad_grouped: problem %d: K_valid = %d outside [0, K = %d]", i, d.K_valid, d.K);
     HAMT_CHECK_ARG(d.wire_scale == 0.f || (!d.accum_dw && d.K > 0 && d.ldw % 8 == 0 && (uintptr_t)d.dw % 16 == 0),
                    "hamt_wgrad_grouped: problem %d: a bf16 wire output (wire_scale != 0) is store-only and needs ldw %% 8 == 0 and a 16-byte aligned dw", i);
+    if (d.dy2) {
+      HAMT_CHECK_ARG(d.x2 && d.K > 0 && d.K2 > 0 && d.K2 % 64 == 0 && d.wire_scale == 0.f && (d.K_valid == 0 || d.K_valid == d.K),
+                     "hamt_wgrad_grouped: problem %d: a second operand pair needs x2, K and K2 > 0, K2 %% 64 == 0, K_valid 0 or K, wire_scale 0", i);
+      HAMT_CHECK_ARG(d.ldy2 % 8 == 0 && d.ldy2 >= 64 && d.ldy2 >= d.M && d.ldx2 % 8 == 0 && d.ldx2 >= 128 && d.ldx2 >= d.N && (uintptr_t)d.dy2 % 16 == 0 &&
+                     (uintptr_t)d.x2 % 16 == 0 && d.K2_valid >= 0 && d.K2_valid <= d.K2 && 2.0 * d.K2 * d.ldy2 < 4294967296.0 && 2.0 * d.K2 * d.ldx2 < 4294967296.0,
+                     "hamt_wgrad_grouped: problem %d: bad second operand pair (ldy2 %d, ldx2 %d, K2 %d, K2_valid %d)", i, d.ldy2, d.ldx2, d.K2, d.K2_valid);
+    }
     if (d.K > 0) order.push_back(i);
     else HAMT_CHECK_ARG(d.accum_dw && (!d.db || d.accum_db), "hamt_wgrad_grouped: problem %d: K = 0 with store semantics", i);
   }
@@ -1231,7 +1269,11 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   // Two launch classes: problems whose operand rows are >= 256 elements wide can use 256-square tiles; the rest 128 / 64
   // rows.  Within a class: longest reductions first, the short tail tiles fill in behind them.
   std::vector<int> cls[2];
-  for (int i : order) cls[(probs[i].ldy >= 256 && probs[i].ldx >= 256 && keff(probs[i]) >= 128) ? 0 : 1].push_back(i);
+  for (int i : order) {
+    const hamt_wgrad_desc& d = probs[i];
+    const bool wide2 = !d.dy2 || (d.ldy2 >= 256 && d.ldx2 >= 256 && keff2(d) >= 128);
+    cls[(d.ldy >= 256 && d.ldx >= 256 && keff(d) >= 128 && wide2) ? 0 : 1].push_back(i);
+  }
   static const int use_p8 = getenv("HAMT_WGRAD_P8") ? atoi(getenv("HAMT_WGRAD_P8")) : 1;   // 0: the one-phase 256-square tile
   const char* uenv = getenv("HAMT_WGRAD_UNIT_TILES");   // tuning: tiles per XCD-pinned unit (read per call)
   const int unit_tiles = uenv && atoi(uenv) > 0 ? atoi(uenv) : 12;
@@ -1254,7 +1296,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
   for (int c = 0; c < 2; ++c) {
     std::vector<int>& v = cls[c];
     if (v.empty()) continue;
-    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return keff(probs[a]) > keff(probs[b]); });
+    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return kall(probs[a]) > kall(probs[b]); });
     long t128 = 0, t256 = 0;
     for (int i : v) {
       t128 += (long)((probs[i].M + 127) / 128) * ((probs[i].N + 127) / 128);
@@ -1289,7 +1331,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
         for (int c0 = 0; c0 < tn; c0 += uc) {
           const int rows = std::min(ur * bm, d.M - r0 * bm), cols = std::min(uc * bn, d.N - c0 * bn);
           const int t = ((rows + bm - 1) / bm) * ((cols + bn - 1) / bn);
-          units.push_back(Unit{i, r0 * bm, rows, c0 * bn, cols, t, (double)t * keff(d)});
+          units.push_back(Unit{i, r0 * bm, rows, c0 * bn, cols, t, (double)t * kall(d)});
         }
     }
     std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
@@ -1311,7 +1353,7 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     double launch_flops = 0.0;
     for (int x = 0; x < 8; ++x) {
       xs.start[x] = (int)flat.size();
-      std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return keff(probs[units[a].prob]) > keff(probs[units[b].prob]); });
+      std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return kall(probs[units[a].prob]) > kall(probs[units[b].prob]); });
       int tiles = 0;
       for (int u : xq[x]) {
         const Unit& un = units[u];
@@ -1325,9 +1367,11 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
                                  (d.db && un.n_lo == 0) ? d.db + un.m_lo : nullptr,       // the column sums of dY: by the unit that holds column 0
                                  (d.ss && !wire) ? d.ss + (size_t)(un.m_lo >> 6) * ss_ld + (un.n_lo >> 7) : nullptr,
                                  un.m_rows, un.n_cols, d.K, d.ldy, d.ldx, d.ldw,
-                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0) | (ss_ld << 8), tiles, kv_of(d), d.wire_scale});
+                                 (d.accum_dw ? 1 : 0) | (d.accum_db ? 2 : 0) | (ss_ld << 8), tiles, kv_of(d), d.wire_scale,
+                                 d.dy2 ? (const bf16_t*)d.dy2 + un.m_lo : nullptr, d.dy2 ? (const bf16_t*)d.x2 + un.n_lo : nullptr,
+                                 keff2(d), d.ldy2, d.ldx2, kv2_of(d)});
         flat.back().K = keff(d);                        // whole k-tiles behind the last valid row are not multiplied at all
-        launch_flops += 2.0 * un.m_rows * un.n_cols * keff(d);
+        launch_flops += 2.0 * un.m_rows * un.n_cols * kall(d);
       }
       max_tiles = std::max(max_tiles, tiles);
     }

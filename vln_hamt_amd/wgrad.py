@@ -31,6 +31,7 @@ from . import _lib as L
 
 ENABLED = os.environ.get("HAMT_NO_DEFER_WGRAD") is None     # ablation switch: compute every dW immediately
 FUSE_SUMSQ = os.environ.get("HAMT_NO_FUSED_SUMSQ") is None  # ablation switch: the gradient norm reads every gradient back
+MERGE_PAIRS = os.environ.get("HAMT_WGRAD_NO_PAIRS") is None   # a parameter used twice in a pass: one problem with two operand pairs
 
 stats = {"flushes": 0, "problems": 0, "dropped_stale": 0}
 
@@ -324,6 +325,7 @@ def _launch_items(ps: _Pass, items, later=frozenset()):
     # write to a buffer goes into the k-th launch group, and groups run in stream order.
     base_seen = dict(seen)
     groups: List[list] = []
+    first_entry: dict = {}
     for (w, b, dy16, x16) in items:
         tw, aw = _target(w, targets, fresh)
         tb, ab = (None, 0)
@@ -339,9 +341,22 @@ def _launch_items(ps: _Pass, items, later=frozenset()):
         g = k - bk                               # writes to these buffers by earlier launches are complete (same stream): only this call's count
         if bk > 0 and id(tw) in ps_fused_ids(ps):
             refused = True                       # a weight an earlier launch of this pass left tile sums for is written again
+        # the SECOND use of a parameter in this pass (the cross-attention weights an x-layer shares between its two directions): a second
+        # operand pair of the first use's problem (hamt_wgrad_desc.dy2) instead of an accumulating launch of its own behind the first
+        e0 = first_entry.get(id(tw)) if (MERGE_PAIRS and g == 1) else None
+        if (e0 is not None and e0[7] is None and e0[5] is tb and valid_rows(e0[1]) == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0
+                and dy16.stride(0) >= 64 and x16.stride(0) >= 128):
+            e0[7], e0[8] = dy16, x16
+            seen[id(tw)] = k                     # (still ONE problem writing this buffer)
+            if tb is not None:
+                seen[id(tb)] = k
+            continue
         while len(groups) <= g:
             groups.append([])
-        groups[g].append((w, dy16, x16, tw, aw or k > 0, tb, ab or k > 0))
+        entry = [w, dy16, x16, tw, aw or k > 0, tb, ab or k > 0, None, None]
+        groups[g].append(entry)
+        if g == 0 and bk == 0:
+            first_entry[id(tw)] = entry
     lib = L.load()
     # Sum of squares of the gradients while their tiles are still in registers (hamt_wgrad_desc.ss): for every weight whose
     # gradient is STORED once in this pass straight into its gradient-arena slot -- the bulk of the parameters -- so that the
@@ -360,7 +375,7 @@ def _launch_items(ps: _Pass, items, later=frozenset()):
     if FUSE_SUMSQ and groups and not refused:
         slots_of = lambda w: ((w.shape[0] + 63) // 64) * ((w.shape[1] + 127) // 128)
         n_ss = 0
-        for (w, dy16, x16, tw, aw, tb, ab) in groups[0]:
+        for (w, dy16, x16, tw, aw, tb, ab, _dy2, _x2) in groups[0]:
             o = getattr(w, "_hamt_opt", None)
             o = o() if o is not None else None
             slot = getattr(w, "_hamt_grad_slot", None)
@@ -374,7 +389,7 @@ def _launch_items(ps: _Pass, items, later=frozenset()):
     ss_of = {k: off for (k, _w, off) in fused}
     for gi, grp in enumerate(groups):
         descs = (L.WgradDesc * len(grp))()
-        for i, (w, dy16, x16, tw, aw, tb, ab) in enumerate(grp):
+        for i, (w, dy16, x16, tw, aw, tb, ab, dy2, x2) in enumerate(grp):
             d = descs[i]
             d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), tw.data_ptr(), (tb.data_ptr() if tb is not None else None)
             d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
@@ -382,6 +397,8 @@ def _launch_items(ps: _Pass, items, later=frozenset()):
             d.accum_dw, d.accum_db = int(bool(aw)), int(bool(ab))
             d.K_valid = valid_rows(dy16)
             d.ss = (ss_all.data_ptr() + 4 * ss_of[id(tw)]) if (gi == 0 and id(tw) in ss_of) else None
+            if dy2 is not None:
+                d.dy2, d.x2, d.K2, d.ldy2, d.ldx2, d.K2_valid = dy2.data_ptr(), x2.data_ptr(), dy2.shape[0], dy2.stride(0), x2.stride(0), valid_rows(dy2)
         launch(descs, len(grp))
     if fused:
         opt.note_fused_sumsq(ss_all, [w for (_k, w, _o) in fused], append=ps.launched > 0 and bool(ps_fused_ids(ps)))
