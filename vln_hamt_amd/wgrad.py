@@ -527,6 +527,17 @@ def _build_plan(items, optimizer, n_groups, wire):
             return None
         probs.append((ow, ob, w, b, dy16, x16))
     probs.sort(key=lambda t: t[0])
+    if MERGE_PAIRS:       # a parameter used twice in the pass: one problem with two operand pairs (as _launch_items does)
+        merged_probs = []
+        for t in probs:
+            ow, ob, w, b, dy16, x16 = t
+            prev = merged_probs[-1] if merged_probs else None
+            if (prev is not None and prev[0] == ow and prev[1] == ob and len(prev) == 6 and valid_rows(prev[4]) == 0 and w.grad is None
+                    and (b is None or b.grad is None)):
+                merged_probs[-1] = prev + (dy16, x16)
+            else:
+                merged_probs.append(t)
+        probs = merged_probs
     # cut weights: the parameters' sizes, NOT the operands' row counts -- those differ between the ranks of a data-parallel job
     # (per-batch padding to the local longest instruction, the packed text's row bucket), and the launch groups decide when an
     # arena range may be exchanged: the cuts must be the same on every rank that queued the same parameters
@@ -541,7 +552,7 @@ def _build_plan(items, optimizer, n_groups, wire):
     # a buffer written twice in the pass: the second write must land in a LATER launch than the first
     last_group: dict = {}
     dep_pairs = set()
-    for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
+    for i, (ow, ob, w, b, dy16, x16, *_pair) in enumerate(probs):
         prev = [last_group[o] for o in (ow, ob) if o is not None and o in last_group]
         gmin = max(prev, default=-1) + 1
         group_of[i] = max(group_of[i], gmin)
@@ -558,7 +569,7 @@ def _build_plan(items, optimizer, n_groups, wire):
     for (ow, *_r) in probs:
         n_writes[ow] = n_writes.get(ow, 0) + 1
     direct = set()                         # arena offsets of the weights whose launch writes the bf16 wire value itself
-    for i, (ow, ob, w, b, dy16, x16) in enumerate(probs):
+    for i, (ow, ob, w, b, dy16, x16, *pair) in enumerate(probs):
         # (a gradient that exists already -- an autograd tensor the caller packs into the slot before the groups run, or the slot
         # itself holding what was added in place during the pass: an embedding table tied to this weight -- is accumulated onto)
         aw = 1 if (ow in written or w.grad is not None) else 0
@@ -567,19 +578,21 @@ def _build_plan(items, optimizer, n_groups, wire):
             ab = 1 if (ob in written or b.grad is not None) else 0
             written[ob] = True
         written[ow] = True
-        if wire is not None and not aw and n_writes[ow] == 1 and ow + w.numel() <= wire[2] and w.shape[1] % 8 == 0:
-            direct.add(ow)
-        per_group[group_of[i]].append((ow, ob, w, b, dy16, x16, aw, ab))
-        plan.keep += [dy16, x16]
+        if wire is not None and not aw and n_writes[ow] == 1 and not pair and ow + w.numel() <= wire[2] and w.shape[1] % 8 == 0:
+            direct.add(ow)           # (two operand pairs: fp32 slot + the pack pass, as for every weight written twice before)
+        per_group[group_of[i]].append((ow, ob, w, b, dy16, x16, aw, ab, pair))
+        plan.keep += [dy16, x16] + list(pair)
     for grp in per_group:
         descs = (L.WgradDesc * max(1, len(grp)))()
-        for i, (ow, ob, w, b, dy16, x16, aw, ab) in enumerate(grp):
+        for i, (ow, ob, w, b, dy16, x16, aw, ab, pair) in enumerate(grp):
             d = descs[i]
             d.dy, d.x, d.dw, d.db = dy16.data_ptr(), x16.data_ptr(), base + 4 * ow, (base + 4 * ob if ob is not None else None)
             d.M, d.N, d.K = w.shape[0], w.shape[1], dy16.shape[0]
             d.ldy, d.ldx, d.ldw = dy16.stride(0), x16.stride(0), w.shape[1]
             d.accum_dw, d.accum_db = aw, ab
             d.K_valid = valid_rows(dy16)
+            if pair:
+                d.dy2, d.x2, d.K2, d.ldy2, d.ldx2, d.K2_valid = pair[0].data_ptr(), pair[1].data_ptr(), pair[0].shape[0], pair[0].stride(0), pair[1].stride(0), valid_rows(pair[0])
             if ow in direct:
                 d.dw, d.wire_scale = wire[0].data_ptr() + 2 * ow, float(wire[1])
         plan.groups.append((descs, len(grp)))
