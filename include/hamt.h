@@ -34,7 +34,12 @@ extern "C" {
 #define HAMT_ABI_VERSION 1
 
 typedef enum { HAMT_OK = 0, HAMT_ERR_ARG = -1, HAMT_ERR_UNSUPPORTED = -2, HAMT_ERR_LAUNCH = -3 } hamt_status;
-typedef enum { HAMT_F32 = 0, HAMT_BF16 = 1 } hamt_dtype;
+typedef enum { HAMT_F32 = 0, HAMT_BF16 = 1,
+               /* one byte per element, `aux` of HAMT_EPI_GELU_GRAD (without HAMT_EPI_DROPOUT) / HAMT_EPI_MUL_AUX only: the saved gelu'(x),
+                * whose range is [-0.129, 1.129], as code q in [0, 255] with value = 0.005 q - 0.13 (0 and 1 are exact: q = 26 / 226;
+                * |error| <= 0.0025, the size of bf16's rounding of values near 1).  Halves the bytes of the image the FFN-1 epilogue
+                * writes next to gelu(x) and the FFN-2 dgrad epilogue reads back (vilmodel.py:168-175 BertIntermediate backward). */
+               HAMT_U8G = 2 } hamt_dtype;
 /* arithmetic of the contraction: bf16 MFMA operands with fp32 accumulate, or exact fp32 MFMA */
 typedef enum { HAMT_PREC_BF16 = 0, HAMT_PREC_F32 = 1 } hamt_prec;
 

@@ -214,6 +214,13 @@ BENCH_GEMMS = [   # (layout, M, N, K, epilogue, C dtype, kernel the launcher mus
     ("nt", 2752, 768, 768, "bias", "f32", "gemm_fast_kernel<64, 1, false, false>"),      # vision stream
     ("nt", 4096, 4096, 64, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),    # 128-row plain tile
     ("nn", 4096, 4096, 64, "acc", "f32", "gemm_fast_kernel<128, 8, false, true>"),
+    ("nt", 5120, 3072, 768, "gelugrad8", "bf16", "gemm_p8_kernel<129, false, false, 4>"),   # text FFN-1, gelu' saved as one byte (HAMT_U8G)
+    ("nt", 2752, 3072, 768, "gelugrad8", "bf16", None),                                      # vision stream
+    ("nt", 389, 3068, 768, "gelugrad8", "bf16", None),                                       # ragged rows / columns: byte-wise tail of the code image
+    ("nn", 5120, 3072, 768, "mulaux8", "bf16", "gemm_p8_kernel<256, false, true, 4>"),       # dgrad of FFN-2 x the one-byte gelu'
+    ("nn", 11520, 3072, 768, "mulaux8", "bf16", "gemm_p8_kernel<256, false, true, 3>"),
+    ("nn", 2752, 3072, 768, "mulaux8", "bf16", None),
+    ("nn", 389, 3068, 768, "mulaux8", "bf16", None),
     ("nt", 5120, 768, 3072, "bias", "bf16", "gemm_kg_kernel<128, 2, 2, false>"),         # text FFN-2 (K groups)
     ("nn", 5120, 768, 3072, "acc", "f32", "gemm_kg_kernel<128, 2, 2, true>"),
 ]
@@ -232,7 +239,7 @@ def test_gemm_bench_shapes_vs_fp64(layout, M, N, K, epi, cdt, kernel):
     out = torch.full((M, N), float("nan"), device=DEV, dtype=cd)                          # an unwritten element shows
     kw = dict(b_kmajor=layout == "nn", prec="bf16")
     aux = dref = keep_frac = None
-    if epi in ("bias", "gelugrad", "drop_res"):
+    if epi in ("bias", "gelugrad", "gelugrad8", "drop_res"):
         bias = torch.randn(N, device=DEV, generator=g)
         kw["bias"] = bias
         ref = ref + bias.double()
@@ -245,8 +252,15 @@ def test_gemm_bench_shapes_vs_fp64(layout, M, N, K, epi, cdt, kernel):
         aux = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
         kw.update(epilogue=L.EPI_MUL_AUX, aux=aux)
         ref = ref * aux.double()
-    elif epi == "gelugrad":
-        aux = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    elif epi == "mulaux8":      # aux = codes q of the one-byte gelu' image: value 0.005 q - 0.13 (hamt.h HAMT_U8G)
+        aux = torch.randint(0, 256, (M, (N + 15) // 16 * 16), device=DEV, generator=g, dtype=torch.uint8)[:, :N]
+        kw.update(epilogue=L.EPI_MUL_AUX, aux=aux)
+        ref = ref * (aux.double() * 0.005 - 0.13)
+    elif epi in ("gelugrad", "gelugrad8"):
+        if epi == "gelugrad8":
+            aux = torch.full((M, (N + 15) // 16 * 16), 255, device=DEV, dtype=torch.uint8)[:, :N]
+        else:
+            aux = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
         kw.update(epilogue=L.EPI_GELU_GRAD, aux=aux)
         pre = ref
         phi = 0.5 * (1 + torch.erf(pre / 2 ** 0.5))
@@ -256,7 +270,7 @@ def test_gemm_bench_shapes_vs_fp64(layout, M, N, K, epi, cdt, kernel):
         res = torch.randn(M, N, device=DEV, generator=g)
         kw.update(epilogue=L.EPI_ADD_AUX, aux=res, drop=(0.1, 4242))
     ops.gemm(A, b, out, **kw)
-    assert L.last_kernel() == kernel, L.last_kernel()
+    assert kernel is None or L.last_kernel() == kernel, L.last_kernel()
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out).all()), "non-finite / unwritten output elements"
     # fp32 accumulation of K bf16 products: 2e-5 sqrt(K)/4 of the scale (as the small-shape tests); + bf16 rounding of a bf16 C
@@ -269,7 +283,11 @@ def test_gemm_bench_shapes_vs_fp64(layout, M, N, K, epi, cdt, kernel):
         close(torch.where(kept, y, torch.zeros_like(y)), torch.where(kept, ref / 0.9, torch.zeros_like(ref)), 3 * tol, f"{kernel} dropout + residual")
     else:
         close(out, ref, tol, f"{kernel} {layout} {M}x{N}x{K} {epi}")
-    if dref is not None:
+    if dref is not None and epi == "gelugrad8":
+        # code of the value the kernel's fp32 epilogue saw: nearest of 0.005 q - 0.13 (half a step = 0.0025, + the fp32 pre-activation's error)
+        err = float((aux.double() * 0.005 - 0.13 - dref).abs().max())
+        assert err <= 0.0025 + 2 * tol, f"{kernel} one-byte gelu': {err}"
+    elif dref is not None:
         assert bool(torch.isfinite(aux).all())
         close(aux, dref, 2 ** -7, f"{kernel} saved gelu'")
 

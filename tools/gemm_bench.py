@@ -32,6 +32,10 @@ def bench(layout, M, N, K, epi="bias", cdt="f32", iters=30):
         kw.update(epilogue=L.EPI_MUL_DGELU, aux=torch.randn(M, N, device=dev).to(torch.bfloat16))
     elif epi == "gelugrad":
         kw.update(bias=torch.randn(N, device=dev), epilogue=L.EPI_GELU_GRAD, aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+    elif epi == "gelugrad8":
+        kw.update(bias=torch.randn(N, device=dev), epilogue=L.EPI_GELU_GRAD, aux=torch.empty(M, N, device=dev, dtype=torch.uint8))
+    elif epi == "mulaux8":
+        kw.update(epilogue=L.EPI_MUL_AUX, aux=torch.randint(0, 256, (M, N), device=dev, dtype=torch.uint8))
     elif epi == "mulaux":
         kw.update(epilogue=L.EPI_MUL_AUX, aux=torch.randn(M, N, device=dev).to(torch.bfloat16))
     elif epi == "acc":

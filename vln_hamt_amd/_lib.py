@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamt_hip.so")
 
-HAMT_F32, HAMT_BF16 = 0, 1
+HAMT_F32, HAMT_BF16, HAMT_U8G = 0, 1, 2
 PREC_BF16, PREC_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_ACCUM, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_GRAD, EPI_MUL_AUX, EPI_ADD_AUX, EPI_DROPOUT = 128, 256, 512, 1024

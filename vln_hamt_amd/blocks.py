@@ -40,6 +40,11 @@ NO_SHADOW = os.environ.get("HAMT_NO_SHADOW") is not None
 O_DTYPE = torch.float32 if os.environ.get("HAMT_DENSE_OUT_F32") == "1" else torch.bfloat16
 
 
+# the saved gelu' image of the FFN blocks: one byte per element (hamt.h HAMT_U8G: 0.005 q - 0.13, |error| <= 0.0025 -- what bf16's rounding
+# of a value near 1 is) instead of bf16: 16 MB less to write in the FFN-1 epilogue and to read in the FFN-2 dgrad epilogue per 5120 rows.
+# HAMT_GELUP_U8=1 selects it; measured (profiles/r05_epilogue.txt) it buys nothing, the epilogue's cost was never its bytes
+GELUP_DTYPE = torch.uint8 if os.environ.get("HAMT_GELUP_U8") == "1" else torch.bfloat16
+
 ZERO_PAD = os.environ.get("HAMT_ZERO_PAD_ROWS") == "1"       # ablation: zero the padding rows as before (one fill launch per buffer)
 
 
@@ -478,7 +483,7 @@ class FfnBlockFn(torch.autograd.Function):
         Mp = x16.shape[0]
         g16 = _zeros_or_empty(Mp, M, I, dev)
         if grad_on and any(ctx.needs_input_grad):
-            pre = torch.empty(M, I, dtype=torch.bfloat16, device=dev)      # gelu'(W1 x + b1), from the same erf/exp as gelu
+            pre = torch.empty(M, I, dtype=GELUP_DTYPE, device=dev)         # gelu'(W1 x + b1), from the same erf/exp as gelu
             gemm(x16[:M], weight_operand(w1, "bf16"), g16[:M], bias=b1.detach(), epilogue=L.EPI_GELU_GRAD, aux=pre)
         else:        # inference (rollout, validation): nobody reads gelu' -- one M x 3072 image less to write
             pre = None

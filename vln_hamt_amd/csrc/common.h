@@ -108,4 +108,18 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& g, float& dg) {
   dg = phi + x * 0.39894228040143267794f * e;
 }
 
+// ---- HAMT_U8G: gelu'(x) in [-0.129, 1.129] as one byte, value = 0.005 q - 0.13 (hamt.h)
+__device__ __forceinline__ uint32_t g8_pack4(const float* v) {
+  uint32_t r = 0;       // v_cvt_pk_u8_f32: round to nearest, clamp to [0, 255], insert into byte `sel`
+  r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[0], 200.0f, 26.0f), 0, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[1], 200.0f, 26.0f), 1, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[2], 200.0f, 26.0f), 2, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[3], 200.0f, 26.0f), 3, r);
+  return r;
+}
+__device__ __forceinline__ void g8_unpack4(uint32_t w, float* o) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf((float)((w >> (8 * j)) & 0xffu), 0.005f, -0.13f);
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

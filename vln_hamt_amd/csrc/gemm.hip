@@ -46,9 +46,12 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int row, int col, f
     float gg, dg;
     gelu_and_grad(v, gg, dg);
     v = gg;
-    if (g.dtype_aux == HAMT_BF16) ((bf16_t*)g.aux)[ia] = f2bf(dg); else ((float*)g.aux)[ia] = dg;
+    if (g.dtype_aux == HAMT_U8G) { const float d4[4] = {dg, 0.f, 0.f, 0.f}; ((uint8_t*)g.aux)[ia] = (uint8_t)(g8_pack4(d4) & 0xffu); }
+    else if (g.dtype_aux == HAMT_BF16) ((bf16_t*)g.aux)[ia] = f2bf(dg); else ((float*)g.aux)[ia] = dg;
   }
-  if (g.epi & HAMT_EPI_MUL_AUX) v *= (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
+  if (g.epi & HAMT_EPI_MUL_AUX)
+    v *= g.dtype_aux == HAMT_U8G ? __builtin_fmaf((float)((const uint8_t*)g.aux)[ia], 0.005f, -0.13f)
+                                 : ((g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia]);
   if (g.epi & HAMT_EPI_RELU) v = fmaxf(v, 0.0f);
   if (g.epi & (HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
     float h = (g.dtype_aux == HAMT_BF16) ? bf2f(((const bf16_t*)g.aux)[ia]) : ((const float*)g.aux)[ia];
@@ -454,6 +457,9 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
   HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
   HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
   HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX | HAMT_EPI_ADD_AUX)) || aux, "hamt_gemm: epilogue needs aux");
+  if (aux && d->dtype_aux == HAMT_U8G)
+    HAMT_CHECK_ARG((d->epilogue & (HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) && !(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_ADD_AUX | HAMT_EPI_DROPOUT)),
+                   "hamt_gemm: a HAMT_U8G aux is the gelu' image of HAMT_EPI_GELU_GRAD (without dropout) / HAMT_EPI_MUL_AUX only");
   if (d->epilogue & HAMT_EPI_DROPOUT) {
     HAMT_CHECK_ARG(d->rng && d->p_drop >= 0.0f && d->p_drop < 1.0f, "hamt_gemm: EPI_DROPOUT needs rng and 0 <= p_drop < 1");
     HAMT_CHECK_ARG(getenv("HAMT_NO_FAST") == nullptr && hamt_gemm_fast_eligible(d, A, B), "hamt_gemm: EPI_DROPOUT is implemented by the bf16 MFMA path only (bf16 operands, K %% 64 == 0)");

@@ -111,6 +111,13 @@ template <int W> __device__ __forceinline__ void st_f(float* p, const float* v) 
   for (int q = 0; q < W / 4; ++q) *(float4*)(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// the 8 aux values (bf16: 16 bytes; HAMT_U8G: 8 bytes in .x / .y) of row piece (row, col .. col + 7), for the epilogues that request
+// their aux reads ahead of the accumulator transpose (wave-uniform dtype branch)
+__device__ __forceinline__ uint4 ld_aux8(const GemmArgsF& g, int row, int col) {
+  if (g.dtype_aux == HAMT_U8G) { const uint2 u = *(const uint2*)((const uint8_t*)g.aux + (size_t)row * g.ldaux + col); return make_uint4(u.x, u.y, 0u, 0u); }
+  return *(const uint4*)((const bf16_t*)g.aux + (size_t)row * g.ldaux + col);
+}
+
 template <int EPI, int W>
 __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, const float* acc, float* ssq = nullptr,
                                           const uint4* pre_aux = nullptr, const f32x4* pre_c = nullptr, bool pre_ok = false) {
@@ -122,7 +129,7 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
   for (int j = 0; j < W; ++j) v[j] = acc[j] * g.alpha;
   const bool full = col + W <= g.N;
   const size_t ia = (size_t)row * g.ldaux + col, ic = (size_t)row * g.ldc + col;
-  const bool aux16 = g.dtype_aux == HAMT_BF16;
+  const bool aux16 = g.dtype_aux == HAMT_BF16, aux8 = g.dtype_aux == HAMT_U8G;   // (aux8: GELU_GRAD / MUL_AUX only, checked by hamt_gemm)
   // vector access to aux / C: whole segment in range, row stride and base aligned to the vector
   const bool vaux = full && g.aux && (g.ldaux % W) == 0 && ((uintptr_t)g.aux % 16) == 0;
   const bool vc = full && (g.ldc % W) == 0 && ((uintptr_t)g.C % 16) == 0;
@@ -151,15 +158,31 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
     float dg[W];
     for (int j = 0; j < W; ++j) gelu_and_grad(v[j], v[j], dg[j]);
     if (epi & HAMT_EPI_DROPOUT) for (int j = 0; j < W; ++j) dg[j] *= keep[j];
-    if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, dg); else st_f<W>((float*)g.aux + ia, dg); }
+    if (aux8) {
+      uint8_t* a8 = (uint8_t*)g.aux + ia;
+      if (vaux) { if constexpr (W == 8) *(uint2*)a8 = make_uint2(g8_pack4(dg), g8_pack4(dg + 4)); else *(uint32_t*)a8 = g8_pack4(dg); }
+      else {
+        const uint32_t w0 = g8_pack4(dg), w1 = W == 8 ? g8_pack4(dg + (W == 8 ? 4 : 0)) : 0u;
+        for (int j = 0; j < W; ++j) if (col + j < g.N) a8[j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xffu);
+      }
+    } else if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, dg); else st_f<W>((float*)g.aux + ia, dg); }
     else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]); else ((float*)g.aux)[ia + j] = dg[j]; }
   }
   if (epi & (HAMT_EPI_MUL_AUX | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
     float h[W];
     if (W == 8 && pre_aux && pre_ok) {
-      const uint32_t w4[4] = {pre_aux->x, pre_aux->y, pre_aux->z, pre_aux->w};
+      if (aux8) { g8_unpack4(pre_aux->x, h); g8_unpack4(pre_aux->y, h + (W == 8 ? 4 : 0)); }
+      else {
+        const uint32_t w4[4] = {pre_aux->x, pre_aux->y, pre_aux->z, pre_aux->w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { h[2 * q] = __uint_as_float(w4[q] << 16); h[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u); }
+        for (int q = 0; q < 4; ++q) { h[2 * q] = __uint_as_float(w4[q] << 16); h[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u); }
+      }
+    } else if (aux8) {
+      const uint8_t* a8 = (const uint8_t*)g.aux + ia;
+      if (vaux) {
+        if constexpr (W == 8) { const uint2 u = *(const uint2*)a8; g8_unpack4(u.x, h); g8_unpack4(u.y, h + (W == 8 ? 4 : 0)); }
+        else g8_unpack4(*(const uint32_t*)a8, h);
+      } else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? __builtin_fmaf((float)a8[j], 0.005f, -0.13f) : 0.f;
     } else if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
     else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
     for (int j = 0; j < W; ++j)
@@ -196,6 +219,58 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
       if (ssq) *ssq += f * f;
     }
   }
+}
+
+// ---- the epilogue of an INTERIOR tile.  epi_store above is general (ragged rows / columns, any alignment, every flag, two or three
+// dtypes per operand) and hipcc compiles it to ~50 scalar branches per 8-column row piece -- 800-1500 branches and 2-5 k scalar
+// instructions per thread for the 16-32 pieces of a tile, as much issue time as the arithmetic (profiles/r05_epilogue_isa.txt).  A tile
+// whose rows and columns all exist, with 16-byte aligned rows, takes this path instead: the tile-level test is made once (workgroup
+// uniform), the dtype of C is a template argument, the bias of a lane's 8 columns is loaded once per tile, and a piece is two LDS reads,
+// the arithmetic and one or two 16-byte stores.
+constexpr int EPI_FAST_MASK = HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_ACCUM | HAMT_EPI_MUL_AUX;
+__device__ __forceinline__ bool epi_fast_ok(const GemmArgsF& g, int epi, int m0, int n0, int bm, int bn) {
+  bool ok = (epi & ~EPI_FAST_MASK) == 0 && g.ksplit <= 1 && m0 + bm <= g.M && n0 + bn <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && g.ss == nullptr;
+  if (epi & HAMT_EPI_BIAS) ok = ok && ((uintptr_t)g.bias & 15) == 0;
+  if (epi & (HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) ok = ok && g.dtype_aux == HAMT_BF16 && (g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0;
+  return ok;
+}
+// EPI: compile-time flag set (subset of EPI_FAST_MASK); b8: the bias of columns col .. col + 7 (BIAS); pre_aux: the piece's 8 bf16 of aux
+// when the caller requested them ahead of its transpose (MUL_AUX), else nullptr
+template <int EPI, bool C16>
+__device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, const float* acc, const float* b8, const uint4* pre_aux) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (EPI & HAMT_EPI_BIAS) ? __builtin_fmaf(acc[j], g.alpha, b8[j]) : acc[j] * g.alpha;
+  if constexpr ((EPI & HAMT_EPI_GELU) != 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+  }
+  if constexpr ((EPI & HAMT_EPI_GELU_GRAD) != 0) {
+    float dg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gelu_and_grad(v[j], v[j], dg[j]);
+    st_bf<8>((bf16_t*)g.aux + (size_t)row * g.ldaux + col, dg);
+  }
+  if constexpr ((EPI & HAMT_EPI_MUL_AUX) != 0) {
+    const uint4 u = pre_aux ? *pre_aux : *(const uint4*)((const bf16_t*)g.aux + (size_t)row * g.ldaux + col);
+    const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] *= __uint_as_float(w4[q] << 16); v[2 * q + 1] *= __uint_as_float(w4[q] & 0xffff0000u); }
+  }
+  const size_t ic = (size_t)row * g.ldc + col;
+  if constexpr (C16) {
+    bf16_t* c = (bf16_t*)g.C + ic;
+    if constexpr ((EPI & HAMT_EPI_ACCUM) != 0) { float p[8]; ld_bf<8>(c, p); for (int j = 0; j < 8; ++j) v[j] += p[j]; }
+    st_bf<8>(c, v);
+  } else {
+    float* c = (float*)g.C + ic;
+    if constexpr ((EPI & HAMT_EPI_ACCUM) != 0) { float p[8]; ld_f<8>(c, p); for (int j = 0; j < 8; ++j) v[j] += p[j]; }
+    st_f<8>(c, v);
+  }
+}
+template <int EPI> __device__ __forceinline__ void epi_fast_bias(const GemmArgsF& g, int col, float* b8) {
+  if constexpr (EPI >= 0 && (EPI & HAMT_EPI_BIAS) != 0) ld_f<8>(g.bias + col, b8);
+  else { for (int j = 0; j < 8; ++j) b8[j] = 0.f; }
 }
 
 // One float per output tile: the sum of squares of what the tile stored (a weight-gradient tile's share of the global gradient
@@ -362,11 +437,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
     uint4 pa[PRE_AUX ? BM / RPP : 1];
     bool pre_ok = false;
     if constexpr (PRE_AUX) {
-      pre_ok = g.ksplit <= 1 && col + 8 <= g.N && g.dtype_aux == HAMT_BF16 && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
+      pre_ok = g.ksplit <= 1 && col + 8 <= g.N && (g.dtype_aux == HAMT_BF16 || g.dtype_aux == HAMT_U8G) && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
 #pragma unroll
       for (int p = 0; p < BM / RPP; ++p) {
         const int row = m0 + p * RPP + (t >> 4), rr = row < g.M ? row : g.M - 1;
-        if (pre_ok) pa[p] = *(const uint4*)((const bf16_t*)g.aux + (size_t)rr * g.ldaux + col);
+        if (pre_ok) pa[p] = ld_aux8(g, rr, col);
       }
     }
     __syncthreads();                               // every wave is done reading the last operand tile
@@ -378,6 +453,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
         *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[i][j];
       }
     __syncthreads();
+    constexpr bool FASTK = EPI >= 0 && (EPI & ~EPI_FAST_MASK) == 0 && !COLSUM;
+    bool fast = false;
+    if constexpr (FASTK) fast = epi_fast_ok(g, EPI, m0, n0, BM, BN);      // interior tile (workgroup uniform): see epi_fast8
+    if (fast) {
+      if constexpr (FASTK) {
+        float b8[8];
+        epi_fast_bias<EPI>(g, col, b8);
+        auto run = [&](auto c16) {
+#pragma unroll
+          for (int p = 0; p < BM / RPP; ++p) {
+            const int rl = p * RPP + (t >> 4);
+            const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
+            const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+            const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const uint4* pp = nullptr;
+            if constexpr (PRE_AUX) pp = &pa[p];
+            epi_fast8<EPI, decltype(c16)::value>(g, m0 + rl, col, v8, b8, pp);
+          }
+        };
+        if (g.dtype_c == HAMT_BF16) run(std::true_type{}); else run(std::false_type{});
+      }
+    } else {
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
       const int rl = p * RPP + (t >> 4), row = m0 + rl;
@@ -392,6 +489,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
         }
       } else if constexpr (PRE_AUX) epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr, &pa[p], nullptr, pre_ok);
       else epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
+    }
     }
     if constexpr (COLSUM) { if (g.ss) tile_sumsq_store(g, m0, n0, tile_ssq, (float*)lds); }
   }
@@ -514,9 +612,9 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
       *(f32x4*)(ct + rl * BN + ((c4 ^ (rl & 7)) << 2)) = acc[a][j];
     }
   __syncthreads();
-  for (int piece = t; piece < BM * 16; piece += 256 * G) {
-    const int rl = piece >> 4, c8 = piece & 15;
-    float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto piece_sum = [&](int rl, int c8, float* v8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = 0.f;
 #pragma unroll
     for (int q = 0; q < G; ++q) {
       const float* cq = (const float*)(lds + q * RING);
@@ -524,6 +622,34 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
       const f32x4 hi = *(const f32x4*)(cq + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
       v8[0] += lo[0]; v8[1] += lo[1]; v8[2] += lo[2]; v8[3] += lo[3]; v8[4] += hi[0]; v8[5] += hi[1]; v8[6] += hi[2]; v8[7] += hi[3];
     }
+  };
+  // interior tiles with the epilogues this kernel is launched with in the step (bias / accumulate / none): see epi_fast8.  A thread's
+  // pieces all sit in the same 8 columns (256 G threads = a multiple of 16 pieces per row), so its bias is loaded once.
+  const int fe = g.epi;
+  if ((fe == HAMT_EPI_BIAS || fe == HAMT_EPI_ACCUM || fe == 0) && epi_fast_ok(g, fe, m0, n0, BM, BN)) {
+    const int c8 = t & 15, col = n0 + c8 * 8;
+    auto run = [&](auto ec, auto c16) {
+      constexpr int E = decltype(ec)::value;
+      float b8[8];
+      epi_fast_bias<E>(g, col, b8);
+#pragma unroll
+      for (int rl = t >> 4; rl < BM; rl += 16 * G) {
+        float v8[8];
+        piece_sum(rl, c8, v8);
+        epi_fast8<E, decltype(c16)::value>(g, m0 + rl, col, v8, b8, nullptr);
+      }
+    };
+    using std::integral_constant;
+    const bool c16 = g.dtype_c == HAMT_BF16;
+    if (fe == HAMT_EPI_BIAS) { if (c16) run(integral_constant<int, HAMT_EPI_BIAS>{}, std::true_type{}); else run(integral_constant<int, HAMT_EPI_BIAS>{}, std::false_type{}); }
+    else if (fe == HAMT_EPI_ACCUM) { if (c16) run(integral_constant<int, HAMT_EPI_ACCUM>{}, std::true_type{}); else run(integral_constant<int, HAMT_EPI_ACCUM>{}, std::false_type{}); }
+    else { if (c16) run(integral_constant<int, 0>{}, std::true_type{}); else run(integral_constant<int, 0>{}, std::false_type{}); }
+    return;
+  }
+  for (int piece = t; piece < BM * 16; piece += 256 * G) {
+    const int rl = piece >> 4, c8 = piece & 15;
+    float v8[8];
+    piece_sum(rl, c8, v8);
     epi_store<-1, 8>(g, m0 + rl, n0 + c8 * 8, v8);
   }
 }
@@ -914,8 +1040,47 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   if constexpr (NB == 4) col = n0 + p8_index<BGS>(32 * wc + (c8 & 3) * 8, c8 >> 2);
   else col = c8 < 6 ? n0 + p8_bcol3<B_KM>(c8 < 4 ? 32 * wc + c8 * 8 : 16 * wc + (c8 - 4) * 8, c8 >> 2) : g.N;   // (chunks 6, 7: no columns)
   bool pre_ok = false;
-  if constexpr (PRE_AUX) pre_ok = col + 8 <= g.N && g.dtype_aux == HAMT_BF16 && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
+  if constexpr (PRE_AUX) pre_ok = col + 8 <= g.N && (g.dtype_aux == HAMT_BF16 || g.dtype_aux == HAMT_U8G) && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
   if constexpr (PRE_C) pre_ok = col + 8 <= g.N && g.dtype_c == HAMT_F32 && (g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0;
+  constexpr bool FASTK = EPI >= 0 && (EPI & ~EPI_FAST_MASK) == 0 && !COLSUM;
+  bool fast = false;
+  if constexpr (FASTK) fast = epi_fast_ok(g, EPI, m0, n0, 256, 64 * NB);      // interior tile (workgroup uniform): see epi_fast8
+  if (fast) {
+    if constexpr (FASTK) {
+      const bool live = NB == 4 || c8 < 6;         // (256 x 192 tile: row-piece chunks 6 and 7 of a wave's 64-column slab hold no columns)
+      float b8[8];
+      if (live) epi_fast_bias<EPI>(g, col, b8);
+      auto run = [&](auto c16) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint4 pa[PRE_AUX ? 8 : 1];
+          if constexpr (PRE_AUX) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+              if (live) pa[it] = *(const uint4*)((const bf16_t*)g.aux + (size_t)(m0 + 128 * wr + 64 * h + it * 8 + (lane >> 3)) * g.ldaux + col);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const int rl = i * 16 + (lane & 15), c4 = j * 4 + (lane >> 4);
+              *(f32x4*)(ct + rl * 64 + ((c4 ^ (rl & 7)) << 2)) = acc[4 * h + i][j];
+            }
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int rl = it * 8 + (lane >> 3), row = m0 + 128 * wr + 64 * h + rl;
+            const f32x4 lo = *(const f32x4*)(ct + rl * 64 + (((2 * c8) ^ (rl & 7)) << 2));
+            const f32x4 hi = *(const f32x4*)(ct + rl * 64 + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+            const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const uint4* pp = nullptr;
+            if constexpr (PRE_AUX) pp = &pa[it];
+            if (live) epi_fast8<EPI, decltype(c16)::value>(g, row, col, v8, b8, pp);
+          }
+        }
+      };
+      if (g.dtype_c == HAMT_BF16) run(std::true_type{}); else run(std::false_type{});
+    }
+  } else {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     uint4 pa[PRE_AUX ? 8 : 1];
@@ -925,7 +1090,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
       for (int it = 0; it < 8; ++it) {
         const int row = m0 + 128 * wr + 64 * h + it * 8 + (lane >> 3);
         const int rr = row < g.M ? row : g.M - 1;            // (an out-of-range row's piece is loaded from the last row and never used)
-        if constexpr (PRE_AUX) { if (pre_ok) pa[it] = *(const uint4*)((const bf16_t*)g.aux + (size_t)rr * g.ldaux + col); }
+        if constexpr (PRE_AUX) { if (pre_ok) pa[it] = ld_aux8(g, rr, col); }
         if constexpr (PRE_C) {
           if (pre_ok) { const f32x4* cp = (const f32x4*)((const float*)g.C + (size_t)rr * g.ldc + col); pc[2 * it] = cp[0]; pc[2 * it + 1] = cp[1]; }
         }
@@ -948,6 +1113,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
       else if constexpr (PRE_C) epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr, nullptr, &pc[2 * it], pre_ok);
       else epi_store<EPI, 8>(g, row, col, v8, (COLSUM && g.ss) ? &tile_ssq : nullptr);
     }
+  }
   }
   if constexpr (COLSUM) {
     if (g.ss) {

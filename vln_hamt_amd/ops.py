@@ -71,6 +71,8 @@ def _dt(t: torch.Tensor) -> int:
         return L.HAMT_F32
     if t.dtype == torch.bfloat16:
         return L.HAMT_BF16
+    if t.dtype == torch.uint8:       # the one-byte gelu' image (hamt.h: HAMT_U8G) -- `aux` of EPI_GELU_GRAD / EPI_MUL_AUX only
+        return L.HAMT_U8G
     raise L.HamtError(f"unsupported dtype {t.dtype}")
 
 
