@@ -224,12 +224,13 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
 // ---- the epilogue of an INTERIOR tile.  epi_store above is general (ragged rows / columns, any alignment, every flag, two or three
 // dtypes per operand) and hipcc compiles it to ~50 scalar branches per 8-column row piece -- 800-1500 branches and 2-5 k scalar
 // instructions per thread for the 16-32 pieces of a tile, as much issue time as the arithmetic (profiles/r05_epilogue_isa.txt).  A tile
-// whose rows and columns all exist, with 16-byte aligned rows, takes this path instead: the tile-level test is made once (workgroup
+// whose columns all exist (rows may be ragged), with 16-byte aligned rows, takes this path instead: the tile-level test is made once (workgroup
 // uniform), the dtype of C is a template argument, the bias of a lane's 8 columns is loaded once per tile, and a piece is two LDS reads,
 // the arithmetic and one or two 16-byte stores.
 constexpr int EPI_FAST_MASK = HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_ACCUM | HAMT_EPI_MUL_AUX;
 __device__ __forceinline__ bool epi_fast_ok(const GemmArgsF& g, int epi, int m0, int n0, int bm, int bn) {
-  bool ok = (epi & ~EPI_FAST_MASK) == 0 && g.ksplit <= 1 && m0 + bm <= g.M && n0 + bn <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && g.ss == nullptr;
+  (void)m0; (void)bm;     // (rows may be ragged: epi_fast8 skips rows >= M, one compare per piece)
+  bool ok = (epi & ~EPI_FAST_MASK) == 0 && g.ksplit <= 1 && n0 + bn <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0;
   if (epi & HAMT_EPI_BIAS) ok = ok && ((uintptr_t)g.bias & 15) == 0;
   if (epi & (HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) ok = ok && g.dtype_aux == HAMT_BF16 && (g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0;
   return ok;
@@ -237,7 +238,8 @@ __device__ __forceinline__ bool epi_fast_ok(const GemmArgsF& g, int epi, int m0,
 // EPI: compile-time flag set (subset of EPI_FAST_MASK); b8: the bias of columns col .. col + 7 (BIAS); pre_aux: the piece's 8 bf16 of aux
 // when the caller requested them ahead of its transpose (MUL_AUX), else nullptr
 template <int EPI, bool C16>
-__device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, const float* acc, const float* b8, const uint4* pre_aux) {
+__device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, const float* acc, const float* b8, const uint4* pre_aux, float* ssq = nullptr) {
+  if (row >= g.M) return;
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = (EPI & HAMT_EPI_BIAS) ? __builtin_fmaf(acc[j], g.alpha, b8[j]) : acc[j] * g.alpha;
@@ -266,6 +268,7 @@ __device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, 
     float* c = (float*)g.C + ic;
     if constexpr ((EPI & HAMT_EPI_ACCUM) != 0) { float p[8]; ld_f<8>(c, p); for (int j = 0; j < 8; ++j) v[j] += p[j]; }
     st_f<8>(c, v);
+    if (ssq) { for (int j = 0; j < 8; ++j) *ssq += v[j] * v[j]; }       // (weight-gradient tiles: the sum of squares of what was stored)
   }
 }
 template <int EPI> __device__ __forceinline__ void epi_fast_bias(const GemmArgsF& g, int col, float* b8) {
@@ -1043,9 +1046,37 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
   if constexpr (PRE_AUX) pre_ok = col + 8 <= g.N && (g.dtype_aux == HAMT_BF16 || g.dtype_aux == HAMT_U8G) && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0;
   if constexpr (PRE_C) pre_ok = col + 8 <= g.N && g.dtype_c == HAMT_F32 && (g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0;
   constexpr bool FASTK = EPI >= 0 && (EPI & ~EPI_FAST_MASK) == 0 && !COLSUM;
+  constexpr bool FASTW = COLSUM && EPI == -2 && NB == 4;      // the weight-gradient tile: fp32 store or C +=, tile sum of squares
   bool fast = false;
   if constexpr (FASTK) fast = epi_fast_ok(g, EPI, m0, n0, 256, 64 * NB);      // interior tile (workgroup uniform): see epi_fast8
+  if constexpr (FASTW) fast = g.dtype_c == HAMT_F32 && epi_fast_ok(g, g.epi & HAMT_EPI_ACCUM, m0, n0, 256, 256);
   if (fast) {
+    if constexpr (FASTW) {
+      const float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float* sq = g.ss ? &tile_ssq : nullptr;
+      auto run = [&](auto accc) {
+        constexpr int E = decltype(accc)::value ? HAMT_EPI_ACCUM : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const int rl = i * 16 + (lane & 15), c4 = j * 4 + (lane >> 4);
+              *(f32x4*)(ct + rl * 64 + ((c4 ^ (rl & 7)) << 2)) = acc[4 * h + i][j];
+            }
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int rl = it * 8 + (lane >> 3), row = m0 + 128 * wr + 64 * h + rl;
+            const f32x4 lo = *(const f32x4*)(ct + rl * 64 + (((2 * c8) ^ (rl & 7)) << 2));
+            const f32x4 hi = *(const f32x4*)(ct + rl * 64 + (((2 * c8 + 1) ^ (rl & 7)) << 2));
+            const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            epi_fast8<E, false>(g, row, col, v8, b8, nullptr, sq);
+          }
+        }
+      };
+      if (g.epi & HAMT_EPI_ACCUM) run(std::true_type{}); else run(std::false_type{});
+    }
     if constexpr (FASTK) {
       const bool live = NB == 4 || c8 < 6;         // (256 x 192 tile: row-piece chunks 6 and 7 of a wave's 64-column slab hold no columns)
       float b8[8];
@@ -1057,7 +1088,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
           if constexpr (PRE_AUX) {
 #pragma unroll
             for (int it = 0; it < 8; ++it)
-              if (live) pa[it] = *(const uint4*)((const bf16_t*)g.aux + (size_t)(m0 + 128 * wr + 64 * h + it * 8 + (lane >> 3)) * g.ldaux + col);
+              if (live) pa[it] = *(const uint4*)((const bf16_t*)g.aux + (size_t)min(m0 + 128 * wr + 64 * h + it * 8 + (lane >> 3), g.M - 1) * g.ldaux + col);
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
