@@ -57,8 +57,10 @@ int hamt_last_kernel(char* buf, size_t n);
  *   HAMT_WS_WGRAD_TABLE  {M_0, M_1, ...}  (output rows of every problem) hamt_wgrad_grouped `table`
  *   HAMT_WS_LNRED_TABLE  {n}        hamt_ln_bwd_reduce_grouped `table`
  *   HAMT_WS_VIS_EMBED_BWD {M, H}    hamt_vis_embed_bwd `ws`
+ *   HAMT_WS_EMBED_BWD     {R, H}    hamt_embed_sum_bwd `ws`
  * returns the size in bytes, or 0 for an unknown op / malformed shape */
-enum { HAMT_WS_GEMM_SPLITK = 0, HAMT_WS_COLSUM = 1, HAMT_WS_SUMSQ = 2, HAMT_WS_LN_BWD = 3, HAMT_WS_WGRAD_TABLE = 4, HAMT_WS_LNRED_TABLE = 5, HAMT_WS_VIS_EMBED_BWD = 6 };
+enum { HAMT_WS_GEMM_SPLITK = 0, HAMT_WS_COLSUM = 1, HAMT_WS_SUMSQ = 2, HAMT_WS_LN_BWD = 3, HAMT_WS_WGRAD_TABLE = 4, HAMT_WS_LNRED_TABLE = 5, HAMT_WS_VIS_EMBED_BWD = 6,
+       HAMT_WS_EMBED_BWD = 7 /* {R, H}: hamt_embed_sum_bwd `ws` = max(HAMT_WS_COLSUM {R, H}, 8 R bytes) */ };
 size_t hamt_workspace_bytes(int op, const int* shape, int nshape);
 
 /* ------------------------------------------------------------------------------------------------
@@ -331,6 +333,10 @@ int hamt_gather_rows(int R, int W, const float* src, int ld_src, const int64_t* 
                      int ld_base, float* out, int ld_out, int col0, void* stream);
 int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
                           float* dst, int ld_dst, void* stream);
+/* scatter_add in a FIXED summation order (colliding rows are added in row order by one writer per table row: bit-reproducible, unlike the
+ * atomic form); idx must be given.  ws: 2 R ints of device scratch.  Beyond 32 768 source rows it falls back to the atomic kernel. */
+int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
+                                  float* dst, int ld_dst, int* ws, void* stream);
 /* the same for a CONTIGUOUS table dst[T][W] of T <= 8 rows (idx must be given): fixed-order sums instead of atomics -- the table's
  * gradient is then bit-reproducible.  ws: 64 * T * W floats. */
 int hamt_scatter_add_rows_small(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, int T, float* dst,
@@ -339,8 +345,9 @@ int hamt_scatter_add_rows_small(int R, int W, const float* src, int ld_src, int 
 /* BertEmbeddings sum (A1, vilmodel.py:62-66): z[b*L+l] = word[ids[b,l]] + pos[l] + type0 */
 int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* word, const float* pos,
                        const float* type_row, float* z, void* stream);
-/* backward: dword[ids] += dz (atomic), dpos[l] += sum_b dz, dtype_row += sum dz (any of the three may be NULL);
- * ws: HAMT_WS_COLSUM {B * L, H} bytes of scratch, needed when dtype_row is given */
+/* backward: dword[ids] += dz, dpos[l] += sum_b dz, dtype_row += sum dz (any of the three may be NULL);
+ * ws: HAMT_WS_EMBED_BWD {B * L, H} bytes of scratch, needed when dtype_row is given; with ws the word rows are summed in a fixed order
+ * (hamt_scatter_add_rows_ordered), without it (or beyond 32 768 rows) by atomic adds */
 int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword,
                        float* dpos, float* dtype_row, float* ws, void* stream);
 

@@ -1887,7 +1887,7 @@ def _two_rank_batch(t, r, cfg, shapes):
     return make_batch(t, 4, cfg, seed=100 * r + sum(map(ord, t)), ragged=True, device=DEV, **kw)
 
 
-def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False, long_run=False):
+def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False, long_run=False, skip_at=None):
     """One data-parallel rank (gloo carries the collectives of CUDA tensors, so two ranks can share the box's single
     GPU): the product's multi-GPU step on this rank's own batches.  use_graph == "wrapped": the reference's OWN loop lines
     (main_r2r.py:150-156, 237-281) around `wrap_model` -- no exchange call, no optimizer argument to clip_grad_norm_, a plain
@@ -1931,12 +1931,13 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
         o.step()                                     # main_r2r.py:229-230
         batches = {t: _two_rank_batch(t, rank, cfg, shapes) for t in set(seq)}
         try:
-            for t in seq:
+            for i_, t in enumerate(seq):
                 loss = model(batches[t], task=t, compute_loss=True)
                 loss = loss.mean()
                 loss.backward()
                 clip_grad_norm_(model.parameters(), 5.0)
-                o.step()
+                if i_ != skip_at:                    # (skip_at: a loop that drops this pass -- NaN guard, early `continue` -- and only zeroes the gradients)
+                    o.step()
                 o.zero_grad()
             sync = model.grad_sync
             assert sync is not None and bool(getattr(sync, "sharded", False)) == bool(sharded), sync
@@ -2061,7 +2062,8 @@ def test_exchange_schedule_is_independent_of_the_batch(sharded):
                                                              ("fp32", True, True, True), ("fp32", False, True, True), ("bf16", True, True, True),
                                                              ("fp32", True, False, True), ("bf16", True, False, True),
                                                              ("fp32", "wrapped", False, False), ("fp32", "wrapped", True, False),
-                                                             ("bf16", "wrapped", True, True), ("bf16", "wrapped", False, True)])
+                                                             ("bf16", "wrapped", True, True), ("bf16", "wrapped", False, True),
+                                                             ("fp32", "wrapped", True, 2), ("fp32", "wrapped", False, 2)])
 def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph, sharded, long_run):
     """world_size = 2 for real: two processes, different batches, the product's overlapped exchange (gloo moves the
     CUDA tensors) -- against one process that computes both ranks' gradients on the same weights, averages them,
@@ -2080,8 +2082,12 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     from vln_hamt_amd.synth import make_batch
     if not wgrad.ENABLED:
         pytest.skip("HAMT_NO_DEFER_WGRAD")
+    # long_run == 2: the short run with its THIRD pass dropped after backward + clip (no optimizer.step(), only zero_grad()): the pending
+    # exchange must be discarded -- the next backward exchanges again instead of raising, and no stale norm reaches the next update
+    skip_at = 2 if long_run == 2 else None
+    long_run = long_run is True
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph, sharded, long_run), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph, sharded, long_run, skip_at), nprocs=2, join=True)
     p0, p1 = torch.load(os.path.join(str(tmp_path), "params0.pt")), torch.load(os.path.join(str(tmp_path), "params1.pt"))
     assert torch.equal(p0, p1), "ranks diverged"
     x0, x1 = torch.load(os.path.join(str(tmp_path), "exchanges0.pt")), torch.load(os.path.join(str(tmp_path), "exchanges1.pt"))
@@ -2104,7 +2110,9 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     o.materialize()
     bs = [{t: _two_rank_batch(t, r, cfg, shapes) for t in set(seq)} for r in range(2)]
     ref_losses = [[], []]
-    for t in seq:
+    for i_, t in enumerate(seq):
+        if i_ == skip_at:
+            continue
         l_ = m(bs[0][t], t, True).mean()
         ref_losses[0].append(float(l_))
         l_.backward()

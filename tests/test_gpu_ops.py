@@ -156,7 +156,9 @@ def test_gemm_k_groups(layout, shape, variant):
     tol = 2e-5 * math.sqrt(K) / 4
     out = torch.empty(M, N, device=DEV)
     ops.gemm(a16, b16, out, b_kmajor=b_km, prec="bf16")
-    assert L.last_kernel().startswith(variant), L.last_kernel()
+    # (about one round of 128-square tiles with a plain / bias / accumulate epilogue: the four-deep 128-square tile, gemm_q4.hip;
+    # the K-group tile of that size keeps the other epilogues)
+    assert L.last_kernel().startswith("gemm_q4_kernel" if variant.startswith("gemm_kg_kernel<128") else variant), L.last_kernel()
     close(out, ref, tol, f"kg plain {layout} {shape}")
     bias = rnd(N, seed=5)
     base = rnd(M, N, seed=6)
@@ -182,7 +184,7 @@ def test_gemm_k_groups(layout, shape, variant):
         Az = A.clone()
         Az[:, K - 5:] = 0
         ops.gemm(Az.to(DEV).to(torch.bfloat16), b_st[:K - 5].contiguous().to(DEV).to(torch.bfloat16), out, b_kmajor=True, prec="bf16", k_red=K)
-        assert L.last_kernel().startswith(variant), L.last_kernel()
+        assert L.last_kernel().startswith("gemm_q4_kernel" if variant.startswith("gemm_kg_kernel<128") else variant), L.last_kernel()
         close(out, bf16_round(Az).double() @ bf16_round(B).double(), tol, "kg nn ragged K")
 
 
@@ -209,9 +211,17 @@ BENCH_GEMMS = [   # (layout, M, N, K, epilogue, C dtype, kernel the launcher mus
     ("nn", 5120, 2304, 768, "none", "bf16", "gemm_p8_kernel<0, false, true, 3>"),
     ("nn", 5013, 2248, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 3>"),    # ragged rows and a ragged 192-column tile, K-strided B
     ("nn", 5009, 3072, 768, "mulaux", "bf16", "gemm_p8_kernel<256, false, true, 4>"),       # ragged rows
-    ("nt", 5120, 768, 768, "bias", "bf16", "gemm_fast_kernel<64, 1, false, false>"),     # attention output projection
-    ("nn", 5120, 768, 768, "none", "bf16", "gemm_fast_kernel<64, 0, false, true>"),      # its dgrad
-    ("nt", 2752, 768, 768, "bias", "f32", "gemm_fast_kernel<64, 1, false, false>"),      # vision stream
+    ("nt", 5120, 768, 768, "bias", "bf16", "gemm_q4_kernel<1, false>"),                  # attention output projection: 240 tiles of 128 x 128, four-deep ring
+    ("nn", 5120, 768, 768, "none", "bf16", "gemm_q4_kernel<0, true>"),                   # its dgrad
+    ("nt", 2752, 768, 768, "bias", "f32", "gemm_q4_kernel<1, false>"),                   # vision stream (132 tiles)
+    ("nt", 1280, 768, 768, "bias", "bf16", "gemm_kg_kernel<32, 2, 4, false>"),           # (B = 16: too few 128-square tiles -- K groups on 32-row tiles)
+    ("nn", 1280, 768, 768, "none", "bf16", "gemm_kg_kernel<32, 2, 4, true>"),
+    ("nt", 5120, 1536, 768, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),   # key / value projection of the cross attention (N = 1536: not the q4 tile's)
+    ("nt", 5003, 760, 832, "bias", "f32", "gemm_q4_kernel<1, false>"),                   # ragged rows and columns
+    ("nn", 5003, 760, 832, "acc", "f32", "gemm_q4_kernel<8, true>"),
+    ("nn", 5120, 768, 2304, "acc", "f32", "gemm_q4_kernel<8, true>"),                    # dgrad of QKV into the residual gradient
+    ("nt", 3200, 768, 192, "bias", "bf16", "gemm_q4_kernel<1, false>"),                  # the shortest reduction the ring takes (3 k-tiles)
+    ("nt", 3200, 768, 256, "none", "bf16", "gemm_q4_kernel<0, false>"),
     ("nt", 4096, 4096, 64, "bias", "bf16", "gemm_fast_kernel<128, 1, false, false>"),    # 128-row plain tile
     ("nn", 4096, 4096, 64, "acc", "f32", "gemm_fast_kernel<128, 8, false, true>"),
     ("nt", 5120, 3072, 768, "gelugrad8", "bf16", "gemm_p8_kernel<129, false, false, 4>"),   # text FFN-1, gelu' saved as one byte (HAMT_U8G)
@@ -221,8 +231,8 @@ BENCH_GEMMS = [   # (layout, M, N, K, epilogue, C dtype, kernel the launcher mus
     ("nn", 11520, 3072, 768, "mulaux8", "bf16", "gemm_p8_kernel<256, false, true, 3>"),
     ("nn", 2752, 3072, 768, "mulaux8", "bf16", None),
     ("nn", 389, 3068, 768, "mulaux8", "bf16", None),
-    ("nt", 5120, 768, 3072, "bias", "bf16", "gemm_kg_kernel<128, 2, 2, false>"),         # text FFN-2 (K groups)
-    ("nn", 5120, 768, 3072, "acc", "f32", "gemm_kg_kernel<128, 2, 2, true>"),
+    ("nt", 5120, 768, 3072, "bias", "bf16", "gemm_q4_kernel<1, false>"),                  # text FFN-2
+    ("nn", 5120, 768, 3072, "acc", "f32", "gemm_q4_kernel<8, true>"),
 ]
 
 
@@ -328,7 +338,7 @@ def _grad_report(named, ref_grads, what, cos_min, probe_tol):
 @pytest.mark.parametrize("B,S", [(64, 80), (320, 36)])       # the step's text stream (5120 rows) and its panorama encoder (64 x 5 panoramas x 36 views = 11520 rows)
 def test_bert_layer_block_at_bench_rows_vs_fp64(B, S):
     """SelfAttnBlockFn + FfnBlockFn (BertLayer, vilmodel.py:188-201) forward + backward at the bench's row counts -- the shapes
-    whose GEMMs run on gemm_p8_kernel / gemm_kg_kernel<128, ...> / gemm_fast_kernel<64, ...> and whose weight gradients run on
+    whose GEMMs run on gemm_p8_kernel / gemm_q4_kernel / gemm_fast_kernel<64, ...> and whose weight gradients run on
     the grouped 256-square tile -- against an fp64 torch restatement with the same (bf16-rounded) weights."""
     from vln_hamt_amd.model import vilmodel
     from vln_hamt_amd.modeling import HamtConfig

@@ -97,6 +97,7 @@ SIGNATURES = {
     "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
     "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
     "hamt_scatter_add_rows_small": [i32, i32, vp, i32, i32, vp, i32, vp, vp, vp],
+    "hamt_scatter_add_rows_ordered": [i32, i32, vp, i32, i32, vp, vp, i32, vp, vp],
     "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "hamt_embed_sum_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "hamt_mean_mid_fwd": [i32, i32, i32, vp, vp, vp],
@@ -187,7 +188,7 @@ def workspace_bytes(op: int, *shape) -> int:
     return int(load().hamt_workspace_bytes(op, arr, len(shape)))
 
 
-WS_GEMM_SPLITK, WS_COLSUM, WS_SUMSQ, WS_LN_BWD, WS_WGRAD_TABLE, WS_LNRED_TABLE, WS_VIS_EMBED_BWD = range(7)
+WS_GEMM_SPLITK, WS_COLSUM, WS_SUMSQ, WS_LN_BWD, WS_WGRAD_TABLE, WS_LNRED_TABLE, WS_VIS_EMBED_BWD, WS_EMBED_BWD = range(8)
 
 
 def check(rc: int, name: str):

@@ -292,6 +292,60 @@ extern "C" int hamt_scatter_add_rows_small(int R, int W, const float* src, int l
   HAMT_CHECK_LAUNCH("hamt_scatter_add_rows_small");
   return HAMT_OK;
 }
+// ---- dst[idx[r]] += src[r] in a FIXED order for any table (the word embeddings: 30 522 rows, a few thousand source rows with repeated
+// tokens).  The atomic scatter adds colliding rows in whatever order the hardware serves them: the table's gradient then differs in the
+// last bit from run to run (tools/grad_bitwise_repeat.py: up to 30 distinct values in 30 repetitions), which is enough to flip a rounded
+// two-rank average.  Here: (1) every source row finds the next row with the same index and whether it is the first
+// such row (R x R comparisons through LDS tiles: 26 M for the step's 5120 rows, a few us); (2) one block per FIRST row walks its chain in
+// row order, sums in registers and adds the sum to the table row -- one writer per table row, no atomics.
+__global__ __launch_bounds__(256) void scatter_chain_kernel(int R, const int64_t* __restrict__ idx, int* __restrict__ next, int* __restrict__ head) {
+  __shared__ int64_t tile[1024];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int64_t mine = r < R ? idx[r] : -1;
+  int nx = 0x7fffffff, first = r;
+  for (int t0 = 0; t0 < R; t0 += 1024) {
+    for (int i = threadIdx.x; i < 1024; i += 256) tile[i] = t0 + i < R ? idx[t0 + i] : -2;
+    __syncthreads();
+    if (r < R) {
+#pragma unroll 8
+      for (int i = 0; i < 1024; ++i) {
+        const int q = t0 + i;
+        if (tile[i] == mine) { if (q < first) first = q; if (q > r && q < nx) nx = q; }
+      }
+    }
+    __syncthreads();
+  }
+  if (r < R) { next[r] = nx == 0x7fffffff ? -1 : nx; head[r] = first == r; }
+}
+__global__ __launch_bounds__(256) void scatter_chain_add_kernel(int R, int W, const float* __restrict__ src, int ld_src, int col0,
+                                                                const int64_t* __restrict__ idx, const int* __restrict__ next,
+                                                                const int* __restrict__ head, float* __restrict__ dst, int ld_dst) {
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    if (!head[r]) continue;                                   // (block uniform)
+    float* drow = dst + (size_t)(idx ? idx[r] : r) * ld_dst;
+    for (int c = threadIdx.x; c < W; c += 256) {
+      float acc = 0.f;
+      for (int q = r; q >= 0; q = next[q]) acc += src[(size_t)q * ld_src + col0 + c];
+      drow[c] += acc;
+    }
+  }
+}
+// ws: 2 R ints.  false: R too large for the quadratic chain search (the caller falls back to atomics)
+static bool scatter_add_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst, int ld_dst, int* ws, hipStream_t s) {
+  if (R > 32768 || !idx || !ws) return false;
+  hipLaunchKernelGGL(scatter_chain_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, idx, ws, ws + R);
+  hipLaunchKernelGGL(scatter_chain_add_kernel, dim3(R < 4096 ? R : 4096), dim3(256), 0, s, R, W, src, ld_src, col0, idx, ws, ws + R, dst, ld_dst);
+  return true;
+}
+extern "C" int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst,
+                                             int ld_dst, int* ws, void* stream) {
+  HAMT_CHECK_ARG(src && dst && idx && ws, "hamt_scatter_add_rows_ordered: null pointer");
+  if (R == 0) return HAMT_OK;
+  if (!scatter_add_ordered(R, W, src, ld_src, col0, idx, dst, ld_dst, ws, as_stream(stream)))
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nblocks((size_t)R * W)), dim3(256), 0, as_stream(stream), R, W, src, ld_src, col0, idx, dst, ld_dst);
+  HAMT_CHECK_LAUNCH("hamt_scatter_add_rows_ordered");
+  return HAMT_OK;
+}
 extern "C" int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst,
                                      int ld_dst, void* stream) {
   HAMT_CHECK_ARG(src && dst, "hamt_scatter_add_rows: null pointer");
@@ -334,10 +388,12 @@ extern "C" int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const
   // fast as 15 000 can -- against 26 here), the positions by the slice-sum kernel (dz = B slices of L * H), the token-type row by the
   // column-sum kernels.  The last two replaced a serial loop per thread (26 + 35 us) at the tail of the backward chain.
   HAMT_CHECK_ARG(ids && dz, "hamt_embed_sum_bwd: null pointer");
-  HAMT_CHECK_ARG(!dtype_row || ws, "hamt_embed_sum_bwd: dtype_row needs ws (HAMT_WS_COLSUM {B * L, H} bytes)");
+  HAMT_CHECK_ARG(!dtype_row || ws, "hamt_embed_sum_bwd: dtype_row needs ws (HAMT_WS_EMBED_BWD {B * L, H} bytes)");
   if (B * L == 0) return HAMT_OK;
   hipStream_t s = as_stream(stream);
-  if (dword) hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(nblocks((size_t)B * L * H)), dim3(256), 0, s, B, L, H, ids, dz, dword);
+  // (the word rows: in a fixed order when ws is given -- scatter_add_ordered above -- else, or beyond 32 768 rows, by atomic adds)
+  if (dword && !scatter_add_ordered(B * L, H, dz, H, 0, ids, dword, H, (int*)ws, s))
+    hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(nblocks((size_t)B * L * H)), dim3(256), 0, s, B, L, H, ids, dz, dword);
   if (dpos) hamt_reduce_partials(B, L * H, dz, dpos, 1, s);
   HAMT_CHECK_LAUNCH("hamt_embed_sum_bwd");
   if (dtype_row) return hamt_colsum(B * L, H, dz, H, HAMT_F32, dtype_row, 1, ws, stream);

@@ -853,7 +853,7 @@ class EmbedSumFn(torch.autograd.Function):
         dword, dpos, dtyp = outs
         if any(r is None for r in rets):
             wgrad.queue(dev).current()              # (opens the pass: orders this stream behind an overlapped optimizer update)
-        ws = torch.empty(L.workspace_bytes(L.WS_COLSUM, B * Lq, H) // 4, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.workspace_bytes(L.WS_EMBED_BWD, B * Lq, H) // 4, dtype=torch.float32, device=dev)
         L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, _p(ids), _p(dz), _p(dword), _p(dpos), _p(dtyp), _p(ws), _stream()),
                 "hamt_embed_sum_bwd")      # (dtyp: row 0 of the type table)
         for p, r, o in zip(ctx.tables, rets, outs):
@@ -863,14 +863,16 @@ class EmbedSumFn(torch.autograd.Function):
 
 
 def _scatter_add(R, W, dout, idx, table):
-    """table[idx[r]] += dout[r]: tables of a few rows (token / navigability types, the cls token) by fixed-order sums
-    (hamt_scatter_add_rows_small: bit-reproducible), anything else by atomics"""
+    """table[idx[r]] += dout[r] in a fixed summation order (bit-reproducible): tables of a few rows (token / navigability types, the cls
+    token) by per-block partial sums (hamt_scatter_add_rows_small), larger ones (position tables, compaction scatters) by one writer per
+    table row walking its colliding source rows in row order (hamt_scatter_add_rows_ordered)"""
     T = table.numel() // W
     if T <= 8 and table.is_contiguous():
         ws = torch.empty(64 * T * W, dtype=torch.float32, device=dout.device)
         L.check(L.load().hamt_scatter_add_rows_small(R, W, _p(dout), W, 0, _p(idx), T, _p(table), _p(ws), _stream()), "hamt_scatter_add_rows_small")
     else:
-        L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(table), W, _stream()), "hamt_scatter_add_rows")
+        ws = torch.empty(2 * max(R, 1), dtype=torch.int32, device=dout.device)
+        L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(dout), W, 0, _p(idx), _p(table), W, _p(ws), _stream()), "hamt_scatter_add_rows_ordered")
 
 
 class GatherRowsFn(torch.autograd.Function):

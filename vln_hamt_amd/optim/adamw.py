@@ -507,6 +507,14 @@ class AdamW(Optimizer):
         self._packed = False
         self._fused = None
         from .. import wgrad
+        sync = getattr(self, "_sharded_sync", None)
+        if sync is not None and sync._unconsumed:
+            # an exchange ran and no update consumed it (a skipped step): the arena holds rank means in the owned chunks only -- drop it
+            # all, and let the next pass exchange again instead of raising
+            sync.discard()
+            self._pending_clip = None
+            if self._built:
+                self._flat_g._hamt_dirty = True
         if self._built and getattr(self._flat_g, "_hamt_dirty", False):
             self.wait_update()
             # something accumulated into arena slots it assumed zero and no update (which zeroes the arena) has run since

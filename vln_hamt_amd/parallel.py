@@ -519,6 +519,14 @@ class ShardedGradSync(OverlappedGradSync):
                             "detached and attach it for the last micro-batch, or use OverlappedGradSync (HAMT_SHARDED=0)")
         self._unconsumed = True
 
+    def discard(self):
+        """Forget a pending exchange whose update will not run (a loop that skips optimizer.step() for this pass: NaN guard, early
+        break -- and then calls optimizer.zero_grad(), which calls this): the next backward pass may exchange again, and a norm
+        reduced for the skipped pass is not mistaken for the next one's."""
+        self._unconsumed = False
+        self._norm_reduced = False
+        self.done = False
+
     def run(self, plan, sumsq=False):
         self._once_per_update()
         super().run(plan, sumsq)
