@@ -60,7 +60,7 @@ int hamt_last_kernel(char* buf, size_t n);
  *   HAMT_WS_EMBED_BWD     {R, H}    hamt_embed_sum_bwd `ws`
  * returns the size in bytes, or 0 for an unknown op / malformed shape */
 enum { HAMT_WS_GEMM_SPLITK = 0, HAMT_WS_COLSUM = 1, HAMT_WS_SUMSQ = 2, HAMT_WS_LN_BWD = 3, HAMT_WS_WGRAD_TABLE = 4, HAMT_WS_LNRED_TABLE = 5, HAMT_WS_VIS_EMBED_BWD = 6,
-       HAMT_WS_EMBED_BWD = 7 /* {R, H}: hamt_embed_sum_bwd `ws` = max(HAMT_WS_COLSUM {R, H}, 8 R bytes) */ };
+       HAMT_WS_EMBED_BWD = 7 /* {R, H}: hamt_embed_sum_bwd `ws` = max(HAMT_WS_COLSUM {R, H}, 136 R bytes) */ };
 size_t hamt_workspace_bytes(int op, const int* shape, int nshape);
 
 /* ------------------------------------------------------------------------------------------------
@@ -282,22 +282,6 @@ int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* residual, con
 int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                 const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                 float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);
-/* Dense layer + bias + dropout + residual + LayerNorm in one launch (forward; bf16 operands, fp32 accumulate and statistics):
- *   z = dropout_pre(a16[M,K] w16[H,K]^T + bias) + residual ;  y = LN(z) gamma + beta
- * -- BertSelfOutput / BertOutput / the output half of BertXAttention (vilmodel.py:139-143, 181-185, 351-360) without the HBM
- * round trip of the dense output and the second launch.  Outputs as hamt_ln_fwd with io16 = HAMT_LN_Z_BF16: z16 [M,H] bf16
- * (saved for hamt_ln_bwd, same dropout stream: call_id), y fp32, y16 [Mpad16,H] bf16 (rows >= M zero), mean, rstd.
- * H must be 768 (the R2R / RxR model width); K % 64 == 0; tile_rows: 0 = automatic, 32 or 64 = rows per workgroup. */
-typedef struct {
-  int M, K, H, lda;
-  float eps, p_pre;
-  uint32_t call_id;
-  int Mpad16;
-  int tile_rows;
-} hamt_gemm_ln_desc;
-int hamt_gemm_ln_fwd(const hamt_gemm_ln_desc* d, const void* a16, const void* w16, const float* bias,
-                     const float* residual, const float* gamma, const float* beta, void* z16, float* y, void* y16,
-                     float* mean, float* rstd, const uint64_t* rng, void* stream);
 /* pre-LN blocks (x + f(LN(x)), vision_transformer.py:196-197): dz = LayerNorm-backward(dy) + add, where `add` is the
  * gradient that reaches x through the residual path -- one pass instead of a LayerNorm backward and an add. */
 int hamt_ln_bwd_add(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean, const float* rstd,
@@ -334,7 +318,7 @@ int hamt_gather_rows(int R, int W, const float* src, int ld_src, const int64_t* 
 int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
                           float* dst, int ld_dst, void* stream);
 /* scatter_add in a FIXED summation order (colliding rows are added in row order by one writer per table row: bit-reproducible, unlike the
- * atomic form); idx must be given.  ws: 2 R ints of device scratch.  Beyond 32 768 source rows it falls back to the atomic kernel. */
+ * atomic form); idx must be given (table rows < 2^31).  ws: 34 R ints of device scratch.  Beyond 32 768 source rows it falls back to the atomic kernel. */
 int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
                                   float* dst, int ld_dst, int* ws, void* stream);
 /* the same for a CONTIGUOUS table dst[T][W] of T <= 8 rows (idx must be given): fixed-order sums instead of atomics -- the table's
@@ -474,26 +458,6 @@ int hamt_clip_scale(size_t n, float* g, const float* gnorm_sq, float max_norm, v
 /* rng[1] += 1 on the stream (new dropout epoch; call once per optimisation step) */
 int hamt_rng_advance(uint64_t* rng, void* stream);
 
-/* ------------------------------------------------------------------------------------------------
- * Running a captured step's parallel branches on separate streams (the reference has no counterpart: torch eager launches,
- * main_r2r.py:237-281; here a whole step is a captured hipGraph, graph.py).  Measured on MI355X / ROCm 7.0: ONE replayed graph runs
- * two independent chains of small kernels at 0.34x the rate of the same chains as two graphs on two streams (tools/
- * graph_branch_probe.py) -- so the captured graph (a hipGraph_t) is cut into its maximal linear chains, each chain becomes a graph of
- * its own on one of n_streams streams, and cross-chain dependencies become events.
- *   hamt_graph_split:          hip_graph = hipGraph_t (kernel / memcpy / memset / empty nodes); it must outlive the handle.
- *   hamt_graph_split_launch:   streams[0] = the caller's stream (the others wait for it first, it waits for them last: the call is
- *                              stream-ordered on streams[0] like hipGraphLaunch); the streams must be pairwise distinct.
- *   hamt_graph_split_info:     node / segment / cross-stream-dependency counts, nodes per stream.
- *   hamt_graph_split_segments: per segment {stream, nodes, dependency mask (bit k: depends on segment s - 1 - k)} into triples[3 * cap];
- *                              returns the number of segments. */
-typedef struct hamt_graph_exec hamt_graph_exec;
-int hamt_graph_split(void* hip_graph, int n_streams, hamt_graph_exec** out);
-int hamt_graph_split_launch(hamt_graph_exec* x, void* const* streams, int n_streams);
-int hamt_graph_split_info(const hamt_graph_exec* x, int* n_nodes, int* n_segments, int* n_cross, int* stream_nodes, int n_streams);
-int hamt_graph_split_segments(const hamt_graph_exec* x, int* triples, int cap);
-/* one token per node of segment `seg` (kernel name, M<bytes> memcpy, S memset, E empty), ';'-separated; returns the length written */
-int hamt_graph_split_describe(const hamt_graph_exec* x, int seg, char* buf, size_t n);
-int hamt_graph_split_destroy(hamt_graph_exec* x);
 
 #ifdef __cplusplus
 }

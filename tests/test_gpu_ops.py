@@ -420,68 +420,6 @@ def test_cross_attention_block_at_bench_rows_vs_fp64():
     _grad_report(named, [P[n].grad for n, _ in named], "BertXAttention both directions", 0.9995, 3e-2)
 
 
-@pytest.mark.parametrize("M,K,tile", [(5120, 768, 0), (2752, 768, 32), (11520, 768, 64), (333, 768, 32), (100, 3072, 64), (5120, 3072, 32), (33, 128, 0)])
-@pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_gemm_ln_fused_matches_the_two_launch_path_and_fp64(M, K, tile, p_drop):
-    """hamt_gemm_ln_fwd (csrc/gemm_ln.hip: dense + bias + dropout + residual + LayerNorm, vilmodel.py:139-143 / 181-185, in one
-    launch) against (1) fp64 torch on the same bf16 operands given the kernel's own dropout mask, (2) hamt_gemm (fp32 output) +
-    hamt_ln_fwd with the SAME call id -- identical mask stream, so hamt_ln_bwd serves both -- and (3) the backward kernel fed the
-    fused outputs.  Ragged last tiles, both tile heights, rows of the bf16 image behind M zeroed."""
-    import ctypes as C
-    from vln_hamt_amd import _lib as L
-    ops = _ops()
-    H = 768
-    g = torch.Generator(device=DEV).manual_seed(M * 3 + K)
-    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
-    w = (torch.randn(H, K, device=DEV, generator=g) * 0.03).to(torch.bfloat16)
-    b = torch.randn(H, device=DEV, generator=g) * 0.1
-    ga, be = 1 + 0.1 * torch.randn(H, device=DEV, generator=g), 0.1 * torch.randn(H, device=DEV, generator=g)
-    r = torch.randn(M, H, device=DEV, generator=g)
-    y, y16, z, mean, rstd, cid = ops.gemm_ln_fwd(a, w, b, r, ga, be, 1e-12, p_drop, tile_rows=tile)
-    want_kernel = f"gemm_ln_kernel<{tile}>" if tile else ("gemm_ln_kernel<32>" if M <= 32 * 256 else "gemm_ln_kernel<64>")
-    assert L.last_kernel() == want_kernel, L.last_kernel()
-    torch.cuda.synchronize()
-    assert y16.shape[0] % 64 == 0 and float(y16[M:].float().abs().max() if y16.shape[0] > M else 0.0) == 0.0
-    # (2) two launches, same call id
-    o = torch.empty(M, H, device=DEV)
-    ops.gemm(a, w, o, bias=b)
-    z2, y2 = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
-    y16_2 = torch.empty(y16.shape, dtype=torch.bfloat16, device=DEV)
-    mean2, rstd2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-    d = L.LnDesc(M, H, 1e-12, p_drop, 0.0, cid, y16.shape[0], 0)
-    L.check(L.load().hamt_ln_fwd(C.byref(d), ops._p(o), ops._p(r), ops._p(ga), ops._p(be), ops._p(z2), ops._p(y2), ops._p(y16_2), ops._p(mean2),
-                                 ops._p(rstd2), ops._p(ops.rng_state(torch.device(DEV))), ops._stream()), "hamt_ln_fwd")
-    tol = 2e-5 * math.sqrt(K)
-    close(y, y2, tol, "fused y vs gemm + ln_fwd")
-    close(mean, mean2, tol, "mean")
-    close(rstd, rstd2, tol, "rstd")
-    close(z.float(), z2, 2 ** -8, "saved pre-LN sum (bf16)")
-    close(y16[:M].float(), y2, 2 ** -8, "bf16 image of y")
-    if p_drop > 0:       # same mask: the dropped positions of the dense output coincide exactly
-        dropped = (z2 - r) == 0
-        frac = float(dropped.float().mean())
-        assert abs(frac - p_drop) < 0.01, frac
-        assert bool((((z.float() - r).abs() < 2 ** -6 * (1 + r.abs())) | ~dropped).all())
-    # (1) fp64 given the mask
-    lin = a.double() @ w.double().t() + b.double()
-    keep = ((z2 - r) != 0).double() / (1.0 - p_drop) if p_drop > 0 else 1.0
-    zr = lin * keep + r.double()
-    mu = zr.mean(-1, keepdim=True)
-    var = ((zr - mu) ** 2).mean(-1, keepdim=True)
-    yr = (zr - mu) / torch.sqrt(var + 1e-12) * ga.double() + be.double()
-    close(y, yr, tol, "fused y vs fp64")
-    # (3) backward from the fused forward's saved tensors == backward from the two-launch forward's
-    dy = torch.randn(M, H, device=DEV, generator=g)
-    dz1, _, dx16_1, dg1, db1, dxs1 = ops._ln_bwd(dy, z, mean, rstd, ga, 1e-12, p_drop, 0.0, cid, False, True, True)
-    dz2, _, dx16_2, dg2, db2, dxs2 = ops._ln_bwd(dy, z2, mean2, rstd2, ga, 1e-12, p_drop, 0.0, cid, False, True, True)
-    close(dz1, dz2, 2e-2, "dz")                   # (bf16 vs fp32 saved sum)
-    close(dg1, dg2, 2e-2, "dgamma")
-    close(db1, db2, 1e-5, "dbeta")
-    close(dxs1, dxs2, 2e-2, "bias gradient")
-    if p_drop > 0:
-        assert torch.equal(dx16_1[:M] == 0, dx16_2[:M] == 0) or float(((dx16_1[:M] == 0) != (dx16_2[:M] == 0)).float().mean()) < 1e-4
-
-
 def test_gemm_tr_read_matches_scalar_fallback():
     """ds_read_b64_tr_b16 fragment path == scalar LDS gather path (HAMT_NO_TR=1), bit for bit."""
     code = r"""
@@ -1093,6 +1031,61 @@ def test_embed_sum_and_gather_scatter_exact():
         (tr_[idx]).backward(go.double())
         close(grads[0], tr_.grad, 1e-5, f"small-table dtab T={T}")
         assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), "small-table scatter is not bit-reproducible"
+
+
+@pytest.mark.parametrize("R,T,W", [(5120, 30522, 768), (5120, 40, 768), (2368, 9, 768), (33000, 100, 64), (1, 5, 128), (1025, 1024, 132)])
+def test_scatter_add_ordered_is_bit_reproducible(R, T, W):
+    """dst[idx[r]] += src[r] with colliding rows summed in ROW order by one writer per table row (hamt_scatter_add_rows_ordered, the word
+    embeddings' gradient in hamt_embed_sum_bwd): equal to a sequential fp32 sum in row order -- hence bit-identical from run to run,
+    which the atomic scatter was not (tools/grad_bitwise_repeat.py) -- on top of what the table held.  33 000 rows: the atomic fallback
+    beyond 32 768 (correct, not ordered)."""
+    import ctypes as C
+    from vln_hamt_amd import _lib as L
+    from vln_hamt_amd.ops import _p, _stream
+    g = torch.Generator().manual_seed(R + T)
+    idx = torch.randint(0, T, (R,), generator=g)
+    if R > 100:
+        idx[: R // 4] = idx[0]                                   # one table row hit by a quarter of the source rows
+    src = rnd(R, W, seed=3)
+    base = rnd(T, W, seed=4)
+    outs = []
+    src_d, idx_d = src.to(DEV), idx.to(DEV)                      # (held: a temporary's block would be handed to the next allocation)
+    for rep in range(3):
+        junk = torch.randn(1000 * (rep + 1), device=DEV)
+        dst = base.to(DEV).clone()
+        ws = torch.empty(34 * R, dtype=torch.int32, device=DEV)
+        L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(src_d), W, 0, _p(idx_d), _p(dst), W, _p(ws), _stream()), "scatter")
+        torch.cuda.synchronize()
+        outs.append(dst.cpu())
+        del junk
+    ref = base.double().index_add(0, idx, src.double())
+    close(outs[0], ref, 2e-5, "ordered scatter")
+    if R <= 32768:
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "ordered scatter is not bit-reproducible"
+        # (the defined order: up to 8 source rows of a table row are summed in row order; more: members j = 0 .. 7 (mod 8) in row order,
+        # the eight sums added in that order; the total is added to the table row)
+        if R <= 6000 and T <= 100:
+            want = base.clone()
+            for t_ in range(T):
+                rows = (idx == t_).nonzero().flatten().tolist()
+                if not rows:
+                    continue
+                if len(rows) <= 8:
+                    tot = torch.zeros(W)
+                    for r_ in rows:
+                        tot = tot + src[r_]
+                else:
+                    parts = []
+                    for k in range(8):
+                        a_ = torch.zeros(W)
+                        for r_ in rows[k::8]:
+                            a_ = a_ + src[r_]
+                        parts.append(a_)
+                    tot = parts[0]
+                    for k in range(1, 8):
+                        tot = tot + parts[k]
+                want[t_] = base[t_] + tot
+            assert torch.equal(outs[0], want), "not the defined summation order"
 
 
 @pytest.mark.parametrize("B,L,H,V", [(64, 80, 768, 30522), (5, 33, 1024, 100), (2, 7, 132, 50), (3, 9, 1028, 40)])

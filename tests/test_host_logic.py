@@ -70,33 +70,6 @@ def test_wgrad_queue_bookkeeping_cpu():
         W._flush_pass = orig
 
 
-def test_interleaved_issue_of_chains(monkeypatch):
-    """streams.interleave: the chains' units are issued alternately, the chain with the least accumulated cost first, every
-    unit under its own chain's stream, results in chain order; HAMT_INTERLEAVE=0 issues one chain after the other."""
-    import contextlib
-    from vln_hamt_amd import streams
-    entered = []
-    monkeypatch.setattr(torch.cuda, "stream", lambda st: (entered.append(st), contextlib.nullcontext())[1])
-    order = []
-
-    def chain(name, costs):
-        for c in costs:
-            order.append(name)
-            yield c
-        return name.upper()
-
-    monkeypatch.setattr(streams, "INTERLEAVE", True)
-    res = streams.interleave([("s1", chain("v", [10, 10, 10])), ("s0", chain("t", [5, 5, 5, 5, 5, 5]))])
-    assert res == ["V", "T"]
-    assert "".join(order) == "vttvttvtt", order           # v (tie, first), then t until it has caught up, ...
-    assert set(entered) == {"s0", "s1"}
-    order.clear()
-    monkeypatch.setattr(streams, "INTERLEAVE", False)
-    assert streams.interleave([("s1", chain("v", [1, 1])), ("s0", chain("t", [1, 1, 1]))]) == ["V", "T"]
-    assert "".join(order) == "vvttt"
-    assert streams.drive(chain("x", [])) == "X"
-
-
 def test_range_finality_and_static_cuts():
     """parallel.range_finality maps a step's plan (rank-local) onto the STATIC ranges: a static range is final after the last
     launch group that writes into any plan range overlapping it; the static ranges themselves depend on the layout only."""

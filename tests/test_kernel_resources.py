@@ -11,9 +11,9 @@ import pytest
 
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
-HOT = ("gemm_p8_kernel", "wgrad_grouped_p8_kernel", "wgrad_grouped_kernel", "gemm_fast_kernel", "gemm_fast256_kernel", "gemm_kg_kernel",
+HOT = ("gemm_p8_kernel", "gemm_q4_kernel", "wgrad_grouped_p8_kernel", "wgrad_grouped_kernel", "gemm_fast_kernel", "gemm_fast256_kernel", "gemm_kg_kernel",
        "attn_s128_fwd_kernel", "attn_s128_bwd_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "adamw_table_kernel", "sumsq_table_partial_kernel",
-       "gemm_ln_kernel", "unpack_sumsq_partial_kernel", "attn_wide_bwd_kernel", "vis_embed_fwd_kernel", "vis_embed_bwd_kernel",
+       "unpack_sumsq_partial_kernel", "attn_wide_bwd_kernel", "vis_embed_fwd_kernel", "vis_embed_bwd_kernel",
        "sumsq_table_balanced_kernel")
 
 

@@ -52,10 +52,6 @@ class VisEmbedDesc(C.Structure):
     _fields_ = [("M", i32), ("H", i32), ("A", i32), ("ld_ang", i32), ("eps1", f32), ("eps2", f32), ("x_bf16", i32), ("Mpad16", i32)]
 
 
-class GemmLnDesc(C.Structure):
-    _fields_ = [("M", i32), ("K", i32), ("H", i32), ("lda", i32), ("eps", f32), ("p_pre", f32), ("call_id", u32), ("Mpad16", i32), ("tile_rows", i32)]
-
-
 # name -> argtypes (every entry point of include/hamt.h; tests/test_abi.py cross-checks against the header)
 WGRAD_TABLE_ENTRY = 112     # HAMT_WGRAD_TABLE_ENTRY
 
@@ -89,7 +85,6 @@ SIGNATURES = {
     "hamt_vis_embed_fwd": [C.POINTER(VisEmbedDesc)] + [vp] * 12,
     "hamt_vis_embed_bwd": [C.POINTER(VisEmbedDesc)] + [vp] * 18,
     "hamt_ln_fwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "hamt_gemm_ln_fwd": [C.POINTER(GemmLnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd_add": [C.POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "hamt_ln_bwd_reduce": [i32, i32, vp, vp, vp, vp, vp],
@@ -136,12 +131,6 @@ SIGNATURES = {
     "hamt_adamw_table_range": [sz, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp],
     "hamt_clip_scale": [sz, vp, vp, f32, vp],
     "hamt_rng_advance": [vp, vp],
-    "hamt_graph_split": [vp, i32, C.POINTER(vp)],
-    "hamt_graph_split_launch": [vp, C.POINTER(vp), i32],
-    "hamt_graph_split_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32],
-    "hamt_graph_split_segments": [vp, vp, i32],
-    "hamt_graph_split_describe": [vp, i32, C.c_char_p, sz],
-    "hamt_graph_split_destroy": [vp],
 }
 
 _lib = None

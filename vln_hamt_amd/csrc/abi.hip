@@ -63,7 +63,7 @@ extern "C" size_t hamt_workspace_bytes(int op, const int* shape, int nshape) {
     case HAMT_WS_VIS_EMBED_BWD: return nshape >= 2 && shape ? hamt_vis_embed_ws_bytes(shape[0], shape[1]) : 0;
     case HAMT_WS_EMBED_BWD: {
       if (nshape < 2 || !shape) return 0;
-      const size_t a = (size_t)64 * shape[1] * 4, b = (size_t)8 * shape[0];
+      const size_t a = (size_t)64 * shape[1] * 4, b = (size_t)136 * shape[0];
       return a > b ? a : b;
     }
     default: return 0;

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libhamt_hip.so")
-SOURCES = ["abi.hip", "graph_split.hip", "gemm.hip", "gemm_fast.hip", "gemm_q4.hip", "gemm_ln.hip", "attn.hip", "attn16.hip", "norm.hip", "vis_embed.hip", "elementwise.hip", "loss.hip", "optim.hip"]
+SOURCES = ["abi.hip", "gemm.hip", "gemm_fast.hip", "gemm_q4.hip", "attn.hip", "attn16.hip", "norm.hip", "vis_embed.hip", "elementwise.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("HAMT_EXTRA_FLAGS", "").split()
 
 

@@ -293,48 +293,157 @@ extern "C" int hamt_scatter_add_rows_small(int R, int W, const float* src, int l
   return HAMT_OK;
 }
 // ---- dst[idx[r]] += src[r] in a FIXED order for any table (the word embeddings: 30 522 rows, a few thousand source rows with repeated
-// tokens).  The atomic scatter adds colliding rows in whatever order the hardware serves them: the table's gradient then differs in the
-// last bit from run to run (tools/grad_bitwise_repeat.py: up to 30 distinct values in 30 repetitions), which is enough to flip a rounded
-// two-rank average.  Here: (1) every source row finds the next row with the same index and whether it is the first
-// such row (R x R comparisons through LDS tiles: 26 M for the step's 5120 rows, a few us); (2) one block per FIRST row walks its chain in
-// row order, sums in registers and adds the sum to the table row -- one writer per table row, no atomics.
-__global__ __launch_bounds__(256) void scatter_chain_kernel(int R, const int64_t* __restrict__ idx, int* __restrict__ next, int* __restrict__ head) {
-  __shared__ int64_t tile[1024];
+// tokens -- [MASK] alone is 15 % of an MLM batch).  The atomic scatter adds colliding rows in whatever order the hardware serves them: the
+// table's gradient then differs in the last bit from run to run (tools/grad_bitwise_repeat.py: up to 30 distinct values in 30 repetitions),
+// which is enough to flip a rounded two-rank average.  Here the source rows are ranked by (index, row) -- a counting
+// sort by comparison: R x R integer comparisons through LDS tiles, 26 M for the step's 5120 rows, spread over up to 32 slices of the row range --
+// and every table row that is hit is summed over its (now contiguous) list of source rows by one wave (up to 8 rows, in row order) or
+// by the eight waves of a block (wave k: the members j = k (mod 8) in order; the partial sums added in wave order).  One writer per
+// table row, no atomics, the same association for the same indices: bit-reproducible.  (A first version walked a linked list of equal
+// rows per table row: the 770-row chain of [MASK] cost 0.4 ms of dependent loads.)
+constexpr int SCAT_SLICES = 32;
+__global__ __launch_bounds__(256) void scatter_rank_kernel(int R, int per, const int64_t* __restrict__ idx, int* __restrict__ cnt) {
+  __shared__ int tile[256];                          // (table rows < 2^31: 32-bit compares -- 64-bit integer compares run at a quarter of the rate)
   const int r = blockIdx.x * 256 + threadIdx.x;
-  const int64_t mine = r < R ? idx[r] : -1;
-  int nx = 0x7fffffff, first = r;
-  for (int t0 = 0; t0 < R; t0 += 1024) {
-    for (int i = threadIdx.x; i < 1024; i += 256) tile[i] = t0 + i < R ? idx[t0 + i] : -2;
+  const int mine = r < R ? (int)idx[r] : -1;
+  const int q0 = blockIdx.y * per, q1 = min(R, q0 + per);
+  int below = 0;                                     // rows q of this slice with (idx[q], q) < (mine, r)
+  for (int t0 = q0; t0 < q1; t0 += 256) {
+    const int nv = min(256, q1 - t0);
+    if ((int)threadIdx.x < nv) tile[threadIdx.x] = (int)idx[t0 + threadIdx.x];
     __syncthreads();
     if (r < R) {
 #pragma unroll 8
-      for (int i = 0; i < 1024; ++i) {
-        const int q = t0 + i;
-        if (tile[i] == mine) { if (q < first) first = q; if (q > r && q < nx) nx = q; }
-      }
+      for (int i = 0; i < nv; ++i) below += (tile[i] < mine) + ((tile[i] == mine) & (t0 + i < r));
     }
     __syncthreads();
   }
-  if (r < R) { next[r] = nx == 0x7fffffff ? -1 : nx; head[r] = first == r; }
+  if (r < R) cnt[blockIdx.y * R + r] = below;
 }
-__global__ __launch_bounds__(256) void scatter_chain_add_kernel(int R, int W, const float* __restrict__ src, int ld_src, int col0,
-                                                                const int64_t* __restrict__ idx, const int* __restrict__ next,
-                                                                const int* __restrict__ head, float* __restrict__ dst, int ld_dst) {
-  for (int r = blockIdx.x; r < R; r += gridDim.x) {
-    if (!head[r]) continue;                                   // (block uniform)
-    float* drow = dst + (size_t)(idx ? idx[r] : r) * ld_dst;
-    for (int c = threadIdx.x; c < W; c += 256) {
-      float acc = 0.f;
-      for (int q = r; q >= 0; q = next[q]) acc += src[(size_t)q * ld_src + col0 + c];
-      drow[c] += acc;
+__global__ __launch_bounds__(256) void scatter_perm_kernel(int R, int ns, const int64_t* __restrict__ idx, const int* __restrict__ cnt, int* __restrict__ perm,
+                                                           int* __restrict__ sid) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  int pos = 0;
+  for (int y = 0; y < ns; ++y) pos += cnt[y * R + r];
+  perm[pos] = r;                                    // (a permutation: (idx, row) pairs are distinct)
+  sid[pos] = (int)idx[r];
+}
+constexpr int SCAT_WAVES = 8, SCAT_UNROLL = 8;       // (512-thread blocks: 256 registers per lane for the 8 x 12 values in flight; 16 waves spilled)
+// one wave's sum of the members first, first + stride, ... < e of a table row's source rows, 768 columns from `cb` on (3 float4 per lane):
+// the loads of SCAT_UNROLL members are requested together, the adds stay in member order
+__device__ __forceinline__ void scatter_members_sum(const float* __restrict__ src, int ld_src, int col0, int W, int cb, int ln, bool v4,
+                                                    const int* __restrict__ perm, int first, int stride, int e, float* a) {
+#pragma unroll
+  for (int k = 0; k < 12; ++k) a[k] = 0.f;
+  for (int j0 = first; j0 < e; j0 += stride * SCAT_UNROLL) {
+    int rows[SCAT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SCAT_UNROLL; ++u) { const int j = j0 + u * stride; rows[u] = j < e ? perm[j] : -1; }
+    float v[SCAT_UNROLL][12];
+#pragma unroll
+    for (int u = 0; u < SCAT_UNROLL; ++u) {
+      if (rows[u] < 0) continue;                    // (wave uniform)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = cb + 256 * q + 4 * ln;
+        const float* sp = src + (size_t)rows[u] * ld_src + col0 + c;
+        if (v4 && c + 4 <= W) { const float4 f = *(const float4*)sp; v[u][4 * q] = f.x; v[u][4 * q + 1] = f.y; v[u][4 * q + 2] = f.z; v[u][4 * q + 3] = f.w; }
+        else for (int k = 0; k < 4; ++k) v[u][4 * q + k] = c + k < W ? sp[k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SCAT_UNROLL; ++u)
+      if (rows[u] >= 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a[k] += v[u][k];
+      }
+  }
+}
+__device__ __forceinline__ void scatter_row_add(float* __restrict__ drow, int W, int cb, int ln, bool v4, const float* a) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int c = cb + 256 * q + 4 * ln;
+    if (v4 && c + 4 <= W) {
+      float4 d = *(float4*)(drow + c);
+      d.x += a[4 * q]; d.y += a[4 * q + 1]; d.z += a[4 * q + 2]; d.w += a[4 * q + 3];
+      *(float4*)(drow + c) = d;
+    } else for (int k = 0; k < 4; ++k) { if (c + k < W) drow[c + k] += a[4 * q + k]; }
+  }
+}
+__global__ __launch_bounds__(64 * SCAT_WAVES) void scatter_segment_add_kernel(int R, int W, const float* __restrict__ src, int ld_src, int col0,
+                                                                             const int* __restrict__ perm, const int* __restrict__ sid,
+                                                                             float* __restrict__ dst, int ld_dst) {
+  // A block looks at SCAT_WAVES consecutive sorted positions, one per wave.  A position that starts a table row's list [p, e) of source rows:
+  //   n = e - p <= SCAT_WAVES members (nearly all: most tokens occur once or a few times): THAT wave sums them in row order and adds the
+  //     sum to the table row -- no LDS, no barrier;
+  //   longer lists ([MASK]: 15 % of an MLM batch, a position table row: every sample): afterwards, the whole block: wave k sums the
+  //     members j = k (mod SCAT_WAVES) in order, the partial sums are added in wave order, then to the table row.
+  // Either way ONE writer per table row and an order of additions that depends on the indices only.
+  __shared__ float part[SCAT_WAVES - 1][768];
+  __shared__ int longs[SCAT_WAVES];
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const bool v4 = ((ld_src | col0 | W | ld_dst) & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  const int p = blockIdx.x * SCAT_WAVES + wv;
+  int e = p, id = -1;
+  bool start = false;
+  if (p < R) {
+    id = sid[p];
+    start = p == 0 || sid[p - 1] != id;
+    if (start) {      // end of the list: sid is sorted, so a binary search (a linear scan of a 750-row list is 750 dependent L2 round trips)
+      int lo = p + 1, hi = R;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (sid[mid] == id) lo = mid + 1; else hi = mid; }
+      e = lo;
+    }
+  }
+  const int n = e - p;
+  if (ln == 0) longs[wv] = (start && n > SCAT_WAVES) ? e : 0;
+  if (start && n <= SCAT_WAVES) {
+    float a[12];
+    for (int cb = 0; cb < W; cb += 768) {
+      scatter_members_sum(src, ld_src, col0, W, cb, ln, v4, perm, p, 1, e, a);
+      scatter_row_add(dst + (size_t)id * ld_dst, W, cb, ln, v4, a);
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < SCAT_WAVES; ++k) {
+    const int e2 = longs[k];
+    if (!e2) continue;                              // (block uniform)
+    const int p2 = blockIdx.x * SCAT_WAVES + k;
+    float* drow = dst + (size_t)sid[p2] * ld_dst;
+    for (int cb = 0; cb < W; cb += 768) {
+      float a[12];
+      scatter_members_sum(src, ld_src, col0, W, cb, ln, v4, perm, p2 + wv, SCAT_WAVES, e2, a);
+      __syncthreads();
+      if (wv) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *(float4*)&part[wv - 1][256 * q + 4 * ln] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+      }
+      __syncthreads();
+      if (wv == 0) {
+        for (int k2 = 0; k2 < SCAT_WAVES - 1; ++k2)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const float4 f = *(const float4*)&part[k2][256 * q + 4 * ln];
+            a[4 * q] += f.x; a[4 * q + 1] += f.y; a[4 * q + 2] += f.z; a[4 * q + 3] += f.w;
+          }
+        scatter_row_add(drow, W, cb, ln, v4, a);
+      }
     }
   }
 }
-// ws: 2 R ints.  false: R too large for the quadratic chain search (the caller falls back to atomics)
+// ws: (SCAT_SLICES + 2) R ints.  false: no index / no scratch / R too large for the quadratic ranking (the caller falls back to atomics)
 static bool scatter_add_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst, int ld_dst, int* ws, hipStream_t s) {
-  if (R > 32768 || !idx || !ws) return false;
-  hipLaunchKernelGGL(scatter_chain_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, idx, ws, ws + R);
-  hipLaunchKernelGGL(scatter_chain_add_kernel, dim3(R < 4096 ? R : 4096), dim3(256), 0, s, R, W, src, ld_src, col0, idx, ws, ws + R, dst, ld_dst);
+  static const bool off = getenv("HAMT_ATOMIC_SCATTER") != nullptr;      // (measurement: the atomic kernels instead)
+  if (R > 32768 || !idx || !ws || off) return false;
+  const int ns = (R + 255) / 256 < SCAT_SLICES ? (R + 255) / 256 : SCAT_SLICES;      // slices of the row range (grid.y): 256 rows each up to 8192 rows
+  const int per = ((R + ns - 1) / ns + 255) / 256 * 256;
+  int* cnt = ws;
+  int* perm = ws + (size_t)SCAT_SLICES * R;
+  int* sid = perm + R;
+  hipLaunchKernelGGL(scatter_rank_kernel, dim3((R + 255) / 256, ns), dim3(256), 0, s, R, per, idx, cnt);
+  hipLaunchKernelGGL(scatter_perm_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, ns, idx, cnt, perm, sid);
+  hipLaunchKernelGGL(scatter_segment_add_kernel, dim3((R + SCAT_WAVES - 1) / SCAT_WAVES), dim3(64 * SCAT_WAVES), 0, s, R, W, src, ld_src, col0, perm, sid, dst, ld_dst);
   return true;
 }
 extern "C" int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst,

@@ -252,19 +252,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
       if constexpr (FASTK) {
         float b8[8];
         epi_fast_bias<EPI>(g, col, b8);
-        auto run = [&](auto c16) {
-#pragma unroll
-          for (int p = 0; p < BM / RPP; ++p) {
-            const int rl = p * RPP + (t >> 4);
-            const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));
-            const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));
-            const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const uint4* pp = nullptr;
-            if constexpr (PRE_AUX) pp = &pa[p];
-            epi_fast8<EPI, decltype(c16)::value>(g, m0 + rl, col, v8, b8, pp);
-          }
-        };
-        if (g.dtype_c == HAMT_BF16) run(std::true_type{}); else run(std::false_type{});
+        // (no lambda here: one that captures `pa` by reference puts the array into scratch memory -- tests/test_kernel_resources.py)
+#define HAMT_FAST_PIECES(C16_)                                                                                   \
+        _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                                   \
+          const int rl = p * RPP + (t >> 4);                                                                      \
+          const f32x4 lo = *(const f32x4*)(ct + rl * BN + (((2 * c8) ^ (rl & 7)) << 2));                          \
+          const f32x4 hi = *(const f32x4*)(ct + rl * BN + (((2 * c8 + 1) ^ (rl & 7)) << 2));                      \
+          const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                           \
+          if constexpr (PRE_AUX) epi_fast8<EPI, C16_>(g, m0 + rl, col, v8, b8, &pa[p]);                           \
+          else epi_fast8<EPI, C16_>(g, m0 + rl, col, v8, b8, nullptr);                                            \
+        }
+        if (g.dtype_c == HAMT_BF16) { HAMT_FAST_PIECES(true) } else { HAMT_FAST_PIECES(false) }
+#undef HAMT_FAST_PIECES
       }
     } else {
 #pragma unroll

@@ -1,4 +1,4 @@
-// Operand staging and MFMA fragment helpers shared by the bf16 GEMM kernels (gemm_fast.hip, gemm_ln.hip): LDS-DMA pieces
+// Operand staging and MFMA fragment helpers shared by the bf16 GEMM kernels (gemm_fast.hip, gemm_q4.hip): LDS-DMA pieces
 // (global_load_lds_dwordx4 through inline asm), per-tile source offsets, swizzled fragment reads, counted waits.
 // Include inside an anonymous namespace after common.h.
 #pragma once

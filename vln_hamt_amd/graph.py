@@ -17,109 +17,14 @@ import torch
 from . import ops, streams
 
 
-# HAMT_GRAPH_SPLIT=1: replay a captured step chain by chain on separate streams (SplitGraph / csrc/graph_split.hip) instead of as ONE
-# hipGraph (torch's CUDAGraph.replay).  Built and measured in round 4: correct, halves the host time of a replay (0.6 vs
-# 1.3 ms), but the step is no faster -- two long chains that become ready at the same fork still run one after the other on this
-# runtime, separate graphs / streams / hardware queues or not -- so it stays an option.
-SPLIT = os.environ.get("HAMT_GRAPH_SPLIT", "0") == "1"
-SPLIT_STREAMS = int(os.environ.get("HAMT_GRAPH_SPLIT_STREAMS", 2))
-
-
-_skipped: list = []
-
-
-class SplitGraph:
-    """A captured torch.cuda.CUDAGraph(keep_graph=True) replayed chain by chain: `hamt_graph_split` (csrc/graph_split.hip) cuts the
-    captured hipGraph into its maximal linear chains, instantiates each as a graph of its own and launches them on separate streams
-    with events for the dependencies that cross -- inside one replayed graph this runtime runs parallel branches one after the
-    other (and slower than a single chain), see tools/graph_branch_probe.py.  `replay()` is stream-ordered on torch's current stream
-    like CUDAGraph.replay().  The torch graph object stays alive (it owns the captured graph and the memory pool)."""
-
-    def __init__(self, torch_graph, n_streams: int = None):
-        import ctypes as C
-        from . import _lib as L
-        self.g = torch_graph
-        self.n = int(n_streams or SPLIT_STREAMS)
-        h = C.c_void_p()
-        L.check(L.load().hamt_graph_split(C.c_void_p(torch_graph.raw_cuda_graph()), self.n, C.byref(h)), "hamt_graph_split")
-        self.h = h
-        dev = torch.cuda.current_device()
-        global _skipped
-        if not _skipped:      # (experiment: HAMT_BRANCH_SKIP=k takes k HIP streams out of torch's pool first, i.e. another hardware queue for the branch)
-            _skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("HAMT_BRANCH_SKIP", 0)))] or [None]
-        # (measurement switches: HAMT_BRANCH_PRIORITY = 0 / -1 for the branch streams, HAMT_SPLIT_MAIN_HI=1 replays the main chain on a
-        # high-priority stream of its own -- does the critical chain get the CUs first when both chains have work?)
-        bp = os.environ.get("HAMT_BRANCH_PRIORITY")
-        self.branch = [streams.role_stream(dev, f"gbranch{i}", bp) for i in range(1, self.n)]
-        self.main_hi = streams.role_stream(dev, "gmain_hi", -1) if os.environ.get("HAMT_SPLIT_MAIN_HI") == "1" else None
-        self._arr = (C.c_void_p * self.n)()
-
-    def info(self):
-        import ctypes as C
-        from . import _lib as L
-        a, b, c = C.c_int(), C.c_int(), C.c_int()
-        per = (C.c_int * self.n)()
-        L.check(L.load().hamt_graph_split_info(self.h, C.byref(a), C.byref(b), C.byref(c), per, self.n), "hamt_graph_split_info")
-        return {"nodes": a.value, "segments": b.value, "cross_stream_deps": c.value, "nodes_per_stream": list(per)}
-
-    def segments(self):
-        import ctypes as C
-        from . import _lib as L
-        n = L.load().hamt_graph_split_segments(self.h, None, 0)
-        buf = (C.c_int * (3 * n))()
-        L.load().hamt_graph_split_segments(self.h, buf, n)
-        return [(buf[3 * i], buf[3 * i + 1], [i - 1 - k for k in range(30) if buf[3 * i + 2] >> k & 1]) for i in range(n)]
-
-    def describe(self, seg: int) -> list:
-        """the nodes of segment `seg`: kernel names, M<bytes> memcpy, S memset, E empty"""
-        import ctypes as C
-        from . import _lib as L
-        buf = C.create_string_buffer(1 << 16)
-        L.load().hamt_graph_split_describe(self.h, seg, buf, 1 << 16)
-        return [t for t in buf.value.decode(errors="replace").split(";") if t]
-
-    def replay(self):
-        from . import _lib as L
-        cur = outer = torch.cuda.current_stream()
-        if self.main_hi is not None:
-            self.main_hi.wait_stream(outer)
-            cur = self.main_hi
-        self._arr[0] = cur.cuda_stream
-        for i, st in enumerate(self.branch):
-            if st.cuda_stream == cur.cuda_stream:
-                raise L.HamtError("SplitGraph.replay: the current stream is one of the split's branch streams")
-            self._arr[i + 1] = st.cuda_stream
-        L.check(L.load().hamt_graph_split_launch(self.h, self._arr, self.n), "hamt_graph_split_launch")
-        if self.main_hi is not None:
-            outer.wait_stream(self.main_hi)
-
-    def __del__(self):
-        try:
-            from . import _lib as L
-            if getattr(self, "h", None):
-                L.load().hamt_graph_split_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
-
-
 def _new_graph():
-    return torch.cuda.CUDAGraph(keep_graph=True) if SPLIT else torch.cuda.CUDAGraph()
+    return torch.cuda.CUDAGraph()
 
 
 def _finish_graph(g):
-    """what to replay for a captured graph: the chain-by-chain split, or the graph itself"""
-    if not SPLIT:
-        return g
-    sg = SplitGraph(g)
-    if os.environ.get("HAMT_GRAPH_SPLIT_VERBOSE"):
-        import sys
-        print(f"[graph split] {sg.info()} segments (stream, nodes, deps): {sg.segments()}", file=sys.stderr, flush=True)
-        if os.environ.get("HAMT_GRAPH_SPLIT_VERBOSE") == "2":
-            short = lambda t: t.split("<")[0].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-28:]
-            for i, (st, n, deps) in enumerate(sg.segments()):
-                print(f"    seg {i} stream {st} deps {deps}: " + " ".join(short(t) for t in sg.describe(i)), file=sys.stderr, flush=True)
-    return sg
+    """what to replay for a captured graph (round 4 also cut the captured graph into its linear chains and replayed those on separate
+    streams: tools/experiments/graph_split.hip, DESIGN_HISTORY.md -- correct, and no faster)"""
+    return g
 
 
 class GraphedTrainStep:
@@ -340,6 +245,7 @@ class GraphedTrainStep:
             g.replay()
             return loss_c
         self.opt.prepare_step(active)
+        self.opt._table_ready = False          # (consumed by the captured update below: a later eager zero_grad() must not take the step count back)
         g.replay()
         if self.grad_sync is not None:
             sharded = getattr(self.grad_sync, "sharded", False)

@@ -141,7 +141,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                                      hist_pano_ang_fts, hist_masks, None, None, None, None)
         if label_idx is None:
             label_idx = (txt_labels != -1).reshape(-1).nonzero(as_tuple=False).squeeze(1)
-        masked_output = ops.gather_rows(txt_embeds.reshape(-1, txt_embeds.size(-1)), label_idx)
+        masked_output = ops.gather_rows(txt_embeds.reshape(-1, txt_embeds.size(-1)), label_idx, unique=True)
         prediction_scores = self.mlm_head(masked_output)
         if compute_loss:
             return ops.cross_entropy(prediction_scores, txt_labels.reshape(-1).index_select(0, label_idx))
@@ -151,7 +151,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
         """rows of `hidden` where `mask` is set, in row-major order (pretrain_cmt.py:161-165): the index list
         is integer work done once, the row gather (and its scatter in backward) is a HIP kernel."""
         idx = mask.reshape(-1).nonzero(as_tuple=False).squeeze(1)
-        return ops.gather_rows(hidden.reshape(-1, hidden.size(-1)), idx)
+        return ops.gather_rows(hidden.reshape(-1, hidden.size(-1)), idx, unique=True)
 
     # ---- A16
     def forward_sap(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
@@ -174,7 +174,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                                                        ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
         B, L, H = txt_embeds.shape
         cls_rows = ops.const_index("arange_mul", int(B), int(L), device=txt_embeds.device)
-        prediction_scores = self.regress_action(ops.gather_rows(txt_embeds.reshape(B * L, H), cls_rows))
+        prediction_scores = self.regress_action(ops.gather_rows(txt_embeds.reshape(B * L, H), cls_rows, unique=True))
         if compute_loss:
             act_targets = torch.cat([ob_act_angles, ob_progress.unsqueeze(1)], dim=1)
             return ops.mse_loss(prediction_scores, act_targets)
@@ -193,8 +193,8 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
         # is a sum over the 36 copies and one add per anchor row -- a gather of 36 repeated indices would scatter-add 36 atomics into
         # the same row in whatever order they land, and the bf16 images downstream re-round that noise into every weight gradient
         # (run-to-run differences of up to 5e-3 of a gradient's largest element at small batches: tools/determinism_check.py)
-        anchor = ops.gather_rows(flat, base + sp_anchor_idxs)
-        rest = ops.gather_rows(flat, ops.const_index("rows_but_last", int(B), int(S), device=flat.device))
+        anchor = ops.gather_rows(flat, base + sp_anchor_idxs, unique=True)
+        rest = ops.gather_rows(flat, ops.const_index("rows_but_last", int(B), int(S), device=flat.device), unique=True)
         cat_ob_embeds = torch.cat([anchor[:, None].expand(B, S - 1, H), rest.view(B, S - 1, H)], -1)
         prediction_scores = self.sprel_head(cat_ob_embeds)
         if compute_loss:
@@ -212,7 +212,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
         if mrc_idx is None:
             mrc_idx = hist_mrc_masks.reshape(-1).nonzero(as_tuple=False).squeeze(1)
         rows = torch.div(mrc_idx, T, rounding_mode='floor') * T1 + mrc_idx % T + 1   # +1: drop the global cls slot (:232)
-        masked_output = ops.gather_rows(hist_embeds.reshape(B * T1, H), rows)
+        masked_output = ops.gather_rows(hist_embeds.reshape(B * T1, H), rows, unique=True)
         prediction_soft_labels = self.image_classifier(masked_output)
         hist_mrc_targets = hist_img_probs.reshape(B * T, -1).index_select(0, mrc_idx)
         if compute_loss:

@@ -172,19 +172,11 @@ class BertLayer(nn.Module):
         self.output = BertOutput(config)
 
     def forward(self, hidden_states, attention_mask, head_mask=None):
-        return streams.drive(self.forward_units(hidden_states, attention_mask, head_mask))
-
-    def forward_units(self, hidden_states, attention_mask, head_mask=None):
-        """the layer as a chain of two units (attention sub-block, feed-forward sub-block) for streams.interleave: yields each
-        unit's cost (rows x relative GEMM width), returns forward()'s result"""
-        rows = hidden_states.numel() // hidden_states.shape[-1]
         att = self.attention(hidden_states, attention_mask, head_mask)
-        yield rows
         if blocks.usable(self.output.prec, att[0]) and self.intermediate.act == ops.ACT_GELU:
             out = blocks.ffn_block(att[0], self.intermediate, self.output, self.training)
         else:
             out = self.output(self.intermediate(att[0]), att[0])
-        yield 2 * rows
         return (out,) + att[1:]
 
 
@@ -546,10 +538,6 @@ class HistoryEmbeddings(nn.Module):
         return ops.layer_norm(e, None, self.layer_norm, p_post=_p(self.dropout, self))
 
     def forward(self, img_feats, ang_feats, pano_img_feats, pano_ang_feats, pos_ids=None, batch_size=None):
-        return streams.drive(self.forward_units(img_feats, ang_feats, pano_img_feats, pano_ang_feats, pos_ids, batch_size))
-
-    def forward_units(self, img_feats, ang_feats, pano_img_feats, pano_ang_feats, pos_ids=None, batch_size=None):
-        """forward() as a chain of units for streams.interleave (yields each unit's cost, returns forward()'s result)"""
         dev = self.device
         H = self.cls_token.shape[-1]
         zeros_b = ops.const_index("zeros", int(batch_size), device=dev)
@@ -562,28 +550,19 @@ class HistoryEmbeddings(nn.Module):
         e = _VisualLinears.two_stream(self.img_linear, self.img_layer_norm, self.ang_linear, self.ang_layer_norm,
                                       img_feats, ang_feats, self.prec)
         e = ops.gather_rows(self.type_embedding.weight, ops.const_index("zeros", int(B * T), device=dev), base=e)
-        yield B * T
         if self.pano_encoder is not None:
             V = pano_img_feats.shape[2]
             pe = _VisualLinears.two_stream(self.pano_img_linear, self.pano_img_layer_norm, self.pano_ang_linear,
                                            self.pano_ang_layer_norm, pano_img_feats.reshape(B * T, V, -1),
                                            pano_ang_feats.reshape(B * T, V, -1), self.prec, want16=self.prec == "bf16")
-            yield B * T * V // 2
             # all 36 views exist: the reference's mask is all-zero (:560) == no mask
             if pe.shape != (B * T, V, H):
                 pe = pe.view(B * T, V, H)
-            enc = self.pano_encoder
-            if enc.output_hidden_states or enc.output_attentions:
-                pe = enc(pe, None)[0]
-            else:
-                for layer in enc.layer:
-                    streams.gate(layer)
-                    pe = (yield from layer.forward_units(pe, None))[0]
+            pe = self.pano_encoder(pe, None)[0]
             e = ops.add3(e.view(B * T, H), ops.mean_mid(pe))
         e = e.view(B, T, H)
         if pos_ids is not None:
             e = self.add_position(e, pos_ids)
-        yield B * T
         return cls, e
 
 
@@ -599,16 +578,6 @@ class NavPreTrainedModel(BertPreTrainedModel):
         self.encoder = LxmertEncoder(config)
         self.init_weights()
 
-    @staticmethod
-    def _early(x):
-        """behind the text embedder: in BACKWARD this point is reached when the text layers (and everything behind them on this
-        stream) are done and only the embedder's own backward is left -- the weight gradients queued on this stream are launched
-        here, next to the panorama encoder's backward on the second stream (wgrad.flush_current_stream)"""
-        from .. import wgrad
-        if x.is_cuda and streams.two_stream_enabled("trunk"):
-            return wgrad.early_flush_point(x)
-        return x
-
     def _text(self, txt_ids, txt_m, keep_packed=False):
         """Text embedder + the text-only layers (vilmodel.py:601, 441-443).  With a packing plan on `txt_ids` (`_hamt_pack` = (pack_idx
         [M], cu_seqlens int32 [n + 1], unpack_idx [B L]), put there by MultiStepNavCMTPreTraining.forward from the batch's `txt_pack_idx`
@@ -616,30 +585,22 @@ class NavPreTrainedModel(BertPreTrainedModel):
         sequence (hamt_attn_varlen_*), everything else row-wise -- and the result is scattered back into the padded [B, L, H] layout
         for the cross-modal layers.  Padded positions get their sequence's first row: any finite value serves, they are masked as
         keys and nothing reads what they produce as queries (the reference computes them and throws them away)."""
-        return streams.drive(self._text_units(txt_ids, txt_m, keep_packed))
-
-    def _text_units(self, txt_ids, txt_m, keep_packed=False):
-        """_text as a chain of units for streams.interleave (yields each unit's cost, returns _text's result)"""
         pack = getattr(txt_ids, "_hamt_pack", None)
         H = self.config.hidden_size      # (no parameter is touched here: optim.AdamW.attach's read gates sit in the child modules)
         # (the packed attention kernels hold one sequence per workgroup: instructions of up to 128 tokens -- R2R's 80; RxR pretraining
         # pads to 250, config/pretrain_rxr.json: such batches take the padded kernels, which serve up to 256 keys)
         if pack is None or txt_ids.shape[1] > PACK_MAX_LEN or not (blocks.ENABLED and precision_of(self.config) == "bf16" and txt_ids.is_cuda and H % 64 == 0):
-            x = self._early(self.embeddings(txt_ids))
-            yield txt_ids.numel() // 4
+            x = self.embeddings(txt_ids)
             for layer in self.encoder.layer:
-                streams.gate(layer)      # (forward_units is called directly: the module's forward pre-hooks -- optim.AdamW.attach -- do not fire)
-                x = (yield from layer.forward_units(x, txt_m))[0]
+                x = layer(x, txt_m)[0]
             return x
         pack_idx, cu, unpack_idx = pack
         B, L = txt_ids.shape
         ids = txt_ids.reshape(-1)[pack_idx]
-        x = self._early(self.embeddings(ids[None], position_ids=(pack_idx % L)[None]).view(-1, H))
+        x = self.embeddings(ids[None], position_ids=(pack_idx % L)[None]).view(-1, H)
         x._hamt_seq = (cu, int(cu.shape[0]) - 1, L)
-        yield x.shape[0] // 4
         for layer in self.encoder.layer:
-            streams.gate(layer)
-            x = (yield from layer.forward_units(x, None))[0]
+            x = layer(x, None)[0]
         if keep_packed and X_PACK and not XBIDIR:      # (the cross-modal layers go on with the packed rows: LxmertEncoder.forward)
             x._hamt_unpack = (unpack_idx, B, L)
             return x
@@ -657,13 +618,11 @@ class NavPreTrainedModel(BertPreTrainedModel):
         hist_m = self._extend(hist_masks)
         ob_m = self._extend(ob_masks) if ob_img_feats is not None else None
 
-        def vision_units():
+        def vision_side():
             step_ids = None
             if hist_img_feats is not None:
                 step_ids = ops.const_index("arange", int(hist_img_feats.size(1)), device=txt_ids.device)[None]
-            streams.gate(self.hist_embeddings)
-            cls, steps = yield from self.hist_embeddings.forward_units(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
-                                                                       step_ids, batch_size=B)
+            cls, steps = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, step_ids, batch_size=B)
             hist = cls if steps is None else torch.cat([cls, steps], 1)
             ob = None
             if ob_img_feats is not None:
@@ -671,22 +630,19 @@ class NavPreTrainedModel(BertPreTrainedModel):
                 streams.gate(self.embeddings.token_type_embeddings.weight)
                 tt = ops.gather_rows(self.embeddings.token_type_embeddings.weight, ones).view(B, 1, -1)
                 ob = self.img_embeddings(ob_img_feats, ob_ang_feats, tt, nav_types=ob_nav_types)
-                yield ob.shape[0] * ob.shape[1]
             return hist, ob
-
-        def vision_side():
-            return streams.drive(vision_units())
 
         if txt_ids.is_cuda and streams.two_stream_enabled("trunk"):
             # history / observation embedders (incl. the panorama encoder) on the second stream, next to the text embedder
-            # and the text-only layers: the two chains do not meet before the first cross-modal layer.  Their units are ISSUED
-            # alternately (streams.interleave): a captured graph runs its branches in about the order they were captured in
+            # and the text-only layers: the two chains do not meet before the first cross-modal layer
             main = torch.cuda.current_stream()
             side = streams.side_stream(txt_ids.device)
             streams.fork(main, side)
             for t in (hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, ob_img_feats, ob_ang_feats, ob_nav_types):
                 streams.share(t, side)
-            (hist, ob), txt = streams.interleave([(side, vision_units()), (main, self._text_units(txt_ids, txt_m, keep_packed=True))])
+            with torch.cuda.stream(side):
+                hist, ob = vision_side()
+            txt = self._text(txt_ids, txt_m, keep_packed=True)
             streams.join(main, side)
             streams.share(hist, main)
             streams.share(ob, main)
@@ -708,10 +664,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
         cls_rows = [None]
 
         def text_side():
-            return streams.drive(text_units())
-
-        def text_units():
-            txt = yield from self._text_units(txt_ids, txt_m1, keep_packed=True)
+            txt = self._text(txt_ids, txt_m1, keep_packed=True)
             if txt.dim() == 2:
                 # PACKED text [Mb, H] (a ragged batch): n_rep copies back to back, each with the plan's sequences -- real ones and
                 # fillers -- so the fillers lie BETWEEN the copies: the cross attentions get the pairing explicitly (`_hamt_pair`:
@@ -733,12 +686,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
             return txt[None].expand(n_rep, B, L, H).reshape(n_rep * B, L, H), txt_m1.repeat(n_rep, 1, 1, 1)
 
         def vision_side(neg_idxs, shuffled_pos_ids):
-            return streams.drive(vision_units(neg_idxs, shuffled_pos_ids))
-
-        def vision_units(neg_idxs, shuffled_pos_ids):
-            streams.gate(self.hist_embeddings)
-            cls, nopos = yield from self.hist_embeddings.forward_units(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
-                                                                       pos_ids=None, batch_size=B)
+            cls, nopos = self.hist_embeddings(hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, pos_ids=None, batch_size=B)
             hist = torch.cat([cls, self.hist_embeddings.add_position(nopos, torch.arange(T, device=dev)[None])], 1)
             if self.encoder.h_layers is not None:
                 for layer in self.encoder.h_layers:
@@ -776,7 +724,9 @@ class NavPreTrainedModel(BertPreTrainedModel):
             for t in (hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats, hist_m, neg_idxs,
                       *(shuffled_pos_ids or [])):
                 streams.share(t, side)
-            (vis, vis_m), (txt, txt_m) = streams.interleave([(side, vision_units(neg_idxs, shuffled_pos_ids)), (main, text_units())])
+            with torch.cuda.stream(side):
+                vis, vis_m = vision_side(neg_idxs, shuffled_pos_ids)
+            txt, txt_m = text_side()
             streams.join(main, side)
             streams.share(vis, main)
             streams.share(vis_m, main)

@@ -570,52 +570,6 @@ def _ln_fwd(x2, r2, gamma, beta, eps, p_pre, p_post, want16):
     return y, y16, z, mean, rstd, cid
 
 
-# Dense layer + LayerNorm as one launch (csrc/gemm_ln.hip): HAMT_GEMM_LN = 0 never, 1 whenever the kernel is built for the shape,
-# unset: where it measured faster than hamt_gemm + hamt_ln_fwd on MI355X (`gemm_ln_wins`).
-GEMM_LN = os.environ.get("HAMT_GEMM_LN", "auto")
-
-
-def gemm_ln_wins(M: int, K: int, H: int) -> bool:
-    """Every workgroup of the fused kernel streams the whole [H, K] weight through its CU (LayerNorm needs whole rows, so the grid is
-    M / 32 or M / 64 workgroups of H columns): it is bound by the CU's L2 -> LDS path, about 1.5 us per 64 of K whatever M is, while
-    the two-launch path pays a GEMM that grows with M plus 14 B per element of LayerNorm traffic.  Measured (tools/gemm_ln_bench.py,
-    profiles/r03_gemm_ln_bench.txt)."""
-    if GEMM_LN == "0" or H != 768 or K % 64 != 0:
-        return False
-    if GEMM_LN == "1":
-        return True
-    return _GEMM_LN_RULE(M, K)
-
-
-# Measured on MI355X (profiles/r03_gemm_ln_bench.txt): the fused kernel takes 37-40 us at K = 768 whatever M <= 8192 (58 us with 64-row
-# tiles up to M = 16384) and 95-130 us at K = 3072, against 20-46 us / 37-88 us for hamt_gemm + hamt_ln_fwd at the step's row counts:
-# it wins nowhere on this chip (DESIGN: every workgroup of a full-row tile streams the whole weight through its own LDS-DMA path,
-# ~1000 cycles of piece issue per 36 KB k-step, 36 - 144 steps).  Kept behind HAMT_GEMM_LN=1, tested, profiled; off by default.
-_GEMM_LN_RULE = lambda M, K: False
-
-
-def gemm_ln_fwd(a16, w16, bias, r2, gamma, beta, eps, p_pre, tile_rows=0):
-    """(y, y16, z16, mean, rstd, call_id) = LN(dropout(a16 @ w16^T + bias) + r2): the outputs of `_ln_fwd` behind a bf16 dense layer,
-    from ONE kernel.  a16 [M, K] bf16 (row stride >= K), w16 [H, K] bf16, r2 [M, H] fp32 contiguous."""
-    _chk(a16, "gemm_ln_fwd")
-    M, K = a16.shape
-    H = w16.shape[0]
-    dev = a16.device
-    assert a16.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.shape == (H, K) and w16.is_contiguous()
-    assert r2.shape == (M, H) and r2.dtype == torch.float32 and r2.is_contiguous() and a16.stride(1) == 1
-    z = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
-    y = torch.empty(M, H, dtype=torch.float32, device=dev)
-    mean = torch.empty(M, dtype=torch.float32, device=dev)
-    rstd = torch.empty(M, dtype=torch.float32, device=dev)
-    Mp = _rup(M)
-    y16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev)
-    cid = next_call_id() if p_pre > 0 else 0
-    d = L.GemmLnDesc(M, K, H, a16.stride(0), float(eps), float(p_pre), cid, Mp, int(tile_rows))
-    L.check(L.load().hamt_gemm_ln_fwd(C.byref(d), _p(a16), _p(w16), _p(bias), _p(r2), _p(gamma), _p(beta), _p(z), _p(y), _p(y16),
-                                      _p(mean), _p(rstd), _p(rng_state(dev)), _stream()), "hamt_gemm_ln_fwd")
-    return y, y16, z, mean, rstd, cid
-
-
 LN_DEFER = os.environ.get("HAMT_NO_DEFER_LNRED") is None      # ablation: reduce the parameter-gradient partials in line
 
 
@@ -862,16 +816,18 @@ class EmbedSumFn(torch.autograd.Function):
         return None, rets[0], rets[1], rets[2]
 
 
-def _scatter_add(R, W, dout, idx, table):
+def _scatter_add(R, W, dout, idx, table, unique=False):
     """table[idx[r]] += dout[r] in a fixed summation order (bit-reproducible): tables of a few rows (token / navigability types, the cls
     token) by per-block partial sums (hamt_scatter_add_rows_small), larger ones (position tables, compaction scatters) by one writer per
     table row walking its colliding source rows in row order (hamt_scatter_add_rows_ordered)"""
     T = table.numel() // W
-    if T <= 8 and table.is_contiguous():
+    if unique:        # no two source rows share a table row (a compaction / slice): every element is added once, order cannot matter
+        L.check(L.load().hamt_scatter_add_rows(R, W, _p(dout), W, 0, _p(idx), _p(table), W, _stream()), "hamt_scatter_add_rows")
+    elif T <= 8 and table.is_contiguous():
         ws = torch.empty(64 * T * W, dtype=torch.float32, device=dout.device)
         L.check(L.load().hamt_scatter_add_rows_small(R, W, _p(dout), W, 0, _p(idx), T, _p(table), _p(ws), _stream()), "hamt_scatter_add_rows_small")
     else:
-        ws = torch.empty(2 * max(R, 1), dtype=torch.int32, device=dout.device)
+        ws = torch.empty(34 * max(R, 1), dtype=torch.int32, device=dout.device)
         L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(dout), W, 0, _p(idx), _p(table), W, _p(ws), _stream()), "hamt_scatter_add_rows_ordered")
 
 
@@ -880,8 +836,9 @@ class GatherRowsFn(torch.autograd.Function):
     Serves embedding lookups, boolean-mask compaction, anchor gathers and slices (idx arithmetic)."""
 
     @staticmethod
-    def forward(ctx, table, idx, base):
+    def forward(ctx, table, idx, base, unique=False):
         _chk(table, "GatherRowsFn")
+        ctx.unique = bool(unique)
         W = table.shape[-1]
         t2 = table.reshape(-1, W)
         if t2.stride(-1) != 1:
@@ -913,16 +870,18 @@ class GatherRowsFn(torch.autograd.Function):
                 # there -- no 94 MB zero fill for the 30 522 x 768 word table, no copy into the arena afterwards; published as
                 # `.grad` at the end of the pass (the tied MLM decoder's queued weight gradient then accumulates on top)
                 wgrad.queue(slot.device).current()         # (opens the pass: orders this stream behind an overlapped optimizer update)
-                _scatter_add(R, W, dout, idx, slot)
+                _scatter_add(R, W, dout, idx, slot, ctx.unique)
                 wgrad.publish_slot_grad(p, slot)
             else:
                 dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
-                _scatter_add(R, W, dout, idx, dtab)
-        return dtab, None, (dout.view(ctx.bshape) if ctx.has_base else None)
+                _scatter_add(R, W, dout, idx, dtab, ctx.unique)
+        return dtab, None, (dout.view(ctx.bshape) if ctx.has_base else None), None
 
 
-def gather_rows(table, idx, base=None):
-    return GatherRowsFn.apply(table, idx, base)
+def gather_rows(table, idx, base=None, unique=False):
+    """unique: the caller guarantees that no index repeats (a compaction of masked positions, a slice, one row per sample): the
+    backward then adds every gradient row to its own table row, where the order of the adds cannot matter"""
+    return GatherRowsFn.apply(table, idx, base, unique)
 
 
 _CONST_IDX: dict = {}

@@ -322,7 +322,7 @@ class AdamW(Optimizer):
     def note_fused_sumsq(self, ss: torch.Tensor, params, append: bool = False):
         """wgrad.py: the grouped weight-gradient launch of this pass left the sum of squares of these parameters' gradients in
         `ss` (one float per output tile): the norm kernel skips them (table flag 3) and adds sum(ss) instead.  append: a second
-        launch of the same pass (wgrad.flush_current_stream) adds its tiles to the first one's."""
+        launch of the same pass adds its tiles to the first one's."""
         if self._ov is not None:        # (update at the head of the next replay: the table describes the previous step, see attach())
             return
         # valid for as long as nothing else writes the gradient arena: any torch op on a gradient (averaging over micro-batches or
@@ -506,6 +506,14 @@ class AdamW(Optimizer):
         super().zero_grad(set_to_none=set_to_none)
         self._packed = False
         self._fused = None
+        if self._built and self._table_ready:
+            # a step was prepared (clip_grad_norm_ built the table: which parameters have a gradient, step counts advanced) and no update
+            # consumed it -- the loop dropped this pass (NaN guard, early `continue`).  The reference counts a parameter's step inside
+            # step() only (optim/adamw.py:76-84): take the count back, and let the next pass build its own table
+            self._steps[np.asarray(self._table_active) != 0] -= 1
+            self._table_ready = False
+            self._pending_clip = None
+        self._active = None
         from .. import wgrad
         sync = getattr(self, "_sharded_sync", None)
         if sync is not None and sync._unconsumed:

@@ -110,48 +110,3 @@ def gate(*what):
         return
     for o in list(pending_updates):
         o._ov.gate(what)
-
-
-# ---------------------------------------------------------------------------------------------- interleaved issue of independent chains
-# `interleave` issues the units of independent chains alternately (the chain with the least accumulated cost first, each under its own
-# stream) instead of one whole chain after the other, so that capture order = a plausible execution order; autograd then replays the
-# backward nodes interleaved as well.  Built in round 4 to test whether the capture order is what makes a replayed hipGraph run the
-# panorama encoder's backward 1.4 ms late (behind all nine text layers' backward although its inputs are ready: profiles/
-# r04_queues_*.txt).  It is NOT: the same delay appears with the chains as separate graphs on separate streams, whichever is launched
-# first runs first -- and interleaved capture measured 1-3 % slower (B = 64: 9.96 vs 9.86 ms, B = 16: 5.61 vs 5.45 on one
-# box).  Off by default (HAMT_INTERLEAVE=1 turns it on).
-INTERLEAVE = os.environ.get("HAMT_INTERLEAVE", "0") == "1"
-
-
-def drive(gen):
-    """run a chain generator to completion; its return value"""
-    try:
-        while True:
-            next(gen)
-    except StopIteration as e:
-        return e.value
-
-
-def interleave(chains):
-    """chains: [(stream, generator)]; a generator issues one unit of work per `next` and yields that unit's cost (any positive
-    number: rows x relative width), and returns its result.  Returns the list of results.  HAMT_INTERLEAVE=0: one chain after the
-    other, in the given order (the capture order before round 4)."""
-    if not INTERLEAVE:
-        out = []
-        for st, g in chains:
-            with torch.cuda.stream(st):
-                out.append(drive(g))
-        return out
-    n = len(chains)
-    acc, res, live = [0.0] * n, [None] * n, set(range(n))
-    while live:
-        i = min(live, key=lambda k: (acc[k], k))
-        st, g = chains[i]
-        try:
-            with torch.cuda.stream(st):
-                c = next(g)
-            acc[i] += float(c) if c else 1.0
-        except StopIteration as e:
-            res[i] = e.value
-            live.discard(i)
-    return res

@@ -44,7 +44,7 @@ class _Pass:
         self.items: List[tuple] = []     # (w, b, dy16, x16)
         self.vecs: List[tuple] = []      # (parameter, gradient tensor): published as .grad at flush
         self.lnred: List[tuple] = []     # (ws, red, M, H, want_dxsum): LayerNorm-backward partials, one grouped launch at flush
-        # state shared by the launches of one pass (flush_current_stream may launch a part of the queue early)
+        # state of the pass's launch
         self.targets: dict = {}          # id(parameter) -> gradient buffer
         self.seen: dict = {}             # id(buffer) -> writes launched so far
         self.launched = 0                # launches so far
@@ -314,9 +314,8 @@ def ps_fused_ids(ps: _Pass) -> set:
 
 @torch.no_grad()
 def _launch_items(ps: _Pass, items, later=frozenset()):
-    """hamt_wgrad_grouped for `items` on the current stream and publication of the results as `.grad`.  May run more than once per
-    pass (flush_current_stream): `ps.targets` / `ps.seen` carry which buffers earlier launches of the pass wrote -- a later write to
-    the same buffer accumulates.  `later`: ids of parameters that still have queued problems (their gradients are not final after
+    """hamt_wgrad_grouped for `items` on the current stream and publication of the results as `.grad`.  `ps.targets` / `ps.seen` carry which buffers
+    a launch of the pass wrote -- a later write to the same buffer accumulates.  `later`: ids of parameters that still have queued problems (their gradients are not final after
     this launch: no tile sums of squares for them)."""
     targets, seen = ps.targets, ps.seen
     fresh: list = []
@@ -411,57 +410,6 @@ def _launch_items(ps: _Pass, items, later=frozenset()):
             p.grad = t
         else:                                   # an existing gradient of another dtype / layout
             p.grad.add_(t.to(p.grad.dtype))
-
-
-class _EarlyFlushFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        flush_current_stream(g.device)
-        return g
-
-
-def early_flush_point(x: torch.Tensor) -> torch.Tensor:
-    """Identity whose BACKWARD launches the weight-gradient problems queued so far on the current stream (flush_current_stream): put it
-    on a tensor whose gradient arrives when a long chain of backward nodes of this stream is done.  Keeps the bf16-image tag."""
-    if not (ENABLED and x.requires_grad and torch.is_grad_enabled()):
-        return x
-    y = _EarlyFlushFn.apply(x)
-    for k in ("_hamt_bf16", "_hamt_seq", "_hamt_pair", "_hamt_unpack"):
-        if hasattr(x, k):
-            setattr(y, k, getattr(x, k))
-    return y
-
-
-def flush_current_stream(device=None) -> int:
-    """From INSIDE a backward pass: launch NOW, on the current stream, the queued weight-gradient problems whose operands were
-    produced on that stream, instead of at the end of the pass.  model.vilmodel.NavPreTrainedModel puts such a point behind the
-    backward of the text layers: autograd issues the panorama encoder's backward (second stream) after them, and that chain then runs
-    NEXT TO this launch instead of in front of one launch of everything (profiles/r04_graph_branches.txt: 0.6 ms of every step were
-    the tail of that chain with nothing beside it).  No-op with a handler installed (the data-parallel exchange plans the whole pass)
-    or outside a pass.  Returns the number of problems launched.
-    Measured (round 4, tools/prof_ab.sh, alternating on one box): the overlap happens -- and buys nothing: the panorama backward takes
-    1.7 instead of 1.1 ms next to the MFMA-bound launch, B = 64 9.89 / 10.10 vs 9.90 / 10.00 ms, B = 16 5.49 / 5.62 vs 5.40 / 5.63: the
-    chip is throughput bound there, not idle.  Opt-in: HAMT_EARLY_WGRAD=1."""
-    if not ENABLED or os.environ.get("HAMT_EARLY_WGRAD") != "1":
-        return 0
-    q = queue(device)
-    tid = torch._C._current_graph_task_id()
-    ps = q.passes.get(tid) if tid >= 0 else None
-    if ps is None or q.handler is not None or not ps.items:
-        return 0
-    cur = torch.cuda.current_stream().cuda_stream
-    mine = [it for it in ps.items if getattr(it[2], "_hamt_stream", None) == cur]
-    if not mine:
-        return 0
-    from . import streams
-    streams.wait_pending_updates()
-    ps.items = [it for it in ps.items if getattr(it[2], "_hamt_stream", None) != cur]
-    _launch_items(ps, mine, later=frozenset(id(it[0]) for it in ps.items))
-    return len(mine)
 
 
 # ------------------------------------------------------------------------------------------ planned (arena) mode
