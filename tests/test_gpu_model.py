@@ -75,7 +75,13 @@ def head_tol(prec, fam, case, task):
     reference's own bf16 path".  Trunk activations and losses stay at 1e-2 flat."""
     if prec != "bf16":
         return TOL[prec]
-    return max(TOL[prec], float(load_npz("canon_autocast.npz")[f"{fam}/c{case}/{task}/logits"]))
+    return min(HEAD_CAP, max(TOL[prec], float(load_npz("canon_autocast.npz")[f"{fam}/c{case}/{task}/logits"])))
+
+
+# bf16 head outputs, whatever the reference's own bf16 error on the draw (up to 1.6e-2): never beyond this.  Measured 0.4 - 1.03e-2 over
+# every draw of rounds 4 / 5 (profiles/r05_parity_margins.txt): a 25 % regression of the worst one fails (the un-capped
+# gate would have let 1.59e-2 through)
+HEAD_CAP = 1.25e-2
 
 
 def _itm_uncancelled_scale(sd, cfg, cpu_batch, itm):
@@ -626,40 +632,68 @@ def test_canon_gradients_vs_reference_goldens(prec):
 
 @pytest.mark.parametrize("mode", ["padded", "packed"])
 def test_canon_b64_vs_oracle(mode):
-    """The BENCHMARKED batch itself (VERDICT r3: the goldens stop at B = 16): R2R-canon model, B = 64, L = 80, T = 5 (padded, the
-    headline line) and the ragged batch with its text packing plan (bench.py's `ragged` line), bf16, MLM + SAP -- M = 5120-row GEMMs,
-    the 256-row tiles at their full grid, the 11 520-row panorama encoder, the grouped weight gradients with 20 x 256-row panels per
-    problem -- against the pinned oracle (itself pinned to the reference at B = 2 / 16) on the same weights and batch: loss <= 1e-2,
-    full-gradient cosine >= 0.99, norm ratio within 3 %."""
+    """The BENCHMARKED batch itself (VERDICT r3 / r4: the goldens stop at B = 16): R2R-canon model, B = 64, L = 80, T = 5 (padded, the
+    headline line) and the ragged batch with its text packing plan (bench.py's `ragged` line), bf16, ALL SIX tasks (ITM: 32 originals
+    = 160 pairs, loader.py:130) -- M = 5120-row GEMMs on the 128- / 256-row tiles at their full grids, the 11 520-row panorama encoder,
+    the grouped weight gradients with 20 x 256-row panels per problem -- against the pinned oracle (itself pinned to the reference at
+    B = 2 / 16) on the same weights and batch: loss <= 1e-2; the full gradient at cosine >= 0.99 and a norm within 3 % for MLM / SAP /
+    SPREL / MRC.  SAR and ITM: the loss gradient is a sum of terms that cancel (regression residuals of both signs; five nearly
+    identical candidates: see test_canon_multi_seed_margins), so what is compared at cosine >= 0.99 is the gradient of ONE un-cancelled
+    output, mean_b prediction[b, 0] -- and the outputs themselves (predictions / logits) at 1.25e-2 (head outputs: `head_tol`)."""
     from oracle.hamt_oracle import HamtOracle, OracleConfig, make_state_dict, pretrain_param_shapes
-    from vln_hamt_amd.synth import make_batch
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
     cfg = OracleConfig()
     sd = make_state_dict(pretrain_param_shapes(cfg), seed=5)
     model = build(cfg, sd, "bf16")
     named = dict(model.named_parameters())
     packed = mode == "packed"
+
+    def cosine(osd):
+        dot = n1 = n2 = 0.0
+        for k, r in osd.items():
+            if r.grad is None:
+                assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, f"{k}: unexpected gradient"
+                continue
+            g, r = named[k].grad.detach().cpu().double().reshape(-1), r.grad.double().reshape(-1)
+            dot += float(g @ r); n1 += float(g @ g); n2 += float(r @ r)
+        return dot / (n1 ** 0.5 * n2 ** 0.5), (n1 / n2) ** 0.5
+
+    def fresh():
+        for p in named.values():
+            p.grad = None
+        return {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
+
     with _CountCalls("hamt_attn_varlen_fwd", "hamt_attn_varlen_bwd") as cnt:
-        for i, task in enumerate(("mlm", "sap")):
-            batch = make_batch(task, 64, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)
+        for i, task in enumerate(("mlm", "sap", "sar", "sprel", "mrc", "itm")):
+            batch = make_batch(task, 64 if task != "itm" else 32, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)
+            itm = None
+            if task == "itm":
+                itm = make_itm_rng(batch, seed=11)
+                batch["itm_neg_idxs"], batch["itm_shuffled_pos_ids"] = itm["neg_idxs"], itm["shuffled_pos_ids"]
             cpu_batch = {k: v for k, v in batch.items() if not k.startswith("txt_pack") and k not in ("txt_cu", "txt_unpack_idx")}
-            for p in named.values():
-                p.grad = None
+            osd = fresh()
             loss = model(to_dev(batch), task, True)
             loss.mean().backward()
-            osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
-            ref = HamtOracle(osd, cfg).forward(cpu_batch, task, True)
+            ref = HamtOracle(osd, cfg).forward(cpu_batch, task, True, itm)
             ref.mean().backward()
             lerr = rel_err(loss, ref.detach())
-            dot = n1 = n2 = 0.0
-            for k, r in osd.items():
-                if r.grad is None:
-                    assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, f"{task} {k}: unexpected gradient"
-                    continue
-                g, r = named[k].grad.detach().cpu().double().reshape(-1), r.grad.double().reshape(-1)
-                dot += float(g @ r); n1 += float(g @ g); n2 += float(r @ r)
-            cos = dot / (n1 ** 0.5 * n2 ** 0.5)
-            print(f"[canon B=64 {mode} {task}] loss err {lerr:.2e}, global gradient cosine {cos:.5f}, norm ratio {(n1 / n2) ** 0.5:.4f}")
-            assert lerr <= TOL["bf16"] and cos >= 0.99 and abs((n1 / n2) ** 0.5 - 1) <= 0.03, (task, lerr, cos, (n1 / n2) ** 0.5)
+            cos, ratio = cosine(osd)
+            print(f"[canon B=64 {mode} {task}] loss err {lerr:.2e}, global gradient cosine {cos:.5f}, norm ratio {ratio:.4f}")
+            assert lerr <= TOL["bf16"], (task, lerr)
+            if task not in ("sar", "itm"):
+                assert cos >= 0.99 and abs(ratio - 1) <= 0.03, (task, cos, ratio)
+                continue
+            osd = fresh()
+            out = model(to_dev(batch), task, False)
+            out = out[0] if isinstance(out, tuple) else out
+            out[:, 0].float().mean().backward()
+            ro = HamtOracle(osd, cfg).forward(cpu_batch, task, False, itm)
+            ro = ro[0] if isinstance(ro, tuple) else ro
+            ro[:, 0].mean().backward()
+            oerr = rel_err(out, ro.detach())
+            cos1, ratio1 = cosine(osd)
+            print(f"    [{task} outputs] err {oerr:.2e}; gradient of mean_b output[b, 0]: cosine {cos1:.5f}, norm ratio {ratio1:.4f}")
+            assert oerr <= HEAD_CAP and cos1 >= 0.99 and abs(ratio1 - 1) <= 0.03, (task, oerr, cos1, ratio1)
     assert (cnt.n["hamt_attn_varlen_fwd"] > 0) == packed and (cnt.n["hamt_attn_varlen_bwd"] > 0) == packed, cnt.n
 
 
@@ -1184,54 +1218,6 @@ def test_graphed_inference_rollout_matches_eager():
                                 ob_step_ids=torch.tensor([t], device=DEV), hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
                                 hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
         assert len(gv.graphs) == 3
-
-
-def test_bidirectional_cross_attention_node_matches_two_blocks(tiny):
-    """blocks.XBidirBlockFn (HAMT_XBIDIR=1: LXRTXLayer.cross_att, vilmodel.py:379-383, as one node with each stream projected once
-    by the packed QKV weights and one output projection over both streams' rows) == the two separate cross-attention blocks:
-    SAP loss and every parameter gradient, dropout off, same weights and batch; incl. MLM, whose last x-layer leaves the
-    vision stream's output unread (its gradient arrives as None)."""
-    from vln_hamt_amd.model import vilmodel
-    store, cfg, sd = tiny
-    prev = vilmodel.XBIDIR
-    try:
-        for tag in ("sap", "mlm", "sprel"):
-            task = tag
-            batch = to_dev(_batch_with_itm(store, tag))
-            res = []
-            for flag in (False, True):
-                vilmodel.XBIDIR = flag
-                m = build(cfg, sd, "bf16", train=False)
-                loss = m(batch, task, True)
-                loss.mean().backward()
-                torch.cuda.synchronize()
-                res.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
-            (l0, g0), (l1, g1) = res
-            assert set(g0) == set(g1), set(g0) ^ set(g1)
-            assert float((l0 - l1).abs().max()) <= 2e-3 * max(1.0, float(l0.abs().max())), (tag, l0, l1)
-            dot = sum(float((g0[k].double() * g1[k].double()).sum()) for k in g0)
-            n0 = sum(float((g0[k].double() ** 2).sum()) for k in g0) ** 0.5
-            n1 = sum(float((g1[k].double() ** 2).sum()) for k in g0) ** 0.5
-            print(f"[xbidir {tag}] loss diff {float((l0 - l1).abs().max()):.1e}, gradient cosine {dot / (n0 * n1):.6f}, norm ratio {n1 / n0:.4f}")
-            # (the separate blocks sum the two directions' bf16 key/value gradients in fp32 GEMM epilogues, the node in one bf16 image)
-            assert dot / (n0 * n1) >= 0.9995 and abs(n1 / n0 - 1) < 5e-3
-    finally:
-        vilmodel.XBIDIR = prev
-
-
-def _tiny_navcmt(no_lang_ca=True, train=False, p_drop=None):
-    from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
-    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
-    from vln_hamt_amd.modeling import HamtConfig
-    ocfg = tiny_cfg(no_lang_ca=no_lang_ca, act_pred_token="ob" if no_lang_ca else "ob_txt")
-    if p_drop is not None:
-        for k in ("hidden_dropout_prob", "attention_probs_dropout_prob", "pred_head_dropout_prob"):
-            setattr(ocfg, k, p_drop)
-    kw = dict(vars(ocfg))
-    kw.pop("pretrain_tasks")
-    model = NavCMT(HamtConfig(hamt_precision="bf16", **kw))
-    model.load_state_dict(make_state_dict(navcmt_param_shapes(ocfg), seed=9), strict=True)
-    return model.to(DEV).train(train)
 
 
 def test_rollout_caches_match_the_plain_rollout():
@@ -1848,7 +1834,7 @@ def _two_rank_batch(t, r, cfg, shapes):
     return make_batch(t, 4, cfg, seed=100 * r + sum(map(ord, t)), ragged=True, device=DEV, **kw)
 
 
-def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False, long_run=False, skip_at=None):
+def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False, long_run=False, skip_at=None, acc=1):
     """One data-parallel rank (gloo carries the collectives of CUDA tensors, so two ranks can share the box's single
     GPU): the product's multi-GPU step on this rank's own batches.  use_graph == "wrapped": the reference's OWN loop lines
     (main_r2r.py:150-156, 237-281) around `wrap_model` -- no exchange call, no optimizer argument to clip_grad_norm_, a plain
@@ -1883,7 +1869,7 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
             with torch.no_grad():
                 for p_ in m.parameters():      # rank 1 starts from other weights: wrap_model must bring rank 0's (DDP's broadcast at wrap)
                     p_.add_(0.01)
-        model = wrap_model(m, torch.device("cuda", 0), 0)
+        model = wrap_model(m, torch.device("cuda", 0), 0, gradient_accumulation_steps=acc) if acc > 1 else wrap_model(m, torch.device("cuda", 0), 0)
         assert model is not m and model.module is m
         named = list(model.named_parameters())      # (main_r2r.py builds the optimizer from the WRAPPED model: names gain `module.`)
         o = AdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
@@ -1895,7 +1881,11 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
             for i_, t in enumerate(seq):
                 loss = model(batches[t], task=t, compute_loss=True)
                 loss = loss.mean()
+                if acc > 1:                          # main_r2r.py:242-250
+                    loss = loss / acc
                 loss.backward()
+                if (i_ + 1) % acc:
+                    continue
                 clip_grad_norm_(model.parameters(), 5.0)
                 if i_ != skip_at:                    # (skip_at: a loop that drops this pass -- NaN guard, early `continue` -- and only zeroes the gradients)
                     o.step()
@@ -2024,7 +2014,8 @@ def test_exchange_schedule_is_independent_of_the_batch(sharded):
                                                              ("fp32", True, False, True), ("bf16", True, False, True),
                                                              ("fp32", "wrapped", False, False), ("fp32", "wrapped", True, False),
                                                              ("bf16", "wrapped", True, True), ("bf16", "wrapped", False, True),
-                                                             ("fp32", "wrapped", True, 2), ("fp32", "wrapped", False, 2)])
+                                                             ("fp32", "wrapped", True, 2), ("fp32", "wrapped", False, 2),
+                                                             ("fp32", "wrapped", True, 3), ("bf16", "wrapped", True, 3), ("fp32", "wrapped", False, 3)])
 def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph, sharded, long_run):
     """world_size = 2 for real: two processes, different batches, the product's overlapped exchange (gloo moves the
     CUDA tensors) -- against one process that computes both ranks' gradients on the same weights, averages them,
@@ -2045,10 +2036,13 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
         pytest.skip("HAMT_NO_DEFER_WGRAD")
     # long_run == 2: the short run with its THIRD pass dropped after backward + clip (no optimizer.step(), only zero_grad()): the pending
     # exchange must be discarded -- the next backward exchanges again instead of raising, and no stale norm reaches the next update
+    # long_run == 3: gradient accumulation over two backward passes per update (main_r2r.py:242-250) -- the first pass of a pair only sums
+    # into the local arena, the second exchanges the sums: ONE exchange per update, sharded or not (VERDICT r4 missing 4)
     skip_at = 2 if long_run == 2 else None
+    acc = 2 if long_run == 3 else 1
     long_run = long_run is True
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph, sharded, long_run, skip_at), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), wire, use_graph, sharded, long_run, skip_at, acc), nprocs=2, join=True)
     p0, p1 = torch.load(os.path.join(str(tmp_path), "params0.pt")), torch.load(os.path.join(str(tmp_path), "params1.pt"))
     assert torch.equal(p0, p1), "ranks diverged"
     x0, x1 = torch.load(os.path.join(str(tmp_path), "exchanges0.pt")), torch.load(os.path.join(str(tmp_path), "exchanges1.pt"))
@@ -2071,18 +2065,20 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     o.materialize()
     bs = [{t: _two_rank_batch(t, r, cfg, shapes) for t in set(seq)} for r in range(2)]
     ref_losses = [[], []]
-    for i_, t in enumerate(seq):
+    for i_ in range(0, len(seq), acc):
         if i_ == skip_at:
             continue
-        l_ = m(bs[0][t], t, True).mean()
-        ref_losses[0].append(float(l_))
-        l_.backward()
+        for t in seq[i_:i_ + acc]:                  # (rank 0's micro-batches of this update: gradients accumulate in .grad)
+            l_ = m(bs[0][t], t, True).mean()
+            ref_losses[0].append(float(l_))
+            (l_ / acc).backward()
         o._pack_grads()
         g0 = o._flat_g.clone()
         o.zero_grad()
-        l_ = m(bs[1][t], t, True).mean()
-        ref_losses[1].append(float(l_))
-        l_.backward()
+        for t in seq[i_:i_ + acc]:
+            l_ = m(bs[1][t], t, True).mean()
+            ref_losses[1].append(float(l_))
+            (l_ / acc).backward()
         o._pack_grads()
         if long_run and wire == "bf16":
             # the wire's own arithmetic (DDP bf16_compress_hook: halve, round to bf16, sum in bf16): where the two ranks' gradients
@@ -2138,22 +2134,10 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
         for mx, cnt, n in rows_[:8]:
             print(f"        exp_avg off by up to {mx:.2e} in {cnt} elements: {n}")
     # (long run: in units of the learning rate -- an element that met stale or missing moments is off by about lr per step)
-    if long_run and wire == "bf16":
-        # bf16 wire at eps = 1e-6: the comparison above is exact only while the two runs' gradients agree to the last bit, and the
-        # embedding tables' gradients do not -- their rows are summed by float atomics, whose order changes with the timing of the
-        # launch (tools/exchange_identity_probe.py: word / type / nav-type / position tables differ by 1 ulp between two executions of
-        # the same step).  One ulp in a table row moves the next forward pass by 1e-7, and where two ranks' gradients nearly cancel
-        # the ROUNDED average then flips -- a whole lr per flip.  What the test is for -- moments or masters going stale, chunks
-        # changing owner -- puts whole arena chunks (>= 1 / 16 of the elements) off by ~lr PER STEP: gate the count and the size.
-        assert n_off <= 2e-3 * diff.numel() and worst < 8 * hyp["lr"], (n_off, worst, who)
-    else:
-        assert worst < (0.3e-6 if long_run else (2e-5 if wire == "fp32" else 2e-4)), (worst, who)
+    # (round 4 gated the bf16-wire long run by a COUNT of elements off by a step: the word / position tables' gradients were summed by float
+    # atomics, one ulp of run-to-run difference flipped a rounded two-rank average here and there.  The scatter-adds are ordered now
+    # -- hamt_scatter_add_rows_ordered, tools/grad_bitwise_repeat.py: no tensor varies -- and the exact bound is back)
+    assert worst < (0.3e-6 if long_run else (2e-5 if wire == "fp32" else 2e-4)), (worst, who)
     if sharded:
         assert torch.equal(m0, m1) and torch.equal(v0, v1), "gather_state left the ranks with different moments"
-    if long_run and wire == "bf16":      # (as above: a rounded average that flipped leaves its element's moments off by up to an ulp of the halves)
-        n_m = int(((m0 - mr).abs() > tol * float(mr.abs().max())).sum())
-        n_v = int(((v0 - vr).abs() > tol * float(vr.abs().max())).sum())
-        print(f"    moments off by more than {tol:.0e} of their scale: {n_m} / {n_v} elements")
-        assert n_m <= 2e-3 * m0.numel() and n_v <= 2e-3 * v0.numel() and em < 0.2 and ev < 0.2, (n_m, n_v, em, ev)
-    else:
-        assert em < tol and ev < tol, (em, ev)
+    assert em < tol and ev < tol, (em, ev)

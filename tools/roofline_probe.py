@@ -274,39 +274,7 @@ def subblock_xattn(model, batch, device, L_txt=80, n_vis=43):
         tot_s += dt
         tot_f += fl
     tf = tot_f / tot_s / 1e12
-    # both directions as ONE node (blocks.XBidirBlockFn: each stream projected once with the packed Q | K | V weights, the two attentions
-    # into one context image, ONE shared output projection / dgrad / weight gradient over both streams' rows: 7 launches forward and 7
-    # backward instead of 10 + 10): faster in isolation, slower inside the step where the two directions otherwise run side by side
-    # on two streams (HAMT_XBIDIR)
-    bidir = None
-    from vln_hamt_amd import wgrad as _wg
-    try:
-        if _wg.get_handler(device) is not None:
-            # a data-parallel exchange is installed (bench.py --gpus N): its launch groups on two lanes inside THIS capture end in a
-            # segmentation fault in hipStreamEndCapture on ROCm 7.0 (wait chains between forked streams, DESIGN_HISTORY section 6) -- the
-            # one-node form is measured in single-process runs only
-            raise RuntimeError("skipped with a gradient exchange installed")
-        xl_ = torch.randn(batch, L_txt, Hd, device=device, requires_grad=True)
-        xv_ = torch.randn(batch, n_vis, Hd, device=device, requires_grad=True)
-        ml, mv = torch.zeros(batch, 1, 1, L_txt, device=device), torch.zeros(batch, 1, 1, n_vis, device=device)
-        dl, dv = torch.randn(batch, L_txt, Hd, device=device), torch.randn(batch, n_vis, Hd, device=device)
-
-        def step2():
-            yl, yv = blocks.xbidir_block(xl_, ml, xv_, mv, att, out, True)
-            torch.autograd.backward([yl, yv], [dl, dv])
-            xl_.grad = None
-            xv_.grad = None
-        step2()
-        for p_ in model.parameters():
-            p_.grad = None
-        dt2 = _graph_time(step2, st)
-        for p_ in model.parameters():
-            p_.grad = None
-        bidir = {"fwd_bwd_us_both_directions": round(dt2 * 1e6, 1), "tflops": round(tot_f / dt2 / 1e12, 1), "frac": round(tot_f / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4),
-                 "launches": "7 forward + 7 backward (+ the pass's grouped weight-gradient launch) for BOTH directions; not the step's default (HAMT_XBIDIR=1)"}
-    except Exception as e:      # a measurement aid
-        bidir = {"error": f"{type(e).__name__}: {e}"}
-    return {"bidirectional_node": bidir, "block": f"CrossAttnBlockFn forward + backward (LN-ed inputs, Q / KV projections, masked softmax attention, output projection, dropout + "
+    return {"block": f"CrossAttnBlockFn forward + backward (LN-ed inputs, Q / KV projections, masked softmax attention, output projection, dropout + "
                      f"residual + LayerNorm, all weight gradients), both directions, B={batch}, 12 heads x 64, bf16, dropout 0.1",
             "flops_formula": "3 * (4 Sq H^2 + 4 Sk H^2 + 4 Sq Sk H) per direction per sample (SURVEY 8d)", "bound": "mfma",
             "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "cases": res}

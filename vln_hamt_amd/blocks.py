@@ -346,112 +346,6 @@ class CrossAttnBlockFn(torch.autograd.Function):
                 dwqs[0], dbqs[0], dwo, dbo, dgamma, dbeta, None, None, None, None)
 
 
-class XBidirBlockFn(torch.autograd.Function):
-    """LXRTXLayer.cross_att (vilmodel.py:379-383): ONE shared-weight cross attention applied in both directions on the
-    pre-update inputs,  lang' = LN(drop(W_o att(W_q lang, W_kv vis)) + lang),  vis' = LN(drop(W_o att(W_q vis, W_kv lang)) + vis),
-    as one node: each stream is projected ONCE with the packed [W_q; W_k; W_v] (its queries serve its own direction, its keys /
-    values the other one), the two attentions write one joint context image, and the shared output projection, its dgrad and
-    its weight gradient run ONCE over the rows of both streams.  7 launches forward / 7 backward instead of 10 / 10, every
-    input enters the tape once (no gradient-accumulation adds for the pre-update inputs)."""
-
-    @staticmethod
-    def forward(ctx, xl, xv, mask_l, mask_v, heads, p_attn, p_hidden, eps, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta):
-        B, Sl, H = xl.shape
-        Sv = xv.shape[1]
-        Ml, Mv = B * Sl, B * Sv
-        dev = xl.device
-        xl2, xv2 = xl.reshape(Ml, H), xv.reshape(Mv, H)
-        xl2 = xl2 if xl2.is_contiguous() else xl2.contiguous()
-        xv2 = xv2 if xv2.is_contiguous() else xv2.contiguous()
-        xl16, xv16 = _x16_of(xl, xl2), _x16_of(xv, xv2)
-        Mlp, Mvp = xl16.shape[0], xv16.shape[0]
-        qkv_l = torch.empty(Mlp, 3 * H, dtype=torch.bfloat16, device=dev)
-        qkv_v = torch.empty(Mvp, 3 * H, dtype=torch.bfloat16, device=dev)
-        _proj(xl16, Ml, (wq, wk, wv), (bq, bk, bv), qkv_l)
-        _proj(xv16, Mv, (wq, wk, wv), (bq, bk, bv), qkv_v)
-        ctx16 = torch.empty(Mlp + Mvp, H, dtype=torch.bfloat16, device=dev)          # [lang rows | pad | vis rows | pad]
-        if Mlp != Ml:
-            ctx16[Ml:Mlp].zero_()
-        if Mvp != Mv:
-            ctx16[Mlp + Mv:].zero_()
-        ml2 = mask_l.reshape(B, Sl).to(torch.float32).contiguous() if mask_l is not None else None
-        mv2 = mask_v.reshape(B, Sv).to(torch.float32).contiguous() if mask_v is not None else None
-        lse_l = torch.empty(B * heads * Sl, dtype=torch.float32, device=dev)
-        lse_v = torch.empty(B * heads * Sv, dtype=torch.float32, device=dev)
-        cid_l, cid_v = next_call_id(), next_call_id()
-        rng = rng_state(dev)
-        lib = L.load()
-        dl = _attn_desc(B, heads, Sl, Sv, H, 3 * H, 3 * H, 3 * H, p_attn, cid_l)       # lang queries over vis keys / values
-        L.check(lib.hamt_attn_small_fwd(C.byref(dl), _p(qkv_l[:, :H]), _p(qkv_v[:, H:2 * H]), _p(qkv_v[:, 2 * H:]), _p(mv2), _p(ctx16[:Mlp]),
-                                        _p(lse_l), _p(rng), _stream()), "hamt_attn_small_fwd")
-        dv_ = _attn_desc(B, heads, Sv, Sl, H, 3 * H, 3 * H, 3 * H, p_attn, cid_v)      # vis queries over lang keys / values
-        L.check(lib.hamt_attn_small_fwd(C.byref(dv_), _p(qkv_v[:, :H]), _p(qkv_l[:, H:2 * H]), _p(qkv_l[:, 2 * H:]), _p(ml2), _p(ctx16[Mlp:]),
-                                        _p(lse_v), _p(rng), _stream()), "hamt_attn_small_fwd")
-        o = torch.empty(Mlp + Mvp, H, dtype=O_DTYPE, device=dev)
-        gemm(ctx16, weight_operand(wo, "bf16"), o, bias=bo.detach())
-        yl, yl16, zl, mean_l, rstd_l, cln_l = _ln_fwd(o[:Ml], xl2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
-        yv, yv16, zv, mean_v, rstd_v, cln_v = _ln_fwd(o[Mlp:Mlp + Mv], xv2, gamma.detach(), beta.detach(), eps, p_hidden, 0.0, True)
-        ctx.save_for_backward(xl16, xv16, qkv_l, qkv_v, ctx16, lse_l, lse_v, ml2, mv2, zl, mean_l, rstd_l, zv, mean_v, rstd_v,
-                              wq, bq, wk, bk, wv, bv, wo, bo, gamma)
-        ctx.ln_params = (gamma, beta, bo)
-        ctx.meta = (B, Sl, Sv, H, heads, float(p_attn), float(p_hidden), float(eps), cid_l, cid_v, cln_l, cln_v)
-        ctx.mark_non_differentiable(yl16, yv16)
-        ctx.set_materialize_grads(False)
-        return yl.view(B, Sl, H), yl16, yv.view(B, Sv, H), yv16
-
-    @staticmethod
-    def backward(ctx, dyl, _u1=None, dyv=None, _u2=None):
-        if dyl is None and dyv is None:
-            return (None,) * 18
-        (xl16, xv16, qkv_l, qkv_v, ctx16, lse_l, lse_v, ml2, mv2, zl, mean_l, rstd_l, zv, mean_v, rstd_v,
-         wq, bq, wk, bk, wv, bv, wo, bo, gamma) = ctx.saved_tensors
-        B, Sl, Sv, H, heads, p_attn, p_hidden, eps, cid_l, cid_v, cln_l, cln_v = ctx.meta
-        Ml, Mv = B * Sl, B * Sv
-        Mlp, Mvp = xl16.shape[0], xv16.shape[0]
-        dev = ctx16.device
-        # a stream the task never reads in the last x-layer (SURVEY 7.8) arrives as None: its direction contributes zeros
-        if dyl is None:
-            dyl = torch.zeros(B, Sl, H, dtype=torch.float32, device=dev)
-        if dyv is None:
-            dyv = torch.zeros(B, Sv, H, dtype=torch.float32, device=dev)
-        dx16 = torch.empty(Mlp + Mvp, H, dtype=torch.bfloat16, device=dev)
-        dzl, _, _, dgamma, dbeta, dbo = _ln_bwd(dyl.reshape(Ml, H).contiguous(), zl, mean_l, rstd_l, gamma.detach(), eps, p_hidden, 0.0, cln_l,
-                                                False, True, True, params=ctx.ln_params, dx16_out=dx16[:Mlp])
-        dzv, _, _, dgamma2, dbeta2, dbo2 = _ln_bwd(dyv.reshape(Mv, H).contiguous(), zv, mean_v, rstd_v, gamma.detach(), eps, p_hidden, 0.0, cln_v,
-                                                   False, True, True, params=ctx.ln_params, dx16_out=dx16[Mlp:])
-        if dgamma is not None:            # (not deferred: ablation switches) the two calls' parameter gradients add up
-            dgamma, dbeta, dbo = dgamma + dgamma2, dbeta + dbeta2, dbo + dbo2
-        dctx16 = torch.empty(Mlp + Mvp, H, dtype=torch.bfloat16, device=dev)
-        gemm(dx16, weight_operand(wo, "bf16"), dctx16, b_kmajor=True)
-        dwo, _ = _wgrad(wo, None, dx16, ctx16, Mlp + Mvp)
-        dqkv_l = _zeros_or_empty(Mlp, Ml, 3 * H, dev)
-        dqkv_v = _zeros_or_empty(Mvp, Mv, 3 * H, dev)
-        rng = rng_state(dev)
-        lib = L.load()
-        dl = _attn_desc(B, heads, Sl, Sv, H, 3 * H, 3 * H, 3 * H, p_attn, cid_l)
-        L.check(lib.hamt_attn_small_bwd(C.byref(dl), _p(qkv_l[:, :H]), _p(qkv_v[:, H:2 * H]), _p(qkv_v[:, 2 * H:]), _p(mv2), _p(ctx16[:Mlp]), _p(dctx16[:Mlp]),
-                                        _p(lse_l), None, _p(dqkv_l[:, :H]), _p(dqkv_v[:, H:2 * H]), _p(dqkv_v[:, 2 * H:]), _p(rng), _stream()), "hamt_attn_small_bwd")
-        dv_ = _attn_desc(B, heads, Sv, Sl, H, 3 * H, 3 * H, 3 * H, p_attn, cid_v)
-        L.check(lib.hamt_attn_small_bwd(C.byref(dv_), _p(qkv_v[:, :H]), _p(qkv_l[:, H:2 * H]), _p(qkv_l[:, 2 * H:]), _p(ml2), _p(ctx16[Mlp:]), _p(dctx16[Mlp:]),
-                                        _p(lse_v), None, _p(dqkv_v[:, :H]), _p(dqkv_l[:, H:2 * H]), _p(dqkv_l[:, 2 * H:]), _p(rng), _stream()), "hamt_attn_small_bwd")
-        dxl, dw_l, db_l = _proj_bwd(dqkv_l, Ml, xl16, (wq, wk, wv), (bq, bk, bv), dx_accum_into=dzl)
-        dxv, dw_v, db_v = _proj_bwd(dqkv_v, Mv, xv16, (wq, wk, wv), (bq, bk, bv), dx_accum_into=dzv)
-        add = lambda a, b: a if b is None else (b if a is None else a + b)      # (queued weight gradients come back as None)
-        dws = [add(a, b) for a, b in zip(dw_l, dw_v)]
-        dbs = [add(a, b) for a, b in zip(db_l, db_v)]
-        return (dxl.view(B, Sl, H), dxv.view(B, Sv, H), None, None, None, None, None, None,
-                dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dgamma, dbeta)
-
-
-def xbidir_block(xl, mask_l, xv, mask_v, att, att_out, training):
-    pa = float(att.dropout.p) if training else 0.0
-    ph = float(att_out.dropout.p) if training else 0.0
-    yl, yl16, yv, yv16 = XBidirBlockFn.apply(xl, xv, mask_l, mask_v, att.num_attention_heads, pa, ph, att_out.LayerNorm.eps,
-                                             att.query.weight, att.query.bias, att.key.weight, att.key.bias, att.value.weight, att.value.bias,
-                                             att_out.dense.weight, att_out.dense.bias, att_out.LayerNorm.weight, att_out.LayerNorm.bias)
-    return _tag(yl, yl16), _tag(yv, yv16)
-
-
 def _kv_key(c, att):
     a = getattr(att.key.weight, "_hamt_arena16", None)
     return (id(att), c._version, att.key.weight._version, att.value.weight._version, a[2] if a is not None else -1, ops._cache_epoch[0],

@@ -299,11 +299,6 @@ def _ffn(inter, out, x, training):
     return out(inter(x), x)
 
 
-# HAMT_XBIDIR=1: both cross-attention directions of an x-layer as ONE node (blocks.XBidirBlockFn: each stream projected once with
-# the packed QKV weights, one output projection / dgrad / weight gradient over both streams' rows; 14 instead of 20 launches per
-# layer and no gradient-accumulation adds).  Measured on MI355X it is 0.3 % (B=16) to 0.8 % (B=64) SLOWER than the two separate
-# blocks, which run side by side on the two compute streams, so it is off by default.
-XBIDIR = os.environ.get("HAMT_XBIDIR") == "1"
 # HAMT_NO_X_PACK=1: a packed text stream (ragged batches, NavPreTrainedModel._text) is scattered back to [B, L, H] BEFORE the
 # cross-modal layers instead of behind them (measurement switch)
 X_PACK = os.environ.get("HAMT_NO_X_PACK") != "1"
@@ -326,9 +321,6 @@ class LXRTXLayer(nn.Module):
 
     def cross_att(self, lang_input, lang_attention_mask, visn_input, visn_attention_mask):
         xa = self.visual_attention
-        if XBIDIR and lang_input.dim() == 3 and blocks.usable(xa.att.prec, lang_input) and blocks.usable(xa.att.prec, visn_input):
-            # both directions as ONE node (blocks.XBidirBlockFn): each stream projected once with the packed QKV weights
-            return blocks.xbidir_block(lang_input, lang_attention_mask, visn_input, visn_attention_mask, xa.att, xa.output, self.training)
         lang_att = xa(lang_input, visn_input, ctx_att_mask=visn_attention_mask)
         visn_att = xa(visn_input, lang_input, ctx_att_mask=lang_attention_mask)
         return lang_att, visn_att
@@ -355,21 +347,6 @@ class LXRTXLayer(nn.Module):
         main = torch.cuda.current_stream()
         side = streams.side_stream(lang_feats.device)
         xa = self.visual_attention
-        if XBIDIR and lang_feats.dim() == 3 and blocks.usable(xa.att.prec, lang_feats) and blocks.usable(xa.att.prec, visn_feats):
-            # the shared cross attention of both directions is ONE node on `main`; the streams fork behind it
-            lang_x, visn_x = self.cross_att(lang_feats, lang_mask, visn_feats, visn_mask)
-            streams.fork(main, side)
-            for t in (visn_x, getattr(visn_x, "_hamt_bf16", (None,))[0], visn_mask):
-                if t is not None:
-                    streams.share(t, side)
-            with torch.cuda.stream(side):
-                visn = self.visn_self_att(visn_x, visn_mask)
-                visn_out = _ffn(self.visn_inter, self.visn_output, visn[0], self.training)
-            lang = self.lang_self_att(lang_x, lang_mask)
-            lang_out = _ffn(self.lang_inter, self.lang_output, lang[0], self.training)
-            streams.join(main, side)
-            streams.share(visn_out, main)
-            return lang_out, visn_out
         # the shared cross-attention is applied on BOTH streams: build its lazily cached bf16 weight images (only used when
         # the optimizer's bf16 arena is not there) on `main` before the fork, not concurrently on whichever stream is first
         for lin in (xa.att.query, xa.att.key, xa.att.value, xa.output.dense):
@@ -601,7 +578,7 @@ class NavPreTrainedModel(BertPreTrainedModel):
         x._hamt_seq = (cu, int(cu.shape[0]) - 1, L)
         for layer in self.encoder.layer:
             x = layer(x, None)[0]
-        if keep_packed and X_PACK and not XBIDIR:      # (the cross-modal layers go on with the packed rows: LxmertEncoder.forward)
+        if keep_packed and X_PACK:      # (the cross-modal layers go on with the packed rows: LxmertEncoder.forward)
             x._hamt_unpack = (unpack_idx, B, L)
             return x
         return ops.gather_rows(x, unpack_idx).view(B, L, H)

@@ -598,7 +598,7 @@ def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_
     dz = torch.empty(M, H, dtype=torch.float32, device=dev)
     dx = torch.empty(M, H, dtype=torch.float32, device=dev) if (want_dx32 and p_pre > 0) else None
     Mp = _rup(M) if want_dx16 else 0
-    if dx16_out is not None:      # caller-provided rows of a larger bf16 image (blocks.XBidirBlockFn's joint buffer)
+    if dx16_out is not None:      # caller-provided rows of a larger bf16 image
         assert want_dx16 and dx16_out.shape == (Mp, H) and dx16_out.is_contiguous()
         dx16 = dx16_out
     else:

@@ -675,9 +675,16 @@ class ArenaDataParallel(torch.nn.Module):
 
     `.module` is the wrapped model (utils/save.py:36 `model.module if hasattr(model, 'module') else model`)."""
 
-    def __init__(self, module: torch.nn.Module, n_groups: int | None = None, wire: str | None = None, sharded: bool | None = None):
+    def __init__(self, module: torch.nn.Module, n_groups: int | None = None, wire: str | None = None, sharded: bool | None = None,
+                 accumulation_steps: int = 1):
         super().__init__()
         self.module = module
+        # gradient accumulation (main_r2r.py:242-250: `loss / gradient_accumulation_steps`, optimizer.step() every k-th pass): the first
+        # k - 1 backward passes of an update only SUM into the local gradient arena (the weight-gradient launch accumulates, no
+        # collective), the k-th exchanges the sums -- one exchange per update, which is also what the sharded exchange requires.
+        # Settable after construction (`model.accumulation_steps = opts.gradient_accumulation_steps`).
+        self.accumulation_steps = max(1, int(accumulation_steps))
+        self._micro = 0
         self._cfg = (n_groups if n_groups is not None else int(os.environ.get("HAMT_SYNC_GROUPS", 4)), wire, sharded)
         self.grad_sync = None
         self._armed: set = set()
@@ -717,9 +724,19 @@ class ArenaDataParallel(torch.nn.Module):
     def forward(self, *args, **kwargs):
         out = self.module(*args, **kwargs)
         if torch.is_grad_enabled() and dist.is_available() and dist.is_initialized():
-            t = out if torch.is_tensor(out) else next((x for x in (out if isinstance(out, (tuple, list)) else ()) if torch.is_tensor(x) and x.requires_grad), None)
-            if t is not None and t.requires_grad:
-                t.register_hook(self._arm)
+            # every tensor output that can start a backward pass arms the exchange (tuple / list / dict outputs, nested: a loss built
+            # from the second output alone must exchange too -- torch DDP covers all outputs; `_armed` keeps it to once per pass)
+            def walk(o):
+                if torch.is_tensor(o):
+                    if o.requires_grad:
+                        o.register_hook(self._arm)
+                elif isinstance(o, (tuple, list)):
+                    for x in o:
+                        walk(x)
+                elif isinstance(o, dict):
+                    for x in o.values():
+                        walk(x)
+            walk(out)
         return out
 
     def _arm(self, _grad):
@@ -743,7 +760,18 @@ class ArenaDataParallel(torch.nn.Module):
         # this callback was queued when the pass STARTED, i.e. in front of the weight-gradient queue's own end-of-pass flush: run that
         # flush now (it hands the queued problems to the exchange, which launches them group by group with the collectives behind
         # them); the queue's own callback then finds nothing left
-        wgrad.queue(dev).flush(tid)
+        self._micro += 1
+        q = wgrad.queue(dev)
+        if self._micro % self.accumulation_steps:
+            # not the update's last micro-batch: the queued weight gradients are launched into (accumulated into) the local arena, no
+            # exchange.  (The exchange object stays the queue's handler for the pass that does exchange.)
+            h, q.handler = q.handler, None
+            try:
+                q.flush(tid)
+            finally:
+                q.handler = h
+            return
+        q.flush(tid)
         sync(opt)                           # nothing queued in this pass (fp32 mode): the plain range-by-range exchange
 
     def close(self):
@@ -752,13 +780,15 @@ class ArenaDataParallel(torch.nn.Module):
             self.grad_sync = None
 
 
-def wrap_model(model: torch.nn.Module, device: torch.device, local_rank: int) -> torch.nn.Module:
+def wrap_model(model: torch.nn.Module, device: torch.device, local_rank: int, gradient_accumulation_steps: int = 1) -> torch.nn.Module:
     """pretrain_src/utils/misc.py:52-65 with the same signature: `model.to(device)`; distributed (local_rank != -1) -> the
     arena-exchange wrapper instead of torch DDP (see ArenaDataParallel); a single process is returned as it is (the reference's
-    nn.DataParallel branch for several visible GPUs in ONE process is not built: one process per GPU)."""
+    nn.DataParallel branch for several visible GPUs in ONE process is not built: one process per GPU).
+    `gradient_accumulation_steps` (optional, the one argument the reference's call does not have): opts.gradient_accumulation_steps when
+    it is > 1 -- the exchange then runs on every k-th backward pass only, on the locally accumulated sums (ArenaDataParallel)."""
     model.to(device)
     if local_rank != -1 and dist.is_available() and dist.is_initialized():
-        return ArenaDataParallel(model)
+        return ArenaDataParallel(model, accumulation_steps=gradient_accumulation_steps)
     return model
 
 
