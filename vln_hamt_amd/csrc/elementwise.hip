@@ -336,10 +336,15 @@ __device__ __forceinline__ void scatter_members_sum(const float* __restrict__ sr
                                                     const int* __restrict__ perm, int first, int stride, int e, float* a) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) a[k] = 0.f;
+  int nxt[SCAT_UNROLL];                             // (the next round's row numbers are requested while this round's rows arrive)
+#pragma unroll
+  for (int u = 0; u < SCAT_UNROLL; ++u) { const int j = first + u * stride; nxt[u] = j < e ? perm[j] : -1; }
   for (int j0 = first; j0 < e; j0 += stride * SCAT_UNROLL) {
     int rows[SCAT_UNROLL];
 #pragma unroll
-    for (int u = 0; u < SCAT_UNROLL; ++u) { const int j = j0 + u * stride; rows[u] = j < e ? perm[j] : -1; }
+    for (int u = 0; u < SCAT_UNROLL; ++u) rows[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < SCAT_UNROLL; ++u) { const int j = j0 + (SCAT_UNROLL + u) * stride; nxt[u] = j < e ? perm[j] : -1; }
     float v[SCAT_UNROLL][12];
 #pragma unroll
     for (int u = 0; u < SCAT_UNROLL; ++u) {
@@ -390,10 +395,15 @@ __global__ __launch_bounds__(64 * SCAT_WAVES) void scatter_segment_add_kernel(in
   if (p < R) {
     id = sid[p];
     start = p == 0 || sid[p - 1] != id;
-    if (start) {      // end of the list: sid is sorted, so a binary search (a linear scan of a 750-row list is 750 dependent L2 round trips)
-      int lo = p + 1, hi = R;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (sid[mid] == id) lo = mid + 1; else hi = mid; }
-      e = lo;
+    if (start) {      // end of the list: a few steps of a linear scan (most lists have one or two rows), then -- sid is sorted -- a binary search
+      e = p + 1;      // (a linear scan of a 750-row list is 750 dependent L2 round trips; a binary search of every 1-row list is 13)
+      int k = 0;
+      while (e < R && k < 4 && sid[e] == id) { ++e; ++k; }
+      if (k == 4 && e < R && sid[e] == id) {
+        int lo = e + 1, hi = R;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sid[mid] == id) lo = mid + 1; else hi = mid; }
+        e = lo;
+      }
     }
   }
   const int n = e - p;
