@@ -1111,6 +1111,55 @@ def test_two_stream_cross_layers_match_single_stream():
             assert dl <= 1e-6 and dg <= max(1e-6, 10 * floor), (rep, task, dl, dg, floor)
 
 
+@pytest.mark.parametrize("task", ["mlm", "sar", "sprel", "mrc"])
+def test_unread_side_of_the_last_cross_layer_is_dead_code(task):
+    """The MLM / SAR heads read only the text output of the trunk, the SPREL / MRC heads only the history + observation outputs: the
+    other side of the LAST cross-modal layer is not launched (vilmodel.LXRTXLayer.forward `need`).  Loss and EVERY parameter
+    gradient must equal the full computation's bit for bit (dropout off: the per-call mask ids shift with the skipped calls), and
+    the skipped side's parameters get no gradient either way."""
+    from oracle.hamt_oracle import OracleConfig, make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd import ops
+    from vln_hamt_amd.model import vilmodel
+    from vln_hamt_amd.synth import make_batch
+    cfg = OracleConfig()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=13)
+    model = build(cfg, sd, "bf16", train=True)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    b = make_batch(task, 8, cfg, seed=21, txt_len=80, hist_len=5, ragged=True, device=DEV)
+
+    def run(dce):
+        old = vilmodel.DEAD_SIDE_ELIMINATION
+        vilmodel.DEAD_SIDE_ELIMINATION = dce
+        try:
+            ops.manual_seed(5, torch.device(DEV))
+            model.zero_grad(set_to_none=True)
+            loss = model(b, task, True).mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss.detach().clone(), {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+        finally:
+            vilmodel.DEAD_SIDE_ELIMINATION = old
+
+    l_full, g_full = run(False)
+    l_dce, g_dce = run(True)
+    assert torch.equal(l_full, l_dce), (float(l_full), float(l_dce))
+    last = f"bert.encoder.x_layers.{cfg.num_x_layers - 1}."
+    dead = ("visn_self_att", "visn_inter", "visn_output") if task in ("mlm", "sar") else ("lang_self_att", "lang_inter", "lang_output")
+    n_dead = 0
+    for n, g in g_full.items():
+        h = g_dce[n]
+        if n.startswith(last) and any(d in n for d in dead):
+            n_dead += 1
+            assert (g is None or not bool(g.any())) and (h is None or not bool(h.any())), n
+            continue
+        assert (g is None) == (h is None), n
+        if g is not None:
+            assert torch.equal(g, h), (n, float((g - h).abs().max()))
+    assert n_dead >= 10, n_dead
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("no_lang_ca", [False, True])
 def test_finetune_rollout_backward_vs_oracle(prec, no_lang_ca):

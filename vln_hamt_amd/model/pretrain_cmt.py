@@ -137,8 +137,9 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                     hist_masks, txt_labels, compute_loss, label_idx=None):
         """`label_idx` (optional, int64 flat positions of the masked tokens in row-major order, e.g. built by the
         collate on the host) avoids the device->host sync of boolean indexing, so the step is graph-capturable."""
+        # (only the text output is read: the vision side of the last cross-modal layer is dead code, vilmodel.LXRTXLayer.forward)
         txt_embeds, _, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
-                                     hist_pano_ang_fts, hist_masks, None, None, None, None)
+                                     hist_pano_ang_fts, hist_masks, None, None, None, None, need="lang")
         if label_idx is None:
             label_idx = (txt_labels != -1).reshape(-1).nonzero(as_tuple=False).squeeze(1)
         masked_output = ops.gather_rows(txt_embeds.reshape(-1, txt_embeds.size(-1)), label_idx, unique=True)
@@ -171,7 +172,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                     hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, ob_act_angles, ob_progress, compute_loss):
         txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
                                                        hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
-                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, need="lang")
         B, L, H = txt_embeds.shape
         cls_rows = ops.const_index("arange_mul", int(B), int(L), device=txt_embeds.device)
         prediction_scores = self.regress_action(ops.gather_rows(txt_embeds.reshape(B * L, H), cls_rows, unique=True))
@@ -185,7 +186,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                       hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, sp_anchor_idxs, sp_targets, compute_loss):
         txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
                                                        hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
-                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, need="visn")
         B, S, H = ob_embeds.shape                                  # S = 37; the reference hard-codes 36 views (:211-212)
         flat = ob_embeds.reshape(B * S, H)
         base = ops.const_index("arange_mul", int(B), int(S), device=flat.device)
@@ -206,7 +207,7 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                     hist_masks, hist_mrc_masks, hist_img_probs, compute_loss=True, mrc_idx=None):
         """`mrc_idx` (optional): int64 flat positions b*T+t of the masked steps in row-major order (see forward_mlm)."""
         txt_embeds, hist_embeds, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
-                                               hist_pano_ang_fts, hist_masks, None, None, None, None)
+                                               hist_pano_ang_fts, hist_masks, None, None, None, None, need="visn")
         B, T1, H = hist_embeds.shape
         T = T1 - 1
         if mrc_idx is None:

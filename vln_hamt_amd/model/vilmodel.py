@@ -302,6 +302,8 @@ def _ffn(inter, out, x, training):
 # HAMT_NO_X_PACK=1: a packed text stream (ragged batches, NavPreTrainedModel._text) is scattered back to [B, L, H] BEFORE the
 # cross-modal layers instead of behind them (measurement switch)
 X_PACK = os.environ.get("HAMT_NO_X_PACK") != "1"
+# the side of the LAST cross-modal layer whose output the task head does not read is not computed (LXRTXLayer.forward `need`); HAMT_NO_DCE=1: always both
+DEAD_SIDE_ELIMINATION = os.environ.get("HAMT_NO_DCE") is None
 PACK_MAX_LEN = 128      # longest sequence hamt_attn_varlen_* / hamt_attn_varlen_cross_* serve (include/hamt.h)
 
 
@@ -332,7 +334,18 @@ class LXRTXLayer(nn.Module):
     def output_fc(self, lang_input, visn_input):
         return _ffn(self.lang_inter, self.lang_output, lang_input, self.training), _ffn(self.visn_inter, self.visn_output, visn_input, self.training)
 
-    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
+    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask, need="both"):
+        """`need` = "lang" / "visn" (the LAST cross-modal layer only, LxmertEncoder.forward): the caller reads one side's output --
+        after the shared cross-attention the two sides are independent chains, so the other one is dead code (no result, no
+        gradient: autograd never ran its backward either) and is not launched; None is returned in its place."""
+        if need == "lang":
+            lang = self.visual_attention(lang_feats, visn_feats, ctx_att_mask=visn_attention_mask)
+            lang = self.lang_self_att(lang[0] if isinstance(lang, tuple) else lang, lang_attention_mask)
+            return _ffn(self.lang_inter, self.lang_output, lang[0], self.training), None
+        if need == "visn":
+            visn = self.visual_attention(visn_feats, lang_feats, ctx_att_mask=lang_attention_mask)
+            visn = self.visn_self_att(visn[0] if isinstance(visn, tuple) else visn, visn_attention_mask)
+            return None, _ffn(self.visn_inter, self.visn_output, visn[0], self.training)
         if lang_feats.is_cuda and streams.two_stream_enabled():
             return self._forward_two_streams(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         lang, visn = self.cross_att(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
@@ -389,7 +402,9 @@ class LxmertEncoder(nn.Module):
         return txt_embeds
 
     def forward(self, txt_embeds, extended_txt_masks, hist_embeds, extended_hist_masks,
-                img_embeds=None, extended_img_masks=None, text_done=False):
+                img_embeds=None, extended_img_masks=None, text_done=False, need="both"):
+        """`need` = "lang" / "visn": the caller reads only the text output / only the history + observation outputs (the MLM and SAR heads;
+        the MRC and SPREL heads) -- the unread side of the last cross-modal layer is not computed and returned as None."""
         if not text_done:       # (the caller may have run them already, next to the vision-side embedders)
             txt_embeds = self.text_layers(txt_embeds, extended_txt_masks)
         # a PACKED text stream [M, H] (NavPreTrainedModel._text(keep_packed=True): the real tokens of a ragged batch back to back) stays
@@ -417,10 +432,13 @@ class LxmertEncoder(nn.Module):
             # padded layout in front of the cross-modal layers
             txt_embeds = ops.gather_rows(txt_embeds, unpack[0]).view(unpack[1], unpack[2], -1)
             unpack = None
-        for layer in self.x_layers:
-            txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks)
-        if unpack is not None:
+        last = len(self.x_layers) - 1
+        for i, layer in enumerate(self.x_layers):
+            txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks, need=need if (i == last and DEAD_SIDE_ELIMINATION) else "both")
+        if unpack is not None and txt_embeds is not None:
             txt_embeds = ops.gather_rows(txt_embeds, unpack[0]).view(unpack[1], unpack[2], -1)
+        if vis is None:
+            return txt_embeds, None, None
         hist_embeds = vis[:, :n_hist]
         if img_embeds is not None:
             img_embeds = vis[:, n_hist:]
@@ -589,7 +607,9 @@ class NavPreTrainedModel(BertPreTrainedModel):
         return ops.extend_mask(mask)
 
     def forward(self, txt_ids, txt_masks, hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
-                hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks):
+                hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks, need="both"):
+        """`need` (not in the reference's signature; default = its behaviour): "lang" / "visn" when the caller reads only the text output /
+        only the history + observation outputs -- see LxmertEncoder.forward."""
         B = txt_ids.size(0)
         txt_m = self._extend(txt_masks)
         hist_m = self._extend(hist_masks)
@@ -623,10 +643,10 @@ class NavPreTrainedModel(BertPreTrainedModel):
             streams.join(main, side)
             streams.share(hist, main)
             streams.share(ob, main)
-            return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True)
+            return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True, need=need)
         txt = self._text(txt_ids, txt_m, keep_packed=True)
         hist, ob = vision_side()
-        return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True)
+        return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True, need=need)
 
     def forward_itm(self, txt_ids, txt_masks, hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
                     hist_masks, num_neg_trajs=4, neg_idxs=None, shuffled_pos_ids=None):
