@@ -49,6 +49,29 @@ def trunk_fwd_flops(task, L=L_TXT, T=T_HIST):
     return f
 
 
+def dead_fwd_flops(task, L=L_TXT, T=T_HIST, n_masked=12):
+    """forward FLOPs per ORIGINAL sample that the reference launches and nobody reads ("dead code in the last cross-modal layer"):
+    the side of the last layer whose output the head does not read (28 S H^2 + 4 C H^2 + 4 S C H + 4 S^2 H for a side of S rows with a
+    context of C rows) and, of a side read at R rows only, the feed-forward block of the other S - R rows (16 H^2 each).  The reference's
+    autograd never runs the backward of any of it, so of SURVEY 8a's 3 x forward these FLOPs are counted three times and executed once
+    there, zero times here."""
+    ob = task in ("sap", "sar", "sprel")
+    vn = T + 1 + (V + 1 if ob else 0)
+    side = lambda S, C: 28 * S * H * H + 4 * C * H * H + 4 * S * C * H + 4 * S * S * H
+    ffn = lambda rows: 16 * rows * H * H
+    if task == "mlm":
+        return side(vn, L) + ffn(L - n_masked)
+    if task == "sar":
+        return side(vn, L) + ffn(L - 1)
+    if task in ("mrc", "sprel"):
+        return side(L, vn)
+    if task == "sap":
+        return ffn(L - 1)
+    if task == "itm":
+        return 5 * (ffn(L - 1) + ffn(vn - 1))
+    return 0
+
+
 def build_model(prec, device):
     from vln_hamt_amd.model.pretrain_cmt import MultiStepNavCMTPreTraining
     from vln_hamt_amd.modeling import HamtConfig
@@ -215,18 +238,25 @@ def main():
             grad_sync = make_grad_sync(opt, args.prec, n_groups=ng, wire=wire)
     net = model
 
+    from vln_hamt_amd.model import vilmodel as _vil
     sched = TaskSchedule(cyclic=True) if args.task == "mix" else None
     n_distinct = 12
     batches = {}
 
     ragged_mode = [bool(args.ragged)]
+    full_mode = [False]                                 # the `full_work` region: HAMT_NO_DCE behaviour (every launch of the reference's forward)
+
+    def _sfx():
+        return (("ragged",) if ragged_mode[0] else ()) + (("full",) if full_mode[0] else ())
+
     sample_flops = {}                                   # batch key -> 3 x forward FLOPs summed over the batch's samples at THEIR lengths
+    dead_flops, dead_sum = {}, [0.0]                    # ... of which never read by anything (dead_fwd_flops), and their sum over the last timed region
 
     def get_batch(step, bsz=None):
         bsz = bsz or args.batch
         task = sched.task_at(step) if sched else args.task
         rg = ragged_mode[0]
-        key = (task, step % n_distinct, bsz) + (("ragged",) if rg else ())
+        key = (task, step % n_distinct, bsz) + _sfx()
         if key not in batches:                          # synthetic inputs resident in HBM before the timed region
             b = make_batch(task, bsz, cfg, seed=1234 + rank + 7919 * (step % n_distinct), txt_len=L_TXT,
                            hist_len=7 if rg else T_HIST, ragged=rg, mlm_exact=12 if (task == "mlm" and not rg) else None, device=device)
@@ -240,8 +270,12 @@ def main():
                 nm = int(b["txt_label_idx"].numel()) if task == "mlm" else 0
                 sample_flops[key] = 3.0 * (sum(trunk_fwd_flops(task, int(l), int(t)) - (2 * 12 * H * 30522 + 2 * 12 * H * H if task == "mlm" else 0)
                                                for l, t in zip(ls, ts)) + 2 * nm * H * (30522 + H))
+                # (the padded rows of a padded batch are launched, so the dead rows are counted at the padded length; packed text: at the sample's)
+                dead_flops[key] = 3.0 * sum(dead_fwd_flops(task, int(l), int(b["hist_masks"].shape[1]) - 1 if b.get("hist_masks") is not None else 0,
+                                                           nm / max(len(ls), 1)) for l in ls)
             else:
                 sample_flops[key] = 3.0 * trunk_fwd_flops(task) * b["txt_ids"].shape[0]
+                dead_flops[key] = 3.0 * dead_fwd_flops(task) * b["txt_ids"].shape[0]
         return task, batches[key]
 
     log("generating synthetic batches")
@@ -263,7 +297,7 @@ def main():
             lr = 5e-5 * min(1.0, gstep[0] / 10000.0)
             for g in opt.param_groups:
                 g["lr"] = lr
-            key = (task, step % n_distinct, bsz) + (("ragged",) if ragged_mode[0] else ())
+            key = (task, step % n_distinct, bsz) + _sfx()
             graphed.step(key, b, task)
             # the bench's inputs are resident in HBM: keep working on the captured step's own static input tensors (a
             # loader would write each new batch into them; GraphedTrainStep.step copies any other batch in)
@@ -303,10 +337,12 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         samples, flops = 0, 0.0
+        dead_sum[0] = 0.0
         for s in range(warmup, warmup + steps):
             task, n = train_step(s, bsz)
             samples += n
-            flops += sample_flops[(task, s % n_distinct, bsz) + (("ragged",) if ragged_mode[0] else ())]
+            flops += sample_flops[(task, s % n_distinct, bsz) + _sfx()]
+            dead_sum[0] += dead_flops[(task, s % n_distinct, bsz) + _sfx()]
         if graphed is not None:
             graphed.finish()                 # the last step's parameter update (overlap_update: a replay applies the previous step's)
         torch.cuda.synchronize()
@@ -315,6 +351,7 @@ def main():
         return max_over_ranks(time.perf_counter() - t0, device), samples, flops
 
     dt, samples, flops = timed_region(args.batch, args.warmup, args.steps)
+    dead_main = sum_over_ranks(dead_sum[0], device)
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
     # the driver's K may be small (20 steps = 0.2 s): repeat the region so that box-to-box / run-to-run spread is visible
     regions = [dt / args.steps * 1e3]
@@ -346,10 +383,15 @@ def main():
                        "hist_len": "U[0,7]" if args.ragged else T_HIST,
                        "views": V, "task_mix": "mlm:sap:sar:sprel:mrc:itm=5:1:1:1:2:2" if args.task == "mix" else args.task,
                        "parallelism": f"dp{world}" + (f" (flat-arena {'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} " + ("reduce-scatter + owned-slice AdamW + all-gather" if getattr(grad_sync, "sharded", False) else "all-reduce") + f", {wire} on the wire" + (", overlapped with wgrad" if getattr(grad_sync, "overlapped", False) else "") + ")" if dist_on else ""),
-                       "launch": "hipGraph replay" if graphed is not None else "eager"},
+                       "launch": "hipGraph replay" if graphed is not None else "eager",
+                       # what no head reads of the LAST cross-modal layer is not launched (results unchanged: loss and every gradient);
+                       # `full_work` below is the same step with every launch of the reference's forward (HAMT_NO_DCE=1)
+                       "dead_code_elimination": bool(_vil.DEAD_SIDE_ELIMINATION)},
             "per_gpu": round(total_samples / dt / world, 2),
             "model_tflops_per_gpu": round(total_flops / dt / world / 1e12, 2),
             "mfma_roofline_frac_end_to_end": round(total_flops / dt / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+            # SURVEY 8a's 3 x forward counts work the reference launches and never reads (dead_fwd_flops) three times; executed here: none of it
+            "executed_tflops_per_gpu": round((total_flops - (dead_main if _vil.DEAD_SIDE_ELIMINATION else dead_main * 2.0 / 3.0)) / dt / world / 1e12, 2),
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
             "exposed_comm_ms_per_step": exposed_comm_ms,
             "regions_ms_per_step": [round(r, 3) for r in regions], "regions_min_ms": round(min(regions), 3),
@@ -373,6 +415,21 @@ def main():
                 log(f"batch {bsz}: {dt2 / n2 * 1e3:.3f} ms/step")
                 for k in [k for k in batches if k[2] == bsz]:
                     del batches[k]
+        if _vil.DEAD_SIDE_ELIMINATION and not args.no_probes and world == 1:
+            # the same step with EVERY launch of the reference's forward (the unread side / rows of the last cross-modal layer included)
+            full_mode[0] = True
+            _vil.DEAD_SIDE_ELIMINATION = False
+            try:
+                dt4, smp4, fl4 = timed_region(args.batch, n_distinct, max(24, args.steps // 2), verbose=False)
+            finally:
+                _vil.DEAD_SIDE_ELIMINATION = True
+                full_mode[0] = False
+            n4 = max(24, args.steps // 2)
+            out["full_work"] = {"what": "HAMT_NO_DCE=1: nothing of the reference's forward skipped", "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 3),
+                                "value": round(smp4 / dt4, 2), "unit": "panorama-steps/s"}
+            log(f"full work (no dead-code elimination): {dt4 / n4 * 1e3:.3f} ms/step")
+            for k in [k for k in batches if k[-1] == "full"]:
+                del batches[k]
         if not args.ragged and not args.no_probes and args.task == "mix" and world == 1:
             # SURVEY 8d's ragged variant: per-sample L ~ U[20, 80], T ~ U[0, 7], padded to the batch maximum (the reference's collate);
             # throughput in samples/s, FLOPs counted at every sample's OWN lengths (padding is work the path does, not work it is credited for)

@@ -1111,23 +1111,29 @@ def test_two_stream_cross_layers_match_single_stream():
             assert dl <= 1e-6 and dg <= max(1e-6, 10 * floor), (rep, task, dl, dg, floor)
 
 
-@pytest.mark.parametrize("task", ["mlm", "sar", "sprel", "mrc"])
-def test_unread_side_of_the_last_cross_layer_is_dead_code(task):
-    """The MLM / SAR heads read only the text output of the trunk, the SPREL / MRC heads only the history + observation outputs: the
-    other side of the LAST cross-modal layer is not launched (vilmodel.LXRTXLayer.forward `need`).  Loss and EVERY parameter
-    gradient must equal the full computation's bit for bit (dropout off: the per-call mask ids shift with the skipped calls), and
-    the skipped side's parameters get no gradient either way."""
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("task", ["mlm", "sap", "sar", "sprel", "mrc", "itm"])
+def test_unread_outputs_of_the_last_cross_layer_are_dead_code(task, prec):
+    """What a task head does not read of the LAST cross-modal layer is not computed (vilmodel.LXRTXLayer.forward): the whole vision
+    side for MLM / SAR, the whole text side for MRC / SPREL, and of a side of which only some rows are read (the masked positions for
+    MLM, the [CLS] rows for SAP / SAR / ITM) the feed-forward block of the other rows.  Against the full computation (HAMT_NO_DCE
+    behaviour) on the same weights and batch, dropout off: SPREL / MRC skip whole kernels only and must agree bit for bit; where the
+    feed-forward block runs on fewer rows another GEMM tile is picked, so: fp32 mode to summation-order noise, bf16 mode to the
+    re-rolled bf16 roundings of that one block.  The skipped side's parameters get no gradient either way."""
     from oracle.hamt_oracle import OracleConfig, make_state_dict, pretrain_param_shapes
     from vln_hamt_amd import ops
     from vln_hamt_amd.model import vilmodel
-    from vln_hamt_amd.synth import make_batch
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
     cfg = OracleConfig()
     sd = make_state_dict(pretrain_param_shapes(cfg), seed=13)
-    model = build(cfg, sd, "bf16", train=True)
+    model = build(cfg, sd, prec, train=True)
     for mod in model.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
     b = make_batch(task, 8, cfg, seed=21, txt_len=80, hist_len=5, ragged=True, device=DEV)
+    if task == "itm":
+        r = make_itm_rng(b, seed=9)
+        b["itm_neg_idxs"], b["itm_shuffled_pos_ids"] = r["neg_idxs"], r["shuffled_pos_ids"]
 
     def run(dce):
         old = vilmodel.DEAD_SIDE_ELIMINATION
@@ -1138,26 +1144,41 @@ def test_unread_side_of_the_last_cross_layer_is_dead_code(task):
             loss = model(b, task, True).mean()
             loss.backward()
             torch.cuda.synchronize()
-            return loss.detach().clone(), {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+            return loss.detach().double().cpu(), {n: (None if p.grad is None else p.grad.detach().double().cpu()) for n, p in model.named_parameters()}
         finally:
             vilmodel.DEAD_SIDE_ELIMINATION = old
 
     l_full, g_full = run(False)
     l_dce, g_dce = run(True)
-    assert torch.equal(l_full, l_dce), (float(l_full), float(l_dce))
+    exact = task in ("sprel", "mrc")
+    dl = abs(float(l_full - l_dce)) / max(1.0, abs(float(l_full)))
+    assert dl <= (0.0 if exact else (1e-5 if prec == "fp32" else 5e-3)), (float(l_full), float(l_dce))
     last = f"bert.encoder.x_layers.{cfg.num_x_layers - 1}."
-    dead = ("visn_self_att", "visn_inter", "visn_output") if task in ("mlm", "sar") else ("lang_self_att", "lang_inter", "lang_output")
-    n_dead = 0
+    dead = {"mlm": ("visn_self_att", "visn_inter", "visn_output"), "sar": ("visn_self_att", "visn_inter", "visn_output"),
+            "sprel": ("lang_self_att", "lang_inter", "lang_output"), "mrc": ("lang_self_att", "lang_inter", "lang_output")}.get(task, ())
+    n_dead, dot, na, nb, worst = 0, 0.0, 0.0, 0.0, 0.0
+    gmax = max(float(g.abs().max()) for g in g_full.values() if g is not None)
     for n, g in g_full.items():
         h = g_dce[n]
         if n.startswith(last) and any(d in n for d in dead):
             n_dead += 1
             assert (g is None or not bool(g.any())) and (h is None or not bool(h.any())), n
             continue
-        assert (g is None) == (h is None), n
-        if g is not None:
+        gz, hz = g is None or not bool(g.any()), h is None or not bool(h.any())
+        assert gz == hz, n
+        if gz:
+            continue
+        if exact:
             assert torch.equal(g, h), (n, float((g - h).abs().max()))
-    assert n_dead >= 10, n_dead
+        dot += float((g * h).sum()); na += float((g * g).sum()); nb += float((h * h).sum())
+        worst = max(worst, float((g - h).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax))     # (tensors that cancel to noise: against the global scale)
+    cos = dot / (na * nb) ** 0.5
+    print(f"[dce {task} {prec}] loss diff {dl:.2e}, gradient cosine {cos:.7f}, norm ratio {(nb / na) ** 0.5:.6f}, worst per-tensor max diff {worst:.2e} of its max")
+    assert n_dead >= (10 if dead else 0), n_dead
+    if prec == "fp32":
+        assert cos >= 1 - 1e-8 and worst <= 1e-3, (cos, worst)
+    else:
+        assert cos >= 0.9995 and abs((nb / na) ** 0.5 - 1) <= 5e-3, (cos, (nb / na) ** 0.5)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -1267,6 +1288,21 @@ def test_graphed_inference_rollout_matches_eager():
                                 ob_step_ids=torch.tensor([t], device=DEV), hist_pano_img_feats=b["hist_pano_img_fts"][:, t].contiguous(),
                                 hist_pano_ang_feats=b["hist_pano_ang_fts"][:, t].contiguous()))
         assert len(gv.graphs) == 3
+
+
+def _tiny_navcmt(no_lang_ca=True, train=False, p_drop=None):
+    from oracle.hamt_oracle import make_state_dict, navcmt_param_shapes
+    from vln_hamt_amd.models.vilmodel_cmt import NavCMT
+    from vln_hamt_amd.modeling import HamtConfig
+    ocfg = tiny_cfg(no_lang_ca=no_lang_ca, act_pred_token="ob" if no_lang_ca else "ob_txt")
+    if p_drop is not None:
+        for k in ("hidden_dropout_prob", "attention_probs_dropout_prob", "pred_head_dropout_prob"):
+            setattr(ocfg, k, p_drop)
+    kw = dict(vars(ocfg))
+    kw.pop("pretrain_tasks")
+    model = NavCMT(HamtConfig(hamt_precision="bf16", **kw))
+    model.load_state_dict(make_state_dict(navcmt_param_shapes(ocfg), seed=9), strict=True)
+    return model.to(DEV).train(train)
 
 
 def test_rollout_caches_match_the_plain_rollout():

@@ -137,12 +137,13 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
                     hist_masks, txt_labels, compute_loss, label_idx=None):
         """`label_idx` (optional, int64 flat positions of the masked tokens in row-major order, e.g. built by the
         collate on the host) avoids the device->host sync of boolean indexing, so the step is graph-capturable."""
-        # (only the text output is read: the vision side of the last cross-modal layer is dead code, vilmodel.LXRTXLayer.forward)
-        txt_embeds, _, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
-                                     hist_pano_ang_fts, hist_masks, None, None, None, None, need="lang")
         if label_idx is None:
             label_idx = (txt_labels != -1).reshape(-1).nonzero(as_tuple=False).squeeze(1)
-        masked_output = ops.gather_rows(txt_embeds.reshape(-1, txt_embeds.size(-1)), label_idx, unique=True)
+        # (only the masked rows of the text output are read: the vision side of the last cross-modal layer and the other rows of its text-side
+        # feed-forward block are dead code, vilmodel.LXRTXLayer.forward)
+        txt_embeds, _, _ = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts,
+                                     hist_pano_ang_fts, hist_masks, None, None, None, None, need="lang", lang_rows=label_idx)
+        masked_output = txt_embeds if txt_embeds.dim() == 2 else ops.gather_rows(txt_embeds.reshape(-1, txt_embeds.size(-1)), label_idx, unique=True)
         prediction_scores = self.mlm_head(masked_output)
         if compute_loss:
             return ops.cross_entropy(prediction_scores, txt_labels.reshape(-1).index_select(0, label_idx))
@@ -157,10 +158,11 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
     # ---- A16
     def forward_sap(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
                     hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, act_labels, compute_loss):
+        cls_rows = ops.const_index("arange_mul", int(txt_ids.size(0)), int(txt_ids.size(1)), device=txt_ids.device)
         txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
                                                        hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
-                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks)
-        fused = ops.mul_bcast(ob_embeds, txt_embeds[:, 0])
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, lang_rows=cls_rows)
+        fused = ops.mul_bcast(ob_embeds, txt_embeds if txt_embeds.dim() == 2 else txt_embeds[:, 0])     # (2-D: the [CLS] rows already)
         prediction_scores = self.next_action(fused).squeeze(-1)
         prediction_scores = ops.fill_where_zero(prediction_scores, ob_nav_types, -float('inf'))
         if compute_loss:
@@ -170,12 +172,13 @@ class MultiStepNavCMTPreTraining(BertPreTrainedModel):
     # ---- A17
     def forward_sar(self, txt_ids, txt_masks, hist_img_fts, hist_ang_fts, hist_pano_img_fts, hist_pano_ang_fts,
                     hist_masks, ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, ob_act_angles, ob_progress, compute_loss):
+        B, L = txt_ids.shape
+        cls_rows = ops.const_index("arange_mul", int(B), int(L), device=txt_ids.device)
         txt_embeds, hist_embeds, ob_embeds = self.bert(txt_ids, txt_masks, hist_img_fts, hist_ang_fts,
                                                        hist_pano_img_fts, hist_pano_ang_fts, hist_masks,
-                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, need="lang")
-        B, L, H = txt_embeds.shape
-        cls_rows = ops.const_index("arange_mul", int(B), int(L), device=txt_embeds.device)
-        prediction_scores = self.regress_action(ops.gather_rows(txt_embeds.reshape(B * L, H), cls_rows, unique=True))
+                                                       ob_img_fts, ob_ang_fts, ob_nav_types, ob_masks, need="lang", lang_rows=cls_rows)
+        cls = txt_embeds if txt_embeds.dim() == 2 else ops.gather_rows(txt_embeds.reshape(B * L, -1), cls_rows, unique=True)
+        prediction_scores = self.regress_action(cls)
         if compute_loss:
             act_targets = torch.cat([ob_act_angles, ob_progress.unsqueeze(1)], dim=1)
             return ops.mse_loss(prediction_scores, act_targets)

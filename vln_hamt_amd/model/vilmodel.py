@@ -307,6 +307,13 @@ DEAD_SIDE_ELIMINATION = os.environ.get("HAMT_NO_DCE") is None
 PACK_MAX_LEN = 128      # longest sequence hamt_attn_varlen_* / hamt_attn_varlen_cross_* serve (include/hamt.h)
 
 
+def _rows_of(x, rows):
+    """x [B, S, H] (or a packed [M, H]) -> its rows `rows` as [R, H]; x itself when rows is None."""
+    if rows is None:
+        return x
+    return ops.gather_rows(x.reshape(-1, x.shape[-1]), rows, unique=True)
+
+
 class LXRTXLayer(nn.Module):
     """LXMERT cross-modality layer: ONE shared cross-attention applied in both directions on the
     pre-update inputs, then per-stream self-attention and FFN (vilmodel.py:362-412)."""
@@ -334,25 +341,29 @@ class LXRTXLayer(nn.Module):
     def output_fc(self, lang_input, visn_input):
         return _ffn(self.lang_inter, self.lang_output, lang_input, self.training), _ffn(self.visn_inter, self.visn_output, visn_input, self.training)
 
-    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask, need="both"):
-        """`need` = "lang" / "visn" (the LAST cross-modal layer only, LxmertEncoder.forward): the caller reads one side's output --
-        after the shared cross-attention the two sides are independent chains, so the other one is dead code (no result, no
-        gradient: autograd never ran its backward either) and is not launched; None is returned in its place."""
+    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask, need="both", lang_rows=None, visn_rows=None):
+        """`need` = "lang" / "visn" and `lang_rows` / `visn_rows` are for the LAST cross-modal layer only (LxmertEncoder.forward): what
+        the caller reads of this layer's outputs.  After the shared cross-attention the two sides are independent chains, and behind a
+        side's self-attention its feed-forward block is row-wise -- so a side nobody reads (`need`) is not launched at all (None is
+        returned in its place), and of a side of which only some rows are read (`*_rows`: int64 flat row indices into its [B * S, H]
+        self-attention output -- the [CLS] rows, the masked positions) the feed-forward block runs on those rows only and [R, H] is
+        returned.  Dead code in the reference (it computes everything and indexes afterwards; autograd never ran the unread rows'
+        backward either): every result is unchanged."""
         if need == "lang":
             lang = self.visual_attention(lang_feats, visn_feats, ctx_att_mask=visn_attention_mask)
             lang = self.lang_self_att(lang[0] if isinstance(lang, tuple) else lang, lang_attention_mask)
-            return _ffn(self.lang_inter, self.lang_output, lang[0], self.training), None
+            return _ffn(self.lang_inter, self.lang_output, _rows_of(lang[0], lang_rows), self.training), None
         if need == "visn":
             visn = self.visual_attention(visn_feats, lang_feats, ctx_att_mask=lang_attention_mask)
             visn = self.visn_self_att(visn[0] if isinstance(visn, tuple) else visn, visn_attention_mask)
-            return None, _ffn(self.visn_inter, self.visn_output, visn[0], self.training)
+            return None, _ffn(self.visn_inter, self.visn_output, _rows_of(visn[0], visn_rows), self.training)
         if lang_feats.is_cuda and streams.two_stream_enabled():
-            return self._forward_two_streams(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
+            return self._forward_two_streams(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask, lang_rows, visn_rows)
         lang, visn = self.cross_att(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         lang, visn = self.self_att(lang, lang_attention_mask, visn, visn_attention_mask)
-        return self.output_fc(lang[0], visn[0])
+        return self.output_fc(_rows_of(lang[0], lang_rows), _rows_of(visn[0], visn_rows))
 
-    def _forward_two_streams(self, lang_feats, lang_mask, visn_feats, visn_mask):
+    def _forward_two_streams(self, lang_feats, lang_mask, visn_feats, visn_mask, lang_rows=None, visn_rows=None):
         """Same computation with the vision-side chain (cross <- lang, self, FFN) on a second stream: after the shared
         cross-attention both sides are independent until the next layer, and the vision side is a chain of tiny kernels
         (6 history tokens per sample when there is no observation) that would otherwise leave the chip mostly idle.
@@ -365,15 +376,15 @@ class LXRTXLayer(nn.Module):
         for lin in (xa.att.query, xa.att.key, xa.att.value, xa.output.dense):
             ops.weight_operand(lin.weight, xa.att.prec)
         streams.fork(main, side)
-        for t in (lang_feats, visn_feats, lang_mask, visn_mask):
+        for t in (lang_feats, visn_feats, lang_mask, visn_mask, visn_rows):
             streams.share(t, side)                      # inputs produced on `main`, read by the vision-side kernels
         with torch.cuda.stream(side):
             visn = self.visual_attention(visn_feats, lang_feats, ctx_att_mask=lang_mask)
             visn = self.visn_self_att(visn[0] if isinstance(visn, tuple) else visn, visn_mask)
-            visn_out = _ffn(self.visn_inter, self.visn_output, visn[0], self.training)
+            visn_out = _ffn(self.visn_inter, self.visn_output, _rows_of(visn[0], visn_rows), self.training)
         lang = self.visual_attention(lang_feats, visn_feats, ctx_att_mask=visn_mask)
         lang = self.lang_self_att(lang[0] if isinstance(lang, tuple) else lang, lang_mask)
-        lang_out = _ffn(self.lang_inter, self.lang_output, lang[0], self.training)
+        lang_out = _ffn(self.lang_inter, self.lang_output, _rows_of(lang[0], lang_rows), self.training)
         streams.join(main, side)
         streams.share(visn_out, main)                   # produced on `side`, consumed on `main` from here on
         return lang_out, visn_out
@@ -402,9 +413,11 @@ class LxmertEncoder(nn.Module):
         return txt_embeds
 
     def forward(self, txt_embeds, extended_txt_masks, hist_embeds, extended_hist_masks,
-                img_embeds=None, extended_img_masks=None, text_done=False, need="both"):
+                img_embeds=None, extended_img_masks=None, text_done=False, need="both", lang_rows=None):
         """`need` = "lang" / "visn": the caller reads only the text output / only the history + observation outputs (the MLM and SAR heads;
-        the MRC and SPREL heads) -- the unread side of the last cross-modal layer is not computed and returned as None."""
+        the MRC and SPREL heads) -- the unread side of the last cross-modal layer is not computed and returned as None.  `lang_rows` (int64
+        flat positions b * L + l): the caller reads only these text rows (the masked positions, the [CLS] rows) -- the text output is then
+        [R, H], those rows in that order, and the last layer's feed-forward block ran on them only (LXRTXLayer.forward)."""
         if not text_done:       # (the caller may have run them already, next to the vision-side embedders)
             txt_embeds = self.text_layers(txt_embeds, extended_txt_masks)
         # a PACKED text stream [M, H] (NavPreTrainedModel._text(keep_packed=True): the real tokens of a ragged batch back to back) stays
@@ -433,9 +446,16 @@ class LxmertEncoder(nn.Module):
             txt_embeds = ops.gather_rows(txt_embeds, unpack[0]).view(unpack[1], unpack[2], -1)
             unpack = None
         last = len(self.x_layers) - 1
+        if not DEAD_SIDE_ELIMINATION or need == "visn":
+            lang_rows = None
+        if lang_rows is not None and unpack is not None:
+            lang_rows = unpack[0].index_select(0, lang_rows)          # padded position -> row of the packed text
         for i, layer in enumerate(self.x_layers):
-            txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks, need=need if (i == last and DEAD_SIDE_ELIMINATION) else "both")
-        if unpack is not None and txt_embeds is not None:
+            if i == last and DEAD_SIDE_ELIMINATION:
+                txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks, need=need, lang_rows=lang_rows)
+            else:
+                txt_embeds, vis = layer(txt_embeds, extended_txt_masks, vis, vis_masks)
+        if unpack is not None and txt_embeds is not None and lang_rows is None:
             txt_embeds = ops.gather_rows(txt_embeds, unpack[0]).view(unpack[1], unpack[2], -1)
         if vis is None:
             return txt_embeds, None, None
@@ -607,9 +627,10 @@ class NavPreTrainedModel(BertPreTrainedModel):
         return ops.extend_mask(mask)
 
     def forward(self, txt_ids, txt_masks, hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
-                hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks, need="both"):
-        """`need` (not in the reference's signature; default = its behaviour): "lang" / "visn" when the caller reads only the text output /
-        only the history + observation outputs -- see LxmertEncoder.forward."""
+                hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks, need="both", lang_rows=None):
+        """`need`, `lang_rows` (not in the reference's signature; defaults = its behaviour): "lang" / "visn" when the caller reads only the
+        text output / only the history + observation outputs; the text rows it reads -- see LxmertEncoder.forward.  With `lang_rows` the
+        text output is [R, H] (2-D) unless HAMT_NO_DCE=1, in which case it is the full [B, L, H]: callers check `dim()`."""
         B = txt_ids.size(0)
         txt_m = self._extend(txt_masks)
         hist_m = self._extend(hist_masks)
@@ -643,10 +664,10 @@ class NavPreTrainedModel(BertPreTrainedModel):
             streams.join(main, side)
             streams.share(hist, main)
             streams.share(ob, main)
-            return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True, need=need)
+            return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True, need=need, lang_rows=lang_rows)
         txt = self._text(txt_ids, txt_m, keep_packed=True)
         hist, ob = vision_side()
-        return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True, need=need)
+        return self.encoder(txt, txt_m, hist, hist_m, ob, ob_m, text_done=True, need=need, lang_rows=lang_rows)
 
     def forward_itm(self, txt_ids, txt_masks, hist_img_feats, hist_ang_feats, hist_pano_img_feats, hist_pano_ang_feats,
                     hist_masks, num_neg_trajs=4, neg_idxs=None, shuffled_pos_ids=None):
@@ -731,7 +752,17 @@ class NavPreTrainedModel(BertPreTrainedModel):
             txt, txt_m = text_side()
             vis, vis_m = vision_side(neg_idxs, shuffled_pos_ids)
         H = txt.shape[-1]
-        for layer in self.encoder.x_layers:
+        xl = self.encoder.x_layers
+        if DEAD_SIDE_ELIMINATION and len(xl) > 0:
+            # only the [CLS] rows of both outputs are read: the last layer's feed-forward blocks run on those rows (LXRTXLayer.forward)
+            for layer in xl[:-1]:
+                txt, vis = layer(txt, txt_m, vis, vis_m)
+            lang_rows = cls_rows[0] if cls_rows[0] is not None else ops.const_index("arange_mul", int(n_rep * B), int(txt.shape[1]), device=dev)
+            visn_rows = ops.const_index("arange_mul", int(vis.shape[0]), int(vis.shape[1]), device=dev)
+            cls, vis0 = xl[-1](txt, txt_m, vis, vis_m, lang_rows=lang_rows, visn_rows=visn_rows)
+            fused = ops.mul_bcast(cls.view(n_rep * B, 1, H), vis0)
+            return fused.view(n_rep, B, H).transpose(0, 1)
+        for layer in xl:
             txt, vis = layer(txt, txt_m, vis, vis_m)
         cls = ops.gather_rows(txt, cls_rows[0]).view(n_rep * B, 1, H) if cls_rows[0] is not None else txt[:, :1].contiguous()
         fused = ops.mul_bcast(cls, vis[:, 0])                            # txt[:,0] * hist[:,0]
