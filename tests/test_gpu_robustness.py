@@ -317,6 +317,43 @@ def test_unzeroed_weight_gradient_slots_do_not_leak(tiny, monkeypatch):
     assert o1.update_bytes() < o0.update_bytes() == 34.0 * float(o0._ends[-1])
 
 
+def test_clip_without_an_optimizer_argument_binds_only_to_the_exact_parameter_set(tiny):
+    """The reference's call is clip_grad_norm_(model.parameters(), n) (main_r2r.py:271-273): no optimizer.  The fused path (scale
+    applied inside optimizer.step()) is taken only when the list IS the optimizer's parameter set, by identity: a subset, a list
+    with one parameter twice (same length as the set minus one plus a duplicate), or another model's tensors must be clipped in
+    place over exactly the listed gradients, as torch does."""
+    from vln_hamt_amd.optim import clip_grad_norm_
+    from vln_hamt_amd.synth import make_batch
+    _, cfg, sd = tiny
+    b = make_batch("sap", 4, cfg, seed=71, txt_len=20, hist_len=4, device=DEV)
+    m, o = _model_opt(cfg, sd)
+    o.materialize()
+    m(b, "sap", True).mean().backward()
+    ps = [p for p in m.parameters()]
+    full = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ps if p.grad is not None)))
+    # the exact set: deferred (gradients untouched, scale pending)
+    got = float(clip_grad_norm_(ps, 1e-3))
+    assert abs(got - full) <= 1e-5 * full and o._pending_clip is not None
+    o._pending_clip = None
+    # one parameter replaced by a duplicate of another: same length, not the set -> generic path, in place, norm over the LIST
+    with_grad = [p for p in ps if p.grad is not None]
+    dup = list(ps)
+    dup[ps.index(with_grad[0])] = with_grad[1]
+    want = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in dup if p.grad is not None)))
+    before = with_grad[1].grad.detach().clone()
+    got = float(clip_grad_norm_(dup, 1e30))          # (no scaling at this max_norm: the list's own norm comes back, nothing pending)
+    assert abs(got - want) <= 1e-5 * want and o._pending_clip is None, (got, want)
+    assert torch.equal(before, with_grad[1].grad)
+    # a subset: in place over the subset only
+    sub = with_grad[:5]
+    want = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sub)))
+    keep = with_grad[7].grad.detach().clone()
+    got = float(clip_grad_norm_(sub, 0.5 * want))
+    assert abs(got - want) <= 1e-5 * want and o._pending_clip is None
+    after = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sub)))
+    assert abs(after - 0.5 * want) <= 1e-4 * want and torch.equal(keep, with_grad[7].grad), (after, want)
+
+
 def test_gradient_norm_tracks_gradients_changed_after_the_pass(tiny):
     """The weight-gradient launch leaves each tile's sum of squares for the clip (hamt_wgrad_desc.ss) so that the norm does not
     read the gradients back -- valid only while the gradients are what that launch wrote.  Accumulating a second micro-batch,

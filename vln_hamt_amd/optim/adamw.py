@@ -581,8 +581,11 @@ class AdamW(Optimizer):
 
 def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, optimizer: AdamW = None) -> torch.Tensor:
     """torch.nn.utils.clip_grad_norm_ (main_r2r.py:271-273) on the GPU: returns the total L2 norm (device tensor,
-    no host sync).  With `optimizer` (our AdamW) the scaling min(1, max_norm/(norm+1e-6)) is fused into the
-    next ``optimizer.step()``; without it the gradients are scaled in place."""
+    no host sync).  With `optimizer` (our AdamW; found through the parameters when the call names none, as the reference's
+    does, and the list is exactly that optimizer's parameter set) the scaling min(1, max_norm/(norm+1e-6)) is DEFERRED: it is
+    applied inside the next ``optimizer.step()`` -- `.grad` still holds the unscaled gradients after this call (torch scales
+    them in place; code that reads `.grad` between the clip and the step sees the difference, the update does not).  Without
+    an optimizer the gradients are scaled in place."""
     lib = L.load()
     if optimizer is None:
         # the reference's call has no optimizer argument (main_r2r.py:271-273): parameters that live in an AdamW arena name it
@@ -592,8 +595,12 @@ def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, optimiz
             if r is not None:
                 optimizer = r()
                 break
-        if optimizer is not None and not (optimizer._built and len(parameters) == len(optimizer._params)):
-            optimizer = None           # a subset of the optimizer's parameters: the generic path below
+        # the fused path clips EXACTLY the optimizer's parameters: the caller's list must be that set (by identity, not by count -- a list of
+        # the same length holding another model's tensors, or one parameter twice, takes the generic path below)
+        if optimizer is not None and not (optimizer._built and len(parameters) == len(optimizer._params)
+                                          and all(id(p) in optimizer._index_of for p in parameters)
+                                          and len({id(p) for p in parameters}) == len(parameters)):
+            optimizer = None
     if optimizer is not None:
         sync = optimizer._sharded_sync
         if sync is not None and sync._unconsumed:      # reduce-scattered gradients: the norm over the owned chunks, one 4-byte all-reduce
