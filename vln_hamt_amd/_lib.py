@@ -148,6 +148,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HamtError(f"{LIB_PATH} is missing: build it with `python vln_hamt_amd/csrc/build.py` "
                         "(there is no CPU/PyTorch fallback for the HAMT kernels)")
+    # Load order: PyTorch-ROCm ships its own libamdhip64 (torch/lib); libhamt_hip.so is linked against the soname and binds to whichever
+    # runtime is already in the process.  Loaded BEFORE torch it pulls in /opt/rocm's build, torch then loads its own, and the process holds
+    # two HIP runtimes -- the second never sees the device ("no ROCm-capable device is detected" at the first launch).  The host side of
+    # this library is PyTorch's memory and streams anyway: make sure its runtime is the one.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
