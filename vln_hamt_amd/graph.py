@@ -62,11 +62,10 @@ class GraphedTrainStep:
         # ONE dedicated stream for warm-up and for every capture: autograd's per-parameter AccumulateGrad nodes remember
         # the stream they were created on; if a later capture ran on a different stream their accumulation kernels
         # would execute outside the capture (run once, never replayed).
-        # HAMT_MAIN_PRIORITY=1 (measurement switch): the capture stream -- the text-side critical path -- at high priority, so that
-        # the second compute stream's kernels only take what it leaves.  Measured: 16.4 ms per B = 64 step instead of 9.9 (a
-        # non-default priority on EITHER stream costs 60 %: the two streams no longer overlap) -- off
+        # Default priority (a high-priority capture stream -- the text-side critical path -- was measured: 16.4 ms per B = 64 step
+        # instead of 9.9; a non-default priority on EITHER compute stream stops the two from overlapping inside a replay).
         # (one capture stream per process: see streams.role_stream -- it must never coincide with the second compute stream or an update stream)
-        self.stream = streams.role_stream(torch.cuda.current_device(), "capture", -1 if os.environ.get("HAMT_MAIN_PRIORITY") == "1" else None)
+        self.stream = streams.role_stream(torch.cuda.current_device(), "capture")
         # (the warm-up step before each capture runs on that stream while the parameters' AccumulateGrad nodes may date
         # from an earlier pass on the caller's stream: intended, and synchronised by wait_stream on both sides)
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
