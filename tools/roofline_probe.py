@@ -213,12 +213,12 @@ def kernel_table(model, opt, cycle, device, live=True):
     nbytes = opt.update_bytes()       # 30 B per element (+ 4 where the gradient slot is zeroed too)
     if adam["s"] > 0:
         dl, bl = adam["s"], adam["bytes"]
-        rows.append({"kernel": "adamw_table_kernel<4, true, false>", "bound": "hbm", "per_step_ms": round(dl * 1e3, 3), "launches_per_step": 1.0,
+        rows.append({"kernel": "adamw_table_kernel<4>", "bound": "hbm", "per_step_ms": round(dl * 1e3, 3), "launches_per_step": 1.0,
                      "avg_launch_us": round(dl * 1e6, 2), "achieved": round(bl / dl / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
                      "frac": round(bl / dl / 1e9 / PEAK_HBM_GBS, 4), "work_per_launch": bl,
                      "back_to_back_ms_per_step": round(dt * 1e3, 3), "back_to_back_achieved": round(nbytes / dt / 1e9, 1)})
     else:
-        rows.append({"kernel": "adamw_table_kernel<4, true, false>", "bound": "hbm", "per_step_ms": round(dt * 1e3, 3), "launches_per_step": 1.0,
+        rows.append({"kernel": "adamw_table_kernel<4>", "bound": "hbm", "per_step_ms": round(dt * 1e3, 3), "launches_per_step": 1.0,
                      "avg_launch_us": round(dt * 1e6, 2), "achieved": round(nbytes / dt / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
                      "frac": round(nbytes / dt / 1e9 / PEAK_HBM_GBS, 4), "work_per_launch": nbytes})
     opt._packed = False
