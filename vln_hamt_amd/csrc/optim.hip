@@ -249,21 +249,26 @@ __global__ __launch_bounds__(256) void sumsq_table_balanced_kernel(size_t n, con
 __global__ __launch_bounds__(256) void unpack_sumsq_partial_kernel(size_t n, const bf16_t* __restrict__ y, float* __restrict__ g,
                                                                    const int* __restrict__ ends, const float4* __restrict__ hyp, int nparams,
                                                                    size_t first4, float* __restrict__ ws) {
+  // (16-KiB chunks b, b + gridDim, ...: the blocks sweep the range together, see adamw_table_kernel)
   const size_t n4 = n >> 2;
-  const size_t per_block = (n4 + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * per_block, hi = min(n4, lo + per_block);
-  int pi = 0;
-  {
-    int a = 0, b = nparams - 1;
-    const long e0 = (long)(lo + first4) * 4;
-    while (a < b) { const int mid = (a + b) >> 1; if ((long)ends[mid] > e0) b = mid; else a = mid + 1; }
-    pi = a;
-  }
+  constexpr size_t CH = 256 * 4;
   float s = 0.f;
-  for (size_t seg = lo; seg < hi; ++pi) {
-    const size_t pend = pi < nparams - 1 ? min(hi, ((size_t)ends[pi] >> 2) - first4) : hi;
-    const bool act = hyp[pi].w != 0.f && hyp[pi].w != 3.f;
-    for (size_t i = seg + threadIdx.x; i < pend; i += 256 * 4) {
+  int pi = -1;
+  for (size_t lo = (size_t)blockIdx.x * CH; lo < n4; lo += (size_t)gridDim.x * CH) {
+    const size_t hi = min(n4, lo + CH);
+    const long e0 = (long)(lo + first4) * 4;
+    if (pi < 0) {
+      int a = 0, b = nparams - 1;
+      while (a < b) { const int mid = (a + b) >> 1; if ((long)ends[mid] > e0) b = mid; else a = mid + 1; }
+      pi = a;
+    } else {
+      while (pi < nparams - 1 && (long)ends[pi] <= e0) ++pi;
+    }
+    int k = pi;
+    for (size_t seg = lo; seg < hi; ++k) {
+      const size_t pend = k < nparams - 1 ? min(hi, ((size_t)ends[k] >> 2) - first4) : hi;
+      const bool act = hyp[k].w != 0.f && hyp[k].w != 3.f;
+      const size_t i = seg + threadIdx.x;
       uint2 u[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) u[q] = i + (size_t)q * 256 < pend ? ((const uint2*)y)[i + (size_t)q * 256] : make_uint2(0u, 0u);
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(256) void unpack_sumsq_partial_kernel(size_t n, con
           if (act) s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
       }
+      seg = pend;
     }
-    seg = pend;
   }
   __shared__ float red[4];
   s = wave_sum(s);
