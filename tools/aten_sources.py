@@ -10,7 +10,7 @@ from bench import build_model
 from vln_hamt_amd.optim import AdamW, clip_grad_norm_
 from vln_hamt_amd.synth import make_batch, make_itm_rng
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VIEW = ("view", "reshape", "expand", "slice", "select", "t.default", "transpose", "unsqueeze", "squeeze", "detach", "alias", "as_strided",
+VIEW = ("view", "reshape", "expand", "slice", "select", "aten.t.default", "transpose", "unsqueeze", "squeeze", "detach", "alias", "as_strided",
         "_unsafe_view", "permute", "empty", "_local_scalar", "is_", "size", "stride", "record_stream", "narrow", "unbind", "split", "chunk", "lift", "set_")
 
 
