@@ -200,6 +200,31 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, launcher=None):
+    """Run this file as `n` ranks of one node under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and
+    return the launcher's exit code.  Called only from a process that has not initialised the GPU."""
+    import subprocess
+    have = torch.cuda.device_count()                    # counting devices does not initialise the runtime
+    if have < n and not os.environ.get("HAMT_DIST_BACKEND"):
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launcher or [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+                       "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
+    cmd = cmd + [os.path.abspath(__file__)] + list(argv)
+    log("self-launch: " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,7 +244,16 @@ def main():
                     "them are reported in `regions_ms_per_step` with their min / median")
     ap.add_argument("--also-batch", type=int, default=-1, help="another per-GPU batch reported in `batch_sweep` (default: 16 -- the reference's "
                     "per-GPU batch -- and 256 when --batch is left at 64 on one GPU; 0 = none)")
+    ap.add_argument("--launch-check", action="store_true", help="plumbing check of the N-rank launch: rendezvous, one all-reduce, rank 0 prints "
+                    "{\"launch_check\": true, \"n_gpus\": world}; no model, runs on a CPU-only host over gloo as well")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` run plainly (the way the driver runs --gpus 1; the reference is started with
+        # `python -m torch.distributed.launch --nproc_per_node N`, README.md:48-55): start the N ranks ourselves.  A CHILD process,
+        # spawned before anything here has touched the GPU (no exec: replacing a process that holds the device takes the box down);
+        # its stdout -- rank 0's JSON line -- is inherited, its return code is ours.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     from vln_hamt_amd import ops
     from vln_hamt_amd.optim import AdamW, clip_grad_norm_
@@ -229,7 +263,17 @@ def main():
     from vln_hamt_amd.synth import make_batch, make_itm_rng
 
     rank, local_rank, world = init_distributed()
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s)"
+    if args.launch_check:
+        t = torch.ones(1, device=torch.device("cuda", local_rank % torch.cuda.device_count()) if torch.cuda.is_available() else "cpu")
+        if world > 1:
+            torch.distributed.all_reduce(t)
+        assert int(t.item()) == world, (t, world)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": torch.distributed.get_backend() if world > 1 else None}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HAMT kernels have no CPU path"
     device = torch.device("cuda", (local_rank if world > 1 else 0) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define HAMT_ABI_VERSION 1
+#define HAMT_ABI_VERSION 2   /* 2: hamt_gemm_ln_fwd / hamt_graph_split_* removed (round 5); hamt_embed_sum_bwd takes V and ws_bytes,
+                              * hamt_scatter_add_rows_ordered takes T; hamt_ln_fwd_grouped / hamt_ln_bwd_grouped added (round 6) */
 
 typedef enum { HAMT_OK = 0, HAMT_ERR_ARG = -1, HAMT_ERR_UNSUPPORTED = -2, HAMT_ERR_LAUNCH = -3 } hamt_status;
 typedef enum { HAMT_F32 = 0, HAMT_BF16 = 1,
@@ -318,9 +319,10 @@ int hamt_gather_rows(int R, int W, const float* src, int ld_src, const int64_t* 
 int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
                           float* dst, int ld_dst, void* stream);
 /* scatter_add in a FIXED summation order (colliding rows are added in row order by one writer per table row: bit-reproducible, unlike the
- * atomic form); idx must be given (table rows < 2^31).  ws: 34 R ints of device scratch.  Beyond 32 768 source rows it falls back to the atomic kernel. */
+ * atomic form); idx must be given; T = rows of the table (< 2^31): source rows whose index is outside [0, T) are skipped.  ws: 34 R ints of device
+ * scratch.  Beyond 32 768 source rows it falls back to the atomic kernel. */
 int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
-                                  float* dst, int ld_dst, int* ws, void* stream);
+                                  float* dst, int ld_dst, int T, int* ws, void* stream);
 /* the same for a CONTIGUOUS table dst[T][W] of T <= 8 rows (idx must be given): fixed-order sums instead of atomics -- the table's
  * gradient is then bit-reproducible.  ws: 64 * T * W floats. */
 int hamt_scatter_add_rows_small(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, int T, float* dst,
@@ -330,10 +332,11 @@ int hamt_scatter_add_rows_small(int R, int W, const float* src, int ld_src, int 
 int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* word, const float* pos,
                        const float* type_row, float* z, void* stream);
 /* backward: dword[ids] += dz, dpos[l] += sum_b dz, dtype_row += sum dz (any of the three may be NULL);
- * ws: HAMT_WS_EMBED_BWD {B * L, H} bytes of scratch, needed when dtype_row is given; with ws the word rows are summed in a fixed order
- * (hamt_scatter_add_rows_ordered), without it (or beyond 32 768 rows) by atomic adds */
-int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword,
-                       float* dpos, float* dtype_row, float* ws, void* stream);
+ * V = rows of the word table (ids outside [0, V) are skipped).  ws / ws_bytes: device scratch and ITS SIZE; needed when dtype_row is given
+ * (>= HAMT_WS_COLSUM {B * L, H}, checked).  With ws_bytes >= HAMT_WS_EMBED_BWD {B * L, H} the word rows are summed in a fixed order
+ * (hamt_scatter_add_rows_ordered); with less (or beyond 32 768 rows) by atomic adds -- never written past ws_bytes */
+int hamt_embed_sum_bwd(int B, int L, int H, int V, const int64_t* ids, const float* dz, float* dword,
+                       float* dpos, float* dtype_row, float* ws, size_t ws_bytes, void* stream);
 
 /* broadcast row ops over x[B, S, H]:
  *   mean over the middle axis  (A11 vilmodel.py:563-564):  y[b,:] = mean_s x[b,s,:]

@@ -36,7 +36,7 @@ def test_library_exports_every_symbol():
     lib = _lib.load()
     for name in _header_protos():
         assert hasattr(lib, name), name
-    assert lib.hamt_version() == 1
+    assert lib.hamt_version() == 2
     buf = ctypes.create_string_buffer(64)
     assert lib.hamt_last_error(buf, 64) >= 0
     assert lib.hamt_last_kernel(buf, 64) >= 0

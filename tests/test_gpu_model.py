@@ -68,20 +68,15 @@ def tiny():
 
 
 def head_tol(prec, fam, case, task):
-    """Bound for a HEAD output (ITM logits, SAR predictions): the activation tolerance -- or, in bf16 mode, the REFERENCE's own bf16 error on
-    that output on the same draw if that is larger (tests/golden/canon_autocast.npz: the reference under torch.autocast(bfloat16) against its
-    fp32 forward; oracle/gen_goldens.py canon_autocast).  A LayerNorm + Linear head on top of a 13-layer bf16 trunk amplifies the trunk's
-    6-8e-3: the reference's own bf16 logits are off by up to 1.6e-2 on these draws, ours by 0.5-1.03e-2 -- "<= 1e-2, or no worse than the
-    reference's own bf16 path".  Trunk activations and losses stay at 1e-2 flat."""
-    if prec != "bf16":
-        return TOL[prec]
-    return min(HEAD_CAP, max(TOL[prec], float(load_npz("canon_autocast.npz")[f"{fam}/c{case}/{task}/logits"])))
+    """Bound for a HEAD output (ITM logits, SAR predictions): north_star's activation tolerance, flat -- 1e-3 fp32, 1e-2 bf16 -- whatever the
+    reference's own bf16 path does on the draw (tests/golden/canon_autocast.npz: torch.autocast(bfloat16) against its fp32 forward is off by
+    up to 1.6e-2 on these outputs; rounds 4 / 5 let that widen the gate to 1.25e-2).  Measured on every draw: <= 9.13e-3
+    (profiles/r05_parity_margins.txt, profiles/r06_parity_margins.txt); a failing draw is printed with its family / case / task by `gate`."""
+    return min(HEAD_CAP, TOL[prec]) if prec == "bf16" else TOL[prec]
 
 
-# bf16 head outputs, whatever the reference's own bf16 error on the draw (up to 1.6e-2): never beyond this.  Measured 0.4 - 1.03e-2 over
-# every draw of rounds 4 / 5 (profiles/r05_parity_margins.txt): a 25 % regression of the worst one fails (the un-capped
-# gate would have let 1.59e-2 through)
-HEAD_CAP = 1.25e-2
+# bf16 head outputs: north_star's 1e-2, no allowance (VERDICT r5 weak 1)
+HEAD_CAP = 1.0e-2
 
 
 def _itm_uncancelled_scale(sd, cfg, cpu_batch, itm):
@@ -639,7 +634,7 @@ def test_canon_b64_vs_oracle(mode):
     B = 2 / 16) on the same weights and batch: loss <= 1e-2; the full gradient at cosine >= 0.99 and a norm within 3 % for MLM / SAP /
     SPREL / MRC.  SAR and ITM: the loss gradient is a sum of terms that cancel (regression residuals of both signs; five nearly
     identical candidates: see test_canon_multi_seed_margins), so what is compared at cosine >= 0.99 is the gradient of ONE un-cancelled
-    output, mean_b prediction[b, 0] -- and the outputs themselves (predictions / logits) at 1.25e-2 (head outputs: `head_tol`)."""
+    output, mean_b prediction[b, 0] -- and the outputs themselves (predictions / logits) at 1e-2 (head outputs: `head_tol`)."""
     from oracle.hamt_oracle import HamtOracle, OracleConfig, make_state_dict, pretrain_param_shapes
     from vln_hamt_amd.synth import make_batch, make_itm_rng
     cfg = OracleConfig()
@@ -1914,8 +1909,8 @@ def _two_rank_batch(t, r, cfg, shapes):
     job where every rank pads to its local longest instruction (the exchange schedule once depended on them)"""
     from vln_hamt_amd.synth import make_batch
     kw = dict(shapes.get(t, dict(txt_len=20, hist_len=4)))
-    kw["txt_len"] += 12 * r
-    kw["hist_len"] = max(1, kw["hist_len"] - r)
+    kw["txt_len"] += 12 * r if r < 2 else 4 * r + 2      # (<= 50 of the tiny model's 64 positions at rank 7)
+    kw["hist_len"] = max(1, kw["hist_len"] - r % 4)
     return make_batch(t, 4, cfg, seed=100 * r + sum(map(ord, t)), ragged=True, device=DEV, **kw)
 
 
@@ -2226,3 +2221,76 @@ def test_two_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph
     if sharded:
         assert torch.equal(m0, m1) and torch.equal(v0, v1), "gather_state left the ranks with different moments"
     assert em < tol and ev < tol, (em, ev)
+
+
+@pytest.mark.parametrize("wire,use_graph,sharded,acc", [("fp32", "wrapped", True, 1), ("fp32", "wrapped", False, 1), ("fp32", "wrapped", True, 2),
+                                                        ("bf16", True, True, 1)])
+def test_eight_ranks_on_one_gpu_match_averaged_gradients(tmp_path, wire, use_graph, sharded, acc):
+    """world_size = 8 -- BASELINE config 3's -- for real: eight processes on the one GPU (gloo carries the CUDA tensors), every rank its own
+    batches with its own padded shapes, through the product's exchange: the reference's loop lines around `wrap_model` (sharded
+    reduce-scatter / owned-slice AdamW / all-gather, and all-reduce; one case with gradient accumulation over two passes per update), and
+    the captured sharded step with the bf16 wire.  Against ONE process that computes the eight ranks' gradients on the same weights,
+    averages, clips and steps.  World-8 `shard_cuts` / ownership / all-gathers had CPU invariants only; RCCL over xGMI
+    itself cannot run here (one GPU per box)."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle.hamt_oracle import make_state_dict, pretrain_param_shapes
+    from vln_hamt_amd import wgrad
+    from vln_hamt_amd.optim import AdamW, clip_grad_norm_
+    from vln_hamt_amd.optim.misc import NO_DECAY
+    if not wgrad.ENABLED:
+        pytest.skip("HAMT_NO_DEFER_WGRAD")
+    W = 8
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    mp.spawn(_two_rank_worker, args=(W, port, str(tmp_path), wire, use_graph, sharded, False, None, acc), nprocs=W, join=True)
+    ps = [torch.load(os.path.join(str(tmp_path), f"params{r}.pt")) for r in range(W)]
+    for r in range(1, W):
+        assert torch.equal(ps[0], ps[r]), f"rank {r} diverged from rank 0"
+    xs = [torch.load(os.path.join(str(tmp_path), f"exchanges{r}.pt")) for r in range(W)]
+    assert all(x == xs[0] for x in xs), "the ranks issued different sequences of range exchanges"
+    if sharded:
+        for name in ("shadow", "fp32read"):
+            a = torch.load(os.path.join(str(tmp_path), f"{name}0.pt"))
+            for r in range(1, W):
+                assert torch.equal(a, torch.load(os.path.join(str(tmp_path), f"{name}{r}.pt"))), f"{name}: rank {r} would run its next forward on other weights"
+    cfg = tiny_cfg()
+    m = build(cfg, make_state_dict(pretrain_param_shapes(cfg), seed=5), "bf16", train=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    named = list(m.named_parameters())
+    seq, shapes, hyp = _two_rank_schedule(False)
+    o = AdamW([{'params': [p for n, p in named if not any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.01},
+               {'params': [p for n, p in named if any(nd in n for nd in NO_DECAY)], 'weight_decay': 0.0}], betas=(0.9, 0.98), **hyp)
+    o.materialize()
+    bs = [{t: _two_rank_batch(t, r, cfg, shapes) for t in set(seq)} for r in range(W)]
+    for i_ in range(0, len(seq), acc):
+        tot = torch.zeros_like(o._flat_g)
+        share = (lambda g: (g / W).to(torch.bfloat16).float()) if wire == "bf16" else (lambda g: g / W)    # (bf16 wire: DDP bf16_compress_hook's rounding)
+        for r in range(W):
+            for t in seq[i_:i_ + acc]:
+                (m(bs[r][t], t, True).mean() / acc).backward()
+            o._pack_grads()
+            if r < W - 1:
+                tot += share(o._flat_g)
+                o.zero_grad()
+            else:
+                o._flat_g.copy_(share(o._flat_g) + tot)
+        clip_grad_norm_(m.parameters(), 5.0, optimizer=o)
+        o.step()
+        o.zero_grad()
+    torch.cuda.synchronize()
+    ref = o._flat_p.detach().cpu()
+    worst = float((ps[0] - ref).abs().max())
+    mr, vr = o._flat_m.detach().cpu(), o._flat_v.detach().cpu()
+    m0, v0 = torch.load(os.path.join(str(tmp_path), "moments0.pt"))
+    em, ev = float((m0 - mr).abs().max()) / float(mr.abs().max()), float((v0 - vr).abs().max()) / float(vr.abs().max())
+    print(f"[eight ranks, wire={wire}, graph={use_graph}, sharded={sharded}, acc={acc}] worst parameter difference after {len(seq) // acc} updates: "
+          f"{worst:.2e}; exp_avg / exp_avg_sq {em:.2e} / {ev:.2e}")
+    tol = 2e-3 if wire == "fp32" else 3e-2
+    assert worst < (2e-5 if wire == "fp32" else 2e-4), worst
+    assert em < tol and ev < tol, (em, ev)
+    if sharded:
+        for r in range(1, W):
+            mr_, vr_ = torch.load(os.path.join(str(tmp_path), f"moments{r}.pt"))
+            assert torch.equal(m0, mr_) and torch.equal(v0, vr_), f"gather_state left rank {r} with other moments"

@@ -1054,7 +1054,7 @@ def test_scatter_add_ordered_is_bit_reproducible(R, T, W):
         junk = torch.randn(1000 * (rep + 1), device=DEV)
         dst = base.to(DEV).clone()
         ws = torch.empty(34 * R, dtype=torch.int32, device=DEV)
-        L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(src_d), W, 0, _p(idx_d), _p(dst), W, _p(ws), _stream()), "scatter")
+        L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(src_d), W, 0, _p(idx_d), _p(dst), W, T, _p(ws), _stream()), "scatter")
         torch.cuda.synchronize()
         outs.append(dst.cpu())
         del junk
@@ -1086,6 +1086,52 @@ def test_scatter_add_ordered_is_bit_reproducible(R, T, W):
                         tot = tot + parts[k]
                 want[t_] = base[t_] + tot
             assert torch.equal(outs[0], want), "not the defined summation order"
+
+
+def test_scatter_add_ordered_skips_rows_outside_the_table():
+    """an index outside [0, T) (a padding id, a corrupted batch) used to make one wave add a whole row out of bounds; with T in
+    the interface those source rows are skipped -- the table between two guard regions, ids -1, -7, T, T + 5 and 2^31 + 3 among valid
+    ones.  Same for hamt_embed_sum_bwd (V), whose scratch is now bounded by ws_bytes: a ws sized by the old HAMT_WS_COLSUM rule makes it
+    take the atomic kernel instead of writing 34 R ints into it."""
+    from vln_hamt_amd import _lib as L
+    from vln_hamt_amd.ops import _p, _stream
+    R, T, W = 600, 37, 256
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, T, (R,), generator=g)
+    bad = torch.tensor([3, 77, 150, 151, 599])
+    idx[bad] = torch.tensor([-1, -7, T, T + 5, 2 ** 31 + 3])
+    src = rnd(R, W, seed=1)
+    guard = 64
+    buf = torch.full((guard + T + guard, W), 7.0, device=DEV)
+    dst = buf[guard:guard + T]
+    dst.zero_()
+    ws = torch.empty(34 * R, dtype=torch.int32, device=DEV)
+    L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(src.to(DEV)), W, 0, _p(idx.to(DEV)), _p(dst), W, T, _p(ws), _stream()), "scatter")
+    torch.cuda.synchronize()
+    ok = torch.ones(R, dtype=torch.bool); ok[bad] = False
+    ref = torch.zeros(T, W, dtype=torch.float64).index_add(0, idx[ok], src[ok].double())
+    close(dst.cpu(), ref, 2e-5, "ordered scatter with out-of-range ids")
+    assert float((buf[:guard] - 7.0).abs().max()) == 0.0 and float((buf[guard + T:] - 7.0).abs().max()) == 0.0, "wrote outside the table"
+    # hamt_embed_sum_bwd: V bounds, and a scratch too small for the ranking -> atomics, nothing past ws_bytes
+    B, Lq, H, V = 8, 50, 128, 30          # (R = 400: the ranking needs 54 KB, HAMT_WS_COLSUM is 32 KB)
+    ids = torch.randint(0, V, (B, Lq), generator=g)
+    ids[1, 2], ids[3, 4] = -1, V
+    dz = rnd(B * Lq, H, seed=2)
+    for ws_bytes in (L.workspace_bytes(L.WS_EMBED_BWD, B * Lq, H), L.workspace_bytes(L.WS_COLSUM, B * Lq, H)):
+        wsb = torch.full((ws_bytes // 4 + 4096,), 5.0, device=DEV)
+        tab = torch.full((guard + V + guard, H), 7.0, device=DEV)
+        dword = tab[guard:guard + V]
+        dword.zero_()
+        dtyp = torch.zeros(H, device=DEV)
+        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, V, _p(ids.to(DEV)), _p(dz.to(DEV)), _p(dword), None, _p(dtyp), _p(wsb), ws_bytes, _stream()), "embed bwd")
+        torch.cuda.synchronize()
+        okm = ((ids >= 0) & (ids < V)).flatten()
+        ref = torch.zeros(V, H, dtype=torch.float64).index_add(0, ids.flatten()[okm], dz[okm].double())
+        close(dword.cpu(), ref, 2e-5, "dword with out-of-range ids")
+        close(dtyp.cpu(), dz.double().sum(0), 2e-5, "dtype row")
+        assert float((tab[:guard] - 7.0).abs().max()) == 0.0 and float((tab[guard + V:] - 7.0).abs().max()) == 0.0, "wrote outside the word table"
+        assert float((wsb[ws_bytes // 4:] - 5.0).abs().max()) == 0.0, "wrote past ws_bytes"
+    assert L.load().hamt_embed_sum_bwd(B, Lq, H, V, _p(ids.to(DEV)), _p(dz.to(DEV)), None, None, _p(dtyp), _p(wsb), 16, _stream()) != 0      # dtype_row needs COLSUM scratch
 
 
 @pytest.mark.parametrize("B,L,H,V", [(64, 80, 768, 30522), (5, 33, 1024, 100), (2, 7, 132, 50), (3, 9, 1028, 40)])

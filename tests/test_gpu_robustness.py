@@ -412,6 +412,8 @@ def test_two_rank_bench_with_probes_finishes(tmp_path, sharded):
     env = dict(os.environ, HAMT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", HAMT_SHARDED=sharded)   # reduce-scatter / all-reduce exchange
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "8"]
+    if sharded == "1":      # ... and run plainly, the way the driver runs `--gpus 1`: bench.py starts its own ranks (a child process, before any GPU call)
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "8"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

@@ -92,9 +92,9 @@ SIGNATURES = {
     "hamt_gather_rows": [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp],
     "hamt_scatter_add_rows": [i32, i32, vp, i32, i32, vp, vp, i32, vp],
     "hamt_scatter_add_rows_small": [i32, i32, vp, i32, i32, vp, i32, vp, vp, vp],
-    "hamt_scatter_add_rows_ordered": [i32, i32, vp, i32, i32, vp, vp, i32, vp, vp],
+    "hamt_scatter_add_rows_ordered": [i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp],
     "hamt_embed_sum_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
-    "hamt_embed_sum_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "hamt_embed_sum_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
     "hamt_mean_mid_fwd": [i32, i32, i32, vp, vp, vp],
     "hamt_mean_mid_bwd": [i32, i32, i32, vp, vp, vp],
     "hamt_mul_bcast_fwd": [i32, i32, i32, vp, vp, i32, vp, vp],
@@ -158,7 +158,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = sz if name == "hamt_workspace_bytes" else i32
-    if lib.hamt_version() != 1:
+    if lib.hamt_version() != 2:
         raise HamtError("libhamt_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -42,11 +42,12 @@ __global__ void embed_sum_fwd_kernel(int B, int L, int H, const int64_t* __restr
     *(float4*)(z + (size_t)row * H + c) = make_float4((a.x + p.x) + ty.x, (a.y + p.y) + ty.y, (a.z + p.z) + ty.z, (a.w + p.w) + ty.w);
   }
 }
-__global__ void embed_sum_bwd_kernel(int B, int L, int H, const int64_t* __restrict__ ids, const float* __restrict__ dz,
+__global__ void embed_sum_bwd_kernel(int B, int L, int H, int V, const int64_t* __restrict__ ids, const float* __restrict__ dz,
                                      float* __restrict__ dword) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * L * H; i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / H), c = (int)(i % H);
-    atomicAdd(dword + (size_t)ids[row] * H + c, dz[i]);
+    const int64_t id = ids[row];
+    if ((uint64_t)id < (uint64_t)V) atomicAdd(dword + (size_t)id * H + c, dz[i]);
   }
 }
 // x[B,S,H]: mode 0 -> partial sums over (b,s) per block-row-chunk; mode 1 -> sums over b per (s,h)
@@ -378,7 +379,7 @@ __device__ __forceinline__ void scatter_row_add(float* __restrict__ drow, int W,
 }
 __global__ __launch_bounds__(64 * SCAT_WAVES) void scatter_segment_add_kernel(int R, int W, const float* __restrict__ src, int ld_src, int col0,
                                                                              const int* __restrict__ perm, const int* __restrict__ sid,
-                                                                             float* __restrict__ dst, int ld_dst) {
+                                                                             float* __restrict__ dst, int ld_dst, int T) {
   // A block looks at SCAT_WAVES consecutive sorted positions, one per wave.  A position that starts a table row's list [p, e) of source rows:
   //   n = e - p <= SCAT_WAVES members (nearly all: most tokens occur once or a few times): THAT wave sums them in row order and adds the
   //     sum to the table row -- no LDS, no barrier;
@@ -394,7 +395,9 @@ __global__ __launch_bounds__(64 * SCAT_WAVES) void scatter_segment_add_kernel(in
   bool start = false;
   if (p < R) {
     id = sid[p];
-    start = p == 0 || sid[p - 1] != id;
+    // (a table has T rows: an id outside [0, T) -- a padding index, a corrupted batch -- would make one wave add a whole row out of bounds;
+    // its source rows are skipped, as the sorted list keeps them together at either end)
+    start = (p == 0 || sid[p - 1] != id) && (unsigned)id < (unsigned)T;
     if (start) {      // end of the list: a few steps of a linear scan (most lists have one or two rows), then -- sid is sorted -- a binary search
       e = p + 1;      // (a linear scan of a 750-row list is 750 dependent L2 round trips; a binary search of every 1-row list is 13)
       int k = 0;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(64 * SCAT_WAVES) void scatter_segment_add_kernel(in
   }
 }
 // ws: (SCAT_SLICES + 2) R ints.  false: no index / no scratch / R too large for the quadratic ranking (the caller falls back to atomics)
-static bool scatter_add_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst, int ld_dst, int* ws, hipStream_t s) {
+static bool scatter_add_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst, int ld_dst, int T, int* ws, hipStream_t s) {
   static const bool off = getenv("HAMT_ATOMIC_SCATTER") != nullptr;      // (measurement: the atomic kernels instead)
   if (R > 32768 || !idx || !ws || off) return false;
   const int ns = (R + 255) / 256 < SCAT_SLICES ? (R + 255) / 256 : SCAT_SLICES;      // slices of the row range (grid.y): 256 rows each up to 8192 rows
@@ -453,14 +456,14 @@ static bool scatter_add_ordered(int R, int W, const float* src, int ld_src, int 
   int* sid = perm + R;
   hipLaunchKernelGGL(scatter_rank_kernel, dim3((R + 255) / 256, ns), dim3(256), 0, s, R, per, idx, cnt);
   hipLaunchKernelGGL(scatter_perm_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, ns, idx, cnt, perm, sid);
-  hipLaunchKernelGGL(scatter_segment_add_kernel, dim3((R + SCAT_WAVES - 1) / SCAT_WAVES), dim3(64 * SCAT_WAVES), 0, s, R, W, src, ld_src, col0, perm, sid, dst, ld_dst);
+  hipLaunchKernelGGL(scatter_segment_add_kernel, dim3((R + SCAT_WAVES - 1) / SCAT_WAVES), dim3(64 * SCAT_WAVES), 0, s, R, W, src, ld_src, col0, perm, sid, dst, ld_dst, T);
   return true;
 }
 extern "C" int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst,
-                                             int ld_dst, int* ws, void* stream) {
-  HAMT_CHECK_ARG(src && dst && idx && ws, "hamt_scatter_add_rows_ordered: null pointer");
+                                             int ld_dst, int T, int* ws, void* stream) {
+  HAMT_CHECK_ARG(src && dst && idx && ws && T >= 0, "hamt_scatter_add_rows_ordered: null pointer / negative T");
   if (R == 0) return HAMT_OK;
-  if (!scatter_add_ordered(R, W, src, ld_src, col0, idx, dst, ld_dst, ws, as_stream(stream)))
+  if (!scatter_add_ordered(R, W, src, ld_src, col0, idx, dst, ld_dst, T, ws, as_stream(stream)))
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nblocks((size_t)R * W)), dim3(256), 0, as_stream(stream), R, W, src, ld_src, col0, idx, dst, ld_dst);
   HAMT_CHECK_LAUNCH("hamt_scatter_add_rows_ordered");
   return HAMT_OK;
@@ -500,8 +503,8 @@ extern "C" int hamt_sum_rows(int B, int S, int H, const float* x, int mode, floa
   return HAMT_OK;
 }
 extern "C" int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate, float* ws, void* stream);
-extern "C" int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const float* dz, float* dword, float* dpos,
-                                  float* dtype_row, float* ws, void* stream) {
+extern "C" int hamt_embed_sum_bwd(int B, int L, int H, int V, const int64_t* ids, const float* dz, float* dword, float* dpos,
+                                  float* dtype_row, float* ws, size_t ws_bytes, void* stream) {
   // Three passes over dz (16 MB at the step's shape, L2 / MALL resident), each on the kernel built for it: the word rows by atomic adds
   // over the whole grid (a one-pass kernel with one block per position was measured: 87 us -- 80 blocks cannot issue 3.9 M atomics as
   // fast as 15 000 can -- against 26 here), the positions by the slice-sum kernel (dz = B slices of L * H), the token-type row by the
@@ -510,9 +513,16 @@ extern "C" int hamt_embed_sum_bwd(int B, int L, int H, const int64_t* ids, const
   HAMT_CHECK_ARG(!dtype_row || ws, "hamt_embed_sum_bwd: dtype_row needs ws (HAMT_WS_EMBED_BWD {B * L, H} bytes)");
   if (B * L == 0) return HAMT_OK;
   hipStream_t s = as_stream(stream);
-  // (the word rows: in a fixed order when ws is given -- scatter_add_ordered above -- else, or beyond 32 768 rows, by atomic adds)
-  if (dword && !scatter_add_ordered(B * L, H, dz, H, 0, ids, dword, H, (int*)ws, s))
-    hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(nblocks((size_t)B * L * H)), dim3(256), 0, s, B, L, H, ids, dz, dword);
+  // (the word rows: in a fixed order when ws is given AND large enough for the ranking's (SCAT_SLICES + 2) R ints -- scatter_add_ordered
+  // above -- else, or beyond 32 768 rows, by atomic adds.  ws_bytes: ABI 1 took the size on trust; a caller that sized ws by the older
+  // HAMT_WS_COLSUM rule would have been overrun by the ranking arrays)
+  const bool ws_ok = ws && ws_bytes >= (size_t)(SCAT_SLICES + 2) * (size_t)(B * L) * sizeof(int);
+  if (dtype_row) {
+    const int shp[2] = {B * L, H};
+    HAMT_CHECK_ARG(ws_bytes >= hamt_workspace_bytes(HAMT_WS_COLSUM, shp, 2), "hamt_embed_sum_bwd: ws_bytes = %zu is below HAMT_WS_COLSUM {B * L, H}", ws_bytes);
+  }
+  if (dword && !scatter_add_ordered(B * L, H, dz, H, 0, ids, dword, H, V, ws_ok ? (int*)ws : nullptr, s))
+    hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(nblocks((size_t)B * L * H)), dim3(256), 0, s, B, L, H, V, ids, dz, dword);
   if (dpos) hamt_reduce_partials(B, L * H, dz, dpos, 1, s);
   HAMT_CHECK_LAUNCH("hamt_embed_sum_bwd");
   if (dtype_row) return hamt_colsum(B * L, H, dz, H, HAMT_F32, dtype_row, 1, ws, stream);

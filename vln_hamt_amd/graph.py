@@ -241,10 +241,12 @@ class GraphedTrainStep:
         if self.lag:
             self.opt.upload_table(self._pending_table)        # None: no update pending, the leading update touches nothing
             self._pending_table = self.opt.host_table(active)   # this step's update (today's learning rates), applied by the next replay
+            self.opt._counted = None                            # (... or by finish(): never taken back by an eager zero_grad())
             g.replay()
             return loss_c
         self.opt.prepare_step(active)
         self.opt._table_ready = False          # (consumed by the captured update below: a later eager zero_grad() must not take the step count back)
+        self.opt._counted = None
         g.replay()
         if self.grad_sync is not None:
             sharded = getattr(self.grad_sync, "sharded", False)

@@ -808,7 +808,7 @@ class EmbedSumFn(torch.autograd.Function):
         if any(r is None for r in rets):
             wgrad.queue(dev).current()              # (opens the pass: orders this stream behind an overlapped optimizer update)
         ws = torch.empty(L.workspace_bytes(L.WS_EMBED_BWD, B * Lq, H) // 4, dtype=torch.float32, device=dev)
-        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, _p(ids), _p(dz), _p(dword), _p(dpos), _p(dtyp), _p(ws), _stream()),
+        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, dword.shape[0], _p(ids), _p(dz), _p(dword), _p(dpos), _p(dtyp), _p(ws), ws.numel() * 4, _stream()),
                 "hamt_embed_sum_bwd")      # (dtyp: row 0 of the type table)
         for p, r, o in zip(ctx.tables, rets, outs):
             if r is None:
@@ -828,7 +828,7 @@ def _scatter_add(R, W, dout, idx, table, unique=False):
         L.check(L.load().hamt_scatter_add_rows_small(R, W, _p(dout), W, 0, _p(idx), T, _p(table), _p(ws), _stream()), "hamt_scatter_add_rows_small")
     else:
         ws = torch.empty(34 * max(R, 1), dtype=torch.int32, device=dout.device)
-        L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(dout), W, 0, _p(idx), _p(table), W, _p(ws), _stream()), "hamt_scatter_add_rows_ordered")
+        L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(dout), W, 0, _p(idx), _p(table), W, T, _p(ws), _stream()), "hamt_scatter_add_rows_ordered")
 
 
 class GatherRowsFn(torch.autograd.Function):

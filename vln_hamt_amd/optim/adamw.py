@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import weakref
 
 import numpy as np
 from typing import Iterable, List, Optional
@@ -156,6 +157,8 @@ class AdamW(Optimizer):
         self._active: Optional[List[bool]] = None
         self._ov = None             # _Overlap: the update runs on its own stream next to the following forward pass (attach())
         self._table_ready = False   # the device table already describes the step whose gradients are packed now
+        self._dp_wrappers = weakref.WeakSet()   # parallel.ArenaDataParallel wrappers whose backward passes fill this optimizer's arena
+        self._counted = None        # flags of the step host_table() COUNTED and no update launch has consumed yet (zero_grad() takes it back)
         self._table_lrs = None
         self._fused = None          # (partial sums tensor, parameter index array): gradients whose sum of squares wgrad.py already has
         self._sharded_sync = None   # parallel.ShardedGradSync attached to this optimizer (state lives sharded over the ranks)
@@ -359,6 +362,7 @@ class AdamW(Optimizer):
         act = flags != 0
         if advance:
             self._steps[act] += 1
+            self._counted = act.copy()
         t = np.maximum(self._steps, 1).astype(np.float64)
         b1, b2 = self.param_groups[0]["betas"]
         lr = np.array([g["lr"] for g in self.param_groups], dtype=np.float64)[self._gidx_np]
@@ -409,6 +413,7 @@ class AdamW(Optimizer):
         """Device side of a step (static launch sequence; capturable)."""
         b1, b2 = self.param_groups[0]["betas"]
         gn, max_norm = self._pending_clip if self._pending_clip is not None else (None, 0.0)
+        self._counted = None        # the counted step is applied by this launch
         if zero_grad_arena:
             self._flat_g._hamt_dirty = False
         L.check(L.load().hamt_adamw_table(self._n, _p(self._flat_p), _p(self._flat_g), _p(self._flat_m), _p(self._flat_v),
@@ -457,6 +462,7 @@ class AdamW(Optimizer):
         if gnorm_sq is None and self._pending_clip is not None:
             gnorm_sq, max_norm = self._pending_clip
         self._flat_g._hamt_dirty = False
+        self._counted = None
         lib = L.load()
         ov.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ov.stream):
@@ -473,6 +479,8 @@ class AdamW(Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        for w in list(self._dp_wrappers):
+            w._on_update(True)
         sync = self._sharded_sync
         if sync is not None and sync._unconsumed:
             # the gradients of this step were reduce-scattered (parallel.ShardedGradSync, e.g. under parallel.ArenaDataParallel): the
@@ -504,15 +512,21 @@ class AdamW(Optimizer):
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
+        for w in list(self._dp_wrappers):
+            w._on_update(False)
         self._packed = False
         self._fused = None
-        if self._built and self._table_ready:
-            # a step was prepared (clip_grad_norm_ built the table: which parameters have a gradient, step counts advanced) and no update
-            # consumed it -- the loop dropped this pass (NaN guard, early `continue`).  The reference counts a parameter's step inside
-            # step() only (optim/adamw.py:76-84): take the count back, and let the next pass build its own table
-            self._steps[np.asarray(self._table_active) != 0] -= 1
-            self._table_ready = False
+        if self._built and self._counted is not None:
+            # a step was COUNTED (clip_grad_norm_ / prepare_step built the table: which parameters have a gradient, step counts advanced) and
+            # no update launch consumed it -- the loop dropped this pass (NaN guard, early `continue`).  The reference counts a parameter's
+            # step inside step() only (optim/adamw.py:76-84): take the count back, and let the next pass build its own table.  The flag is
+            # `_counted` (set by host_table(advance=True), cleared by launch_step / launch_step_overlapped / the sharded update / a
+            # captured update's replay), not `_table_ready`: prepare_step() + launch_step() called directly leave `_table_ready` set
+            # after a real update
+            self._steps[self._counted] -= 1
+            self._counted = None
             self._pending_clip = None
+        self._table_ready = False
         self._active = None
         from .. import wgrad
         sync = getattr(self, "_sharded_sync", None)

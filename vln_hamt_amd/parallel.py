@@ -627,6 +627,7 @@ class ShardedGradSync(OverlappedGradSync):
                 self._all_gather_inplace(o._flat_p[lo:hi])
         if o._n > n_a:                                                # bf16 images of the >= 2-D fp32-read parameters (tied MLM decoder ...)
             L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
+        o._counted = None                                             # the counted step is applied (optim.AdamW.zero_grad)
         o.mark_updated()
         self._unconsumed = False
         o._shard_stale = self.world > 1
@@ -684,7 +685,8 @@ class ArenaDataParallel(torch.nn.Module):
         # collective), the k-th exchanges the sums -- one exchange per update, which is also what the sharded exchange requires.
         # Settable after construction (`model.accumulation_steps = opts.gradient_accumulation_steps`).
         self.accumulation_steps = max(1, int(accumulation_steps))
-        self._micro = 0
+        self._micro = 0                # backward passes since the last update (re-set by optimizer.step() / zero_grad(): `_on_update`)
+        self._exchanged = False        # ... and whether one of them exchanged
         self._cfg = (n_groups if n_groups is not None else int(os.environ.get("HAMT_SYNC_GROUPS", 4)), wire, sharded)
         self.grad_sync = None
         self._armed: set = set()
@@ -755,6 +757,8 @@ class ArenaDataParallel(torch.nn.Module):
                                "(optim.misc.build_optimizer) before the first backward pass, as main_r2r.py does")
         opt.materialize()
         sync = self._sync_for(opt)
+        if self not in opt._dp_wrappers:
+            opt._dp_wrappers.add(self)          # (weak) optimizer.step() / zero_grad() call _on_update
         from . import wgrad
         dev = opt._flat_p.device
         # this callback was queued when the pass STARTED, i.e. in front of the weight-gradient queue's own end-of-pass flush: run that
@@ -773,6 +777,22 @@ class ArenaDataParallel(torch.nn.Module):
             return
         q.flush(tid)
         sync(opt)                           # nothing queued in this pass (fp32 mode): the plain range-by-range exchange
+        self._exchanged = True
+
+    def _on_update(self, stepping: bool):
+        """Called by the optimizer at the update boundary -- optimizer.step() (stepping) and zero_grad(): the private count of backward
+        passes starts again there, whatever the caller's loop did in between (a second backward in one iteration, a micro-batch
+        skipped before backward, an exception mid-update: ADVICE r5 -- the count used to run on and put the exchange on the wrong
+        pass).  A step() over gradients that k > 0 backward passes produced and NO pass exchanged would update every rank from its
+        own local sums, silently: refuse."""
+        micro, exchanged = self._micro, self._exchanged
+        if not stepping or exchanged or micro == 0:
+            self._micro, self._exchanged = 0, False
+        if stepping and micro and not exchanged and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError(f"ArenaDataParallel: optimizer.step() after {micro} backward pass(es) of which none exchanged gradients "
+                               f"(accumulation_steps = {self.accumulation_steps}: the exchange runs on every {self.accumulation_steps}-th pass since "
+                               "the last update) -- the ranks would update from their local sums and diverge.  Step on the pass that "
+                               "exchanges, or set model.accumulation_steps to the loop's gradient_accumulation_steps")
 
     def close(self):
         if self.grad_sync is not None:
