@@ -40,7 +40,12 @@ typedef enum { HAMT_F32 = 0, HAMT_BF16 = 1,
                 * whose range is [-0.129, 1.129], as code q in [0, 255] with value = 0.005 q - 0.13 (0 and 1 are exact: q = 26 / 226;
                 * |error| <= 0.0025, the size of bf16's rounding of values near 1).  Halves the bytes of the image the FFN-1 epilogue
                 * writes next to gelu(x) and the FFN-2 dgrad epilogue reads back (vilmodel.py:168-175 BertIntermediate backward). */
-               HAMT_U8G = 2 } hamt_dtype;
+               HAMT_U8G = 2,
+               /* IEEE half, for `C` of hamt_gemm (epilogue: none / HAMT_EPI_BIAS / HAMT_EPI_ACCUM) and for `x` / `z` of the LayerNorm family only: the output of a dense layer in front of a
+                * LayerNorm (vilmodel.py:139-143, 181-185) kept in two bytes with 10 mantissa bits instead of bf16's 7 -- the rounding of
+                * that interface is 8 x finer at the same HBM bytes (round 6: the bf16 head outputs at B = 64 drop from 1.03e-2 to
+                * ~6.5e-3 of the fp32 reference; dense outputs are O(1 .. 100), far inside half's range) */
+               HAMT_F16 = 3 } hamt_dtype;
 /* arithmetic of the contraction: bf16 MFMA operands with fp32 accumulate, or exact fp32 MFMA */
 typedef enum { HAMT_PREC_BF16 = 0, HAMT_PREC_F32 = 1 } hamt_prec;
 
@@ -172,6 +177,11 @@ typedef struct {
  * be captured in a hipGraph.  The table must stay untouched until the launches have run. */
 #define HAMT_WGRAD_TABLE_ENTRY 112
 int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream);
+/* The same in two phases, for callers that replay a FIXED set of problems (a captured training step): phase 1 writes the launch table
+ * (once: its content is a function of `probs` only), phase 2 launches the grouped kernels from a table a phase-1 call with the same
+ * `probs` has written, phase 3 = both = hamt_wgrad_grouped.  A replayed phase-2 launch has no one-workgroup table-write kernel in front
+ * of it: on a second stream such a kernel waited ~275 us behind the first stream's chip-filling tiles before it was dispatched. */
+int hamt_wgrad_grouped_ex(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, int phase, void* stream);
 
 /* column sums  out[n] (+)= sum_m x[m,n]   (bias gradients of every nn.Linear).  ws: >= 64*N floats */
 int hamt_colsum(int M, int N, const void* x, int ldx, int dtype_x, float* out, int accumulate,
@@ -270,10 +280,13 @@ typedef struct {
   int Mpad16; /* rows of the optional bf16 images (y16 / dx16); rows [M, Mpad16) are written as zeros (0: no padding) */
   int io16;   /* HAMT_LN_X_BF16: `x` is bf16 (the dense layer in front wrote bf16, as a linear does under autocast);
                * HAMT_LN_Z_BF16: the saved pre-LN sum `z` is stored / read as bf16 (backward re-normalises it with the exact
-               * fp32 mean / rstd).  0: both fp32. */
+               * fp32 mean / rstd).  HAMT_LN_X_F16 / HAMT_LN_Z_F16: the same two as IEEE half (HAMT_F16: same bytes, a rounding 8 x finer).
+               * 0: both fp32.  At most one flag per tensor. */
 } hamt_ln_desc;
 #define HAMT_LN_X_BF16 1
 #define HAMT_LN_Z_BF16 2
+#define HAMT_LN_X_F16 4
+#define HAMT_LN_Z_F16 8
 int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* residual, const float* gamma,
                 const float* beta, void* z, float* y, void* y16, float* mean, float* rstd,
                 const uint64_t* rng, void* stream);

@@ -1611,7 +1611,7 @@ class _GateChecker:
             v = orig(mod, name)
             if isinstance(v, torch.nn.Parameter):
                 for o in streams.pending_updates:
-                    if not o._ov.check_read(v):
+                    if not all(g.check_read(v) for g in o._gates()):
                         bad.append(f"{type(mod).__name__}.{name}")
             return v
         torch.nn.Module.__getattr__ = patched
@@ -1957,8 +1957,14 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
         o.zero_grad()
         o.step()                                     # main_r2r.py:229-230
         batches = {t: _two_rank_batch(t, rank, cfg, shapes) for t in set(seq)}
+        # sharded: the next forward runs under the parameters' all-gathers of the update (ShardedGradSync.attach_gather) -- every read of a
+        # parameter must sit on a stream that already waits for the range holding it (the read trap of the overlapped-update test)
+        chk = _GateChecker()
+        chk.__enter__()
+        gated_seen = False
         try:
             for i_, t in enumerate(seq):
+                gated_seen = gated_seen or bool(o._gather_ov is not None and o._gather_ov.pending)
                 loss = model(batches[t], task=t, compute_loss=True)
                 loss = loss.mean()
                 if acc > 1:                          # main_r2r.py:242-250
@@ -1970,6 +1976,9 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
                 if i_ != skip_at:                    # (skip_at: a loop that drops this pass -- NaN guard, early `continue` -- and only zeroes the gradients)
                     o.step()
                 o.zero_grad()
+            chk.__exit__()
+            assert not chk.bad, sorted(set(chk.bad))
+            assert gated_seen == bool(sharded), "sharded exchange: a forward pass must have started under pending all-gathers (and only then)"
             sync = model.grad_sync
             assert sync is not None and bool(getattr(sync, "sharded", False)) == bool(sharded), sync
             torch.cuda.synchronize()
@@ -1982,6 +1991,7 @@ def _two_rank_worker(rank, world, port, out_dir, wire, use_graph, sharded=False,
             torch.save(o._flat_p.detach().cpu(), os.path.join(out_dir, f"params{rank}.pt"))
             torch.save((o._flat_m.detach().cpu(), o._flat_v.detach().cpu()), os.path.join(out_dir, f"moments{rank}.pt"))
         finally:
+            chk.__exit__()
             model.close()
             dist.destroy_process_group()
         return

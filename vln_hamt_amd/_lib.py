@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamt_hip.so")
 
-HAMT_F32, HAMT_BF16, HAMT_U8G = 0, 1, 2
+HAMT_F32, HAMT_BF16, HAMT_U8G, HAMT_F16 = 0, 1, 2, 3
 PREC_BF16, PREC_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_ACCUM, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_SAVE_PRE = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_GRAD, EPI_MUL_AUX, EPI_ADD_AUX, EPI_DROPOUT = 128, 256, 512, 1024
@@ -41,7 +41,7 @@ class AttnDesc(C.Structure):
                 ("call_id", u32), ("prec", i32)]
 
 
-LN_X_BF16, LN_Z_BF16 = 1, 2      # hamt_ln_desc.io16
+LN_X_BF16, LN_Z_BF16, LN_X_F16, LN_Z_F16 = 1, 2, 4, 8      # hamt_ln_desc.io16
 
 
 class LnDesc(C.Structure):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "hamt_cast_pad_bf16_dropout": [i32, i32, i32, vp, i32, vp, i32, f32, u32, vp, vp],
     "hamt_cast_transpose": [i32, i32, vp, i32, i32, vp, i32, i32, vp],
     "hamt_wgrad_grouped": [i32, C.POINTER(WgradDesc), vp, sz, vp],
+    "hamt_wgrad_grouped_ex": [i32, C.POINTER(WgradDesc), vp, sz, i32, vp],
     "hamt_smallk_wgrad": [i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp],
     "hamt_colsum": [i32, i32, vp, i32, i32, vp, i32, vp, vp],
     "hamt_attn_small_fwd": [C.POINTER(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp],

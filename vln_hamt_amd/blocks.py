@@ -35,9 +35,13 @@ NO_PACKED = os.environ.get("HAMT_NO_PACKED") is not None      # ablation switche
 NO_SHADOW = os.environ.get("HAMT_NO_SHADOW") is not None
 
 
-# dtype of the dense outputs that feed a LayerNorm (attention output projection, second FFN layer): bf16 like every other dense
-# output of the bf16 path; HAMT_DENSE_OUT_F32=1 keeps them in fp32 (ablation: +4 bytes per element through GEMM epilogue + LayerNorm)
-O_DTYPE = torch.float32 if os.environ.get("HAMT_DENSE_OUT_F32") == "1" else torch.bfloat16
+# dtype of the dense outputs that feed a LayerNorm (attention output projection, second FFN layer): two bytes per element like every
+# other dense output of the bf16 path, but IEEE half, not bf16 -- the value is consumed once, by the LayerNorm, in fp32 (never an MFMA
+# operand), it is O(1 .. 100), and half's 10 mantissa bits make the rounding of this interface 8 x finer than bf16's 7 at the same HBM
+# bytes: the bf16-mode head outputs at B = 64 went from 0.99 / 1.03e-2 (SAR / ITM) to ~6e-3 of the fp32 reference (round 6; what fp32
+# outputs give at + 4 bytes per element: HAMT_DENSE_OUT_F32=1).  HAMT_DENSE_OUT_BF16=1: bf16 as before (what a linear returns under autocast)
+O_DTYPE = (torch.float32 if os.environ.get("HAMT_DENSE_OUT_F32") == "1" else
+           (torch.bfloat16 if os.environ.get("HAMT_DENSE_OUT_BF16") == "1" else torch.float16))
 
 
 # the saved gelu' image of the FFN blocks: one byte per element (hamt.h HAMT_U8G: 0.005 q - 0.13, |error| <= 0.0025 -- what bf16's rounding

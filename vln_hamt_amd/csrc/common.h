@@ -44,6 +44,19 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.0f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// ---- IEEE half <-> f32 (HAMT_F16: the 2-byte format of a dense layer's output in front of a LayerNorm -- 10 mantissa bits, a
+// rounding 8 x finer than bf16's at the same bytes; round to nearest even, v_cvt_f16_f32)
+typedef __attribute__((ext_vector_type(2))) _Float16 hamt_h2;
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  const hamt_h2 b = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ void unpack_h2(uint32_t w, float& lo, float& hi) {
+  const hamt_h2 b = __builtin_bit_cast(hamt_h2, w);
+  lo = (float)b[0]; hi = (float)b[1];
+}
+__device__ __forceinline__ bf16_t f2h(float f) { return (bf16_t)(pack_h2(f, 0.0f) & 0xffffu); }
+__device__ __forceinline__ float h2f(bf16_t h) { float a, b; unpack_h2((uint32_t)h, a, b); return a; }
 
 // ---- counter-based dropout RNG: 24-bit uniform from (seed, epoch, call_id, element index)
 __device__ __forceinline__ uint32_t hamt_mix32(uint32_t x) {

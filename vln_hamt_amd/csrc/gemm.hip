@@ -63,6 +63,10 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int row, int col, f
     bf16_t* c = (bf16_t*)g.C;
     if (g.epi & HAMT_EPI_ACCUM) v += bf2f(c[ic]);
     c[ic] = f2bf(v);
+  } else if (g.dtype_c == HAMT_F16) {
+    bf16_t* c = (bf16_t*)g.C;
+    if (g.epi & HAMT_EPI_ACCUM) v += h2f(c[ic]);
+    c[ic] = f2h(v);
   } else {
     float* c = (float*)g.C;
     if (g.epi & HAMT_EPI_ACCUM) v += c[ic];
@@ -455,6 +459,9 @@ extern "C" int hamt_gemm_ws(const hamt_gemm_desc* d, const void* A, const void* 
   const int sa = d->dtype_a == HAMT_BF16 ? 2 : 4, sb = d->dtype_b == HAMT_BF16 ? 2 : 4;
   HAMT_CHECK_ARG((d->lda * sa) % 16 == 0 && (d->ldb * sb) % 16 == 0, "hamt_gemm: lda/ldb rows must be 16-byte aligned (lda=%d ldb=%d)", d->lda, d->ldb);
   HAMT_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "hamt_gemm: A/B must be 16-byte aligned");
+  HAMT_CHECK_ARG(d->dtype_c == HAMT_F32 || d->dtype_c == HAMT_BF16 || d->dtype_c == HAMT_F16, "hamt_gemm: dtype_c = %d (C is fp32, bf16 or IEEE half)", d->dtype_c);
+  HAMT_CHECK_ARG(d->dtype_c != HAMT_F16 || (d->epilogue & ~(HAMT_EPI_BIAS | HAMT_EPI_ACCUM)) == 0, "hamt_gemm: an IEEE-half C (HAMT_F16) takes the plain / bias / accumulate epilogues only");
+  HAMT_CHECK_ARG((d->dtype_a == HAMT_F32 || d->dtype_a == HAMT_BF16) && (d->dtype_b == HAMT_F32 || d->dtype_b == HAMT_BF16), "hamt_gemm: operands are fp32 or bf16");
   HAMT_CHECK_ARG(!(d->epilogue & HAMT_EPI_BIAS) || bias, "hamt_gemm: EPI_BIAS without bias");
   HAMT_CHECK_ARG(!(d->epilogue & (HAMT_EPI_SAVE_PRE | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX | HAMT_EPI_ADD_AUX)) || aux, "hamt_gemm: epilogue needs aux");
   if (aux && d->dtype_aux == HAMT_U8G)

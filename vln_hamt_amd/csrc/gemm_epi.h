@@ -21,6 +21,29 @@ template <int W> __device__ __forceinline__ void st_bf(bf16_t* p, const float* v
   if constexpr (W == 8) *(uint4*)p = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
   else *(uint2*)p = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
 }
+// the same for a 2-byte C that is either bf16 or IEEE half (`f16`: wave uniform).  Both conversions are computed and one is selected
+// per pair (a v_cndmask on a scalar condition) -- a branch around each format kept both sets of temporaries alive across the general
+// epilogue and put 528 bytes of it into scratch (tests/test_kernel_resources.py)
+__device__ __forceinline__ uint32_t pack_16(float lo, float hi, bool f16) { return f16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); }
+__device__ __forceinline__ void unpack_16(uint32_t w, float& lo, float& hi, bool f16) {
+  float a, b;
+  unpack_h2(w, a, b);
+  lo = f16 ? a : __uint_as_float(w << 16);
+  hi = f16 ? b : __uint_as_float(w & 0xffff0000u);
+}
+template <int W> __device__ __forceinline__ void ld_16(const bf16_t* p, float* o, bool f16) {
+  if constexpr (W == 8) {
+    const uint4 u = *(const uint4*)p;
+    unpack_16(u.x, o[0], o[1], f16); unpack_16(u.y, o[2], o[3], f16); unpack_16(u.z, o[4], o[5], f16); unpack_16(u.w, o[6], o[7], f16);
+  } else {
+    const uint2 u = *(const uint2*)p;
+    unpack_16(u.x, o[0], o[1], f16); unpack_16(u.y, o[2], o[3], f16);
+  }
+}
+template <int W> __device__ __forceinline__ void st_16(bf16_t* p, const float* v, bool f16) {
+  if constexpr (W == 8) *(uint4*)p = make_uint4(pack_16(v[0], v[1], f16), pack_16(v[2], v[3], f16), pack_16(v[4], v[5], f16), pack_16(v[6], v[7], f16));
+  else *(uint2*)p = make_uint2(pack_16(v[0], v[1], f16), pack_16(v[2], v[3], f16));
+}
 template <int W> __device__ __forceinline__ void ld_f(const float* p, float* o) {
 #pragma unroll
   for (int q = 0; q < W / 4; ++q) { const float4 f = *(const float4*)(p + 4 * q); o[4 * q] = f.x; o[4 * q + 1] = f.y; o[4 * q + 2] = f.z; o[4 * q + 3] = f.w; }
@@ -53,14 +76,14 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
   const bool vaux = full && g.aux && (g.ldaux % W) == 0 && ((uintptr_t)g.aux % 16) == 0;
   const bool vc = full && (g.ldc % W) == 0 && ((uintptr_t)g.C % 16) == 0;
   if (epi & HAMT_EPI_BIAS) {
-    if (full && ((uintptr_t)g.bias % 16) == 0) { float b[W]; ld_f<W>(g.bias + col, b); for (int j = 0; j < W; ++j) v[j] += b[j]; }
-    else for (int j = 0; j < W; ++j) if (col + j < g.N) v[j] += g.bias[col + j];
+    if (full && ((uintptr_t)g.bias % 16) == 0) { float b[W]; ld_f<W>(g.bias + col, b); _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] += b[j]; }
+    else _Pragma("unroll") for (int j = 0; j < W; ++j) if (col + j < g.N) v[j] += g.bias[col + j];
   }
   if (epi & HAMT_EPI_SAVE_PRE) {
     if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, v); else st_f<W>((float*)g.aux + ia, v); }
-    else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(v[j]); else ((float*)g.aux)[ia + j] = v[j]; }
+    else _Pragma("unroll") for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(v[j]); else ((float*)g.aux)[ia + j] = v[j]; }
   }
-  if (epi & HAMT_EPI_GELU) { for (int j = 0; j < W; ++j) v[j] = gelu_erf(v[j]); }
+  if (epi & HAMT_EPI_GELU) { _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] = gelu_erf(v[j]); }
   float keep[W];
   if (epi & HAMT_EPI_DROPOUT) {   // col % 4 == 0: W / 4 groups of the row's mask stream
     const RngKey key = rng_key(g.rng, g.call_id);
@@ -70,22 +93,22 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
     for (int q = 0; q < W / 4; ++q) {
       float f[4];
       drop_scale4(key, rowh, (uint32_t)(col >> 2) + q, g.p_drop, inv_keep, f);
-      for (int j = 0; j < 4; ++j) keep[q * 4 + j] = f[j];
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) keep[q * 4 + j] = f[j];
     }
   }
   if (epi & HAMT_EPI_GELU_GRAD) {
     float dg[W];
-    for (int j = 0; j < W; ++j) gelu_and_grad(v[j], v[j], dg[j]);
-    if (epi & HAMT_EPI_DROPOUT) for (int j = 0; j < W; ++j) dg[j] *= keep[j];
+    _Pragma("unroll") for (int j = 0; j < W; ++j) gelu_and_grad(v[j], v[j], dg[j]);
+    if (epi & HAMT_EPI_DROPOUT) _Pragma("unroll") for (int j = 0; j < W; ++j) dg[j] *= keep[j];
     if (aux8) {
       uint8_t* a8 = (uint8_t*)g.aux + ia;
       if (vaux) { if constexpr (W == 8) *(uint2*)a8 = make_uint2(g8_pack4(dg), g8_pack4(dg + 4)); else *(uint32_t*)a8 = g8_pack4(dg); }
       else {
         const uint32_t w0 = g8_pack4(dg), w1 = W == 8 ? g8_pack4(dg + (W == 8 ? 4 : 0)) : 0u;
-        for (int j = 0; j < W; ++j) if (col + j < g.N) a8[j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xffu);
+        _Pragma("unroll") for (int j = 0; j < W; ++j) if (col + j < g.N) a8[j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xffu);
       }
     } else if (vaux) { if (aux16) st_bf<W>((bf16_t*)g.aux + ia, dg); else st_f<W>((float*)g.aux + ia, dg); }
-    else for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]); else ((float*)g.aux)[ia + j] = dg[j]; }
+    else _Pragma("unroll") for (int j = 0; j < W; ++j) if (col + j < g.N) { if (aux16) ((bf16_t*)g.aux)[ia + j] = f2bf(dg[j]); else ((float*)g.aux)[ia + j] = dg[j]; }
   }
   if (epi & (HAMT_EPI_MUL_AUX | HAMT_EPI_MUL_DGELU | HAMT_EPI_MUL_DRELU)) {
     float h[W];
@@ -101,38 +124,48 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
       if (vaux) {
         if constexpr (W == 8) { const uint2 u = *(const uint2*)a8; g8_unpack4(u.x, h); g8_unpack4(u.y, h + (W == 8 ? 4 : 0)); }
         else g8_unpack4(*(const uint32_t*)a8, h);
-      } else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? __builtin_fmaf((float)a8[j], 0.005f, -0.13f) : 0.f;
+      } else _Pragma("unroll") for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? __builtin_fmaf((float)a8[j], 0.005f, -0.13f) : 0.f;
     } else if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
-    else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
-    for (int j = 0; j < W; ++j)
+    else _Pragma("unroll") for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
+    _Pragma("unroll") for (int j = 0; j < W; ++j)
       v[j] *= (epi & HAMT_EPI_MUL_AUX) ? h[j] : ((epi & HAMT_EPI_MUL_DGELU) ? dgelu_erf(h[j]) : (h[j] > 0.0f ? 1.0f : 0.0f));
   }
-  if (epi & HAMT_EPI_RELU) { for (int j = 0; j < W; ++j) v[j] = fmaxf(v[j], 0.0f); }
-  if (epi & HAMT_EPI_DROPOUT) { for (int j = 0; j < W; ++j) v[j] *= keep[j]; }
+  if (epi & HAMT_EPI_RELU) { _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] = fmaxf(v[j], 0.0f); }
+  if (epi & HAMT_EPI_DROPOUT) { _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] *= keep[j]; }
   if (epi & HAMT_EPI_ADD_AUX) {   // residual add
     float h[W];
     if (vaux) { if (aux16) ld_bf<W>((const bf16_t*)g.aux + ia, h); else ld_f<W>((const float*)g.aux + ia, h); }
-    else for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
-    for (int j = 0; j < W; ++j) v[j] += h[j];
+    else _Pragma("unroll") for (int j = 0; j < W; ++j) h[j] = (col + j < g.N) ? (aux16 ? bf2f(((const bf16_t*)g.aux)[ia + j]) : ((const float*)g.aux)[ia + j]) : 0.f;
+    _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] += h[j];
   }
-  if (g.dtype_c == HAMT_BF16) {
+  if (g.dtype_c != HAMT_F32) {      // two bytes per element: bf16, or IEEE half (HAMT_F16)
+    // (half only behind a plain / bias / accumulate epilogue -- what hamt_gemm admits: the dense layer in front of a LayerNorm.  In the
+    // instantiations with the long epilogues the extra selects pushed a 32-fold unrolled loop over clang's pragma-unroll budget: the
+    // accumulators then went to scratch, tests/test_kernel_resources.py)
+    constexpr bool F16_OK = EPI < 0 || (EPI & ~(HAMT_EPI_BIAS | HAMT_EPI_ACCUM)) == 0;
+    const bool ch = F16_OK && g.dtype_c == HAMT_F16;
     bf16_t* c = (bf16_t*)g.C + ic;
     if (vc) {
-      if (epi & HAMT_EPI_ACCUM) { float p[W]; ld_bf<W>(c, p); for (int j = 0; j < W; ++j) v[j] += p[j]; }
-      st_bf<W>(c, v);
-    } else for (int j = 0; j < W; ++j) if (col + j < g.N) c[j] = f2bf((epi & HAMT_EPI_ACCUM) ? v[j] + bf2f(c[j]) : v[j]);
+      if (epi & HAMT_EPI_ACCUM) { float p[W]; ld_16<W>(c, p, ch); _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] += p[j]; }
+      st_16<W>(c, v, ch);
+    } else {
+      _Pragma("unroll") for (int j = 0; j < W; ++j) if (col + j < g.N) {       // (unrolled: a rolled loop indexes v[] dynamically, i.e. through scratch)
+        const float f = (epi & HAMT_EPI_ACCUM) ? v[j] + (ch ? h2f(c[j]) : bf2f(c[j])) : v[j];
+        c[j] = ch ? f2h(f) : f2bf(f);
+      }
+    }
   } else {
     float* c = (float*)g.C + ic;
     if (vc) {
       if (epi & HAMT_EPI_ACCUM) {
         float p[W];
-        if (W == 8 && pre_c && pre_ok) { for (int j = 0; j < 4; ++j) { p[j] = pre_c[0][j]; p[4 + j] = pre_c[1][j]; } }
+        if (W == 8 && pre_c && pre_ok) { _Pragma("unroll") for (int j = 0; j < 4; ++j) { p[j] = pre_c[0][j]; p[4 + j] = pre_c[1][j]; } }
         else ld_f<W>(c, p);
-        for (int j = 0; j < W; ++j) v[j] += p[j];
+        _Pragma("unroll") for (int j = 0; j < W; ++j) v[j] += p[j];
       }
       st_f<W>(c, v);
-      if (ssq) for (int j = 0; j < W; ++j) *ssq += v[j] * v[j];
-    } else for (int j = 0; j < W; ++j) if (col + j < g.N) {
+      if (ssq) _Pragma("unroll") for (int j = 0; j < W; ++j) *ssq += v[j] * v[j];
+    } else _Pragma("unroll") for (int j = 0; j < W; ++j) if (col + j < g.N) {
       const float f = (epi & HAMT_EPI_ACCUM) ? c[j] + v[j] : v[j];
       c[j] = f;
       if (ssq) *ssq += f * f;
@@ -180,9 +213,10 @@ __device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, 
   }
   const size_t ic = (size_t)row * g.ldc + col;
   if constexpr (C16) {
+    const bool ch = g.dtype_c == HAMT_F16;      // (kernel-argument compare: scalar, one branch per piece)
     bf16_t* c = (bf16_t*)g.C + ic;
-    if constexpr ((EPI & HAMT_EPI_ACCUM) != 0) { float p[8]; ld_bf<8>(c, p); for (int j = 0; j < 8; ++j) v[j] += p[j]; }
-    st_bf<8>(c, v);
+    if constexpr ((EPI & HAMT_EPI_ACCUM) != 0) { float p[8]; ld_16<8>(c, p, ch); for (int j = 0; j < 8; ++j) v[j] += p[j]; }
+    st_16<8>(c, v, ch);
   } else {
     float* c = (float*)g.C + ic;
     if constexpr ((EPI & HAMT_EPI_ACCUM) != 0) { float p[8]; ld_f<8>(c, p); for (int j = 0; j < 8; ++j) v[j] += p[j]; }

@@ -262,7 +262,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgsF& g, int m0, int n0, in
           if constexpr (PRE_AUX) epi_fast8<EPI, C16_>(g, m0 + rl, col, v8, b8, &pa[p]);                           \
           else epi_fast8<EPI, C16_>(g, m0 + rl, col, v8, b8, nullptr);                                            \
         }
-        if (g.dtype_c == HAMT_BF16) { HAMT_FAST_PIECES(true) } else { HAMT_FAST_PIECES(false) }
+        if (g.dtype_c != HAMT_F32) { HAMT_FAST_PIECES(true) } else { HAMT_FAST_PIECES(false) }
 #undef HAMT_FAST_PIECES
       }
     } else {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kg_kernel(GemmArgsF g) {
       }
     };
     using std::integral_constant;
-    const bool c16 = g.dtype_c == HAMT_BF16;
+    const bool c16 = g.dtype_c != HAMT_F32;
     if (fe == HAMT_EPI_BIAS) { if (c16) run(integral_constant<int, HAMT_EPI_BIAS>{}, std::true_type{}); else run(integral_constant<int, HAMT_EPI_BIAS>{}, std::false_type{}); }
     else if (fe == HAMT_EPI_ACCUM) { if (c16) run(integral_constant<int, HAMT_EPI_ACCUM>{}, std::true_type{}); else run(integral_constant<int, HAMT_EPI_ACCUM>{}, std::false_type{}); }
     else { if (c16) run(integral_constant<int, 0>{}, std::true_type{}); else run(integral_constant<int, 0>{}, std::false_type{}); }
@@ -891,7 +891,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgsF& g, int m0, int n0, floa
           }
         }
       };
-      if (g.dtype_c == HAMT_BF16) run(std::true_type{}); else run(std::false_type{});
+      if (g.dtype_c != HAMT_F32) run(std::true_type{}); else run(std::false_type{});
     }
   } else {
 #pragma unroll
@@ -1227,8 +1227,10 @@ extern "C" int hamt_debug_wgrad_times(float* us, int* tile_rows, double* flops, 
   return n;
 }
 
-extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream) {
-  HAMT_CHECK_ARG(n >= 0 && (n == 0 || probs), "hamt_wgrad_grouped: bad argument");
+// phase: 3 = write the launch table and launch (hamt_wgrad_grouped); 1 = write the table only; 2 = launch only (the table was written
+// by an earlier phase-1 call with the SAME problems: the host part -- classes, units, XCD queues, grid -- is recomputed, identical)
+static int wgrad_grouped_impl(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, int phase, void* stream) {
+  HAMT_CHECK_ARG(n >= 0 && (n == 0 || probs) && phase >= 1 && phase <= 3, "hamt_wgrad_grouped: bad argument");
   std::vector<int> order;
   for (int i = 0; i < n; ++i) {
     const hamt_wgrad_desc& d = probs[i];
@@ -1367,9 +1369,11 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     for (int b0 = 0; b0 < cn; b0 += WG_MAX) {
       WgradChunk ch;
       const int cnt = std::min(WG_MAX, cn - b0);
+      if (!(phase & 1)) break;
       for (int i = 0; i < cnt; ++i) ch.p[i] = flat[b0 + i];
       hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(WG_MAX), 0, s, ch, tab, off + b0, cnt);
     }
+    if (!(phase & 2)) { HAMT_CHECK_LAUNCH("hamt_wgrad_grouped (table)"); off += cn; continue; }
     const dim3 grid(8 * max_tiles);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (wgrad_timing_on) {     // measurement aid (hamt_debug_wgrad_timing): HIP events around the kernel, on its own stream
@@ -1385,4 +1389,10 @@ extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* tab
     off += cn;
   }
   return HAMT_OK;
+}
+extern "C" int hamt_wgrad_grouped(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, void* stream) {
+  return wgrad_grouped_impl(n, probs, table, table_bytes, 3, stream);
+}
+extern "C" int hamt_wgrad_grouped_ex(int n, const hamt_wgrad_desc* probs, void* table, size_t table_bytes, int phase, void* stream) {
+  return wgrad_grouped_impl(n, probs, table, table_bytes, phase, stream);
 }

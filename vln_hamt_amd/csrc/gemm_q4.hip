@@ -61,7 +61,7 @@ __device__ __forceinline__ void q4_store_tile(const GemmArgsF& g, const float* c
         epi_fast8<EPI, decltype(c16)::value>(g, m0 + rl, col, v8, b8, nullptr);
       }
     };
-    if (g.dtype_c == HAMT_BF16) run(std::true_type{}); else run(std::false_type{});
+    if (g.dtype_c != HAMT_F32) run(std::true_type{}); else run(std::false_type{});
   } else {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const void*
     if (c < H) {
       const size_t o = (size_t)row * H + c;
       float4 a;
-      if (d.io16 & HAMT_LN_X_BF16) {      // the dense layer in front wrote bf16 (what autocast does with a linear's output)
+      if (d.io16 & HAMT_LN_X_F16) {       // the dense layer in front wrote IEEE half (HAMT_F16)
+        const uint2 u = *(const uint2*)((const bf16_t*)xv + o);
+        unpack_h2(u.x, a.x, a.y); unpack_h2(u.y, a.z, a.w);
+      } else if (d.io16 & HAMT_LN_X_BF16) {      // the dense layer in front wrote bf16 (what autocast does with a linear's output)
         const uint2 u = *(const uint2*)((const bf16_t*)xv + o);
         a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
       } else a = *(const float4*)((const float*)xv + o);
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(hamt_ln_desc d, const void*
     if (c < H) {
       const size_t o = (size_t)row * H + c;
       if (zv) {
-        if (d.io16 & HAMT_LN_Z_BF16) *(uint2*)((bf16_t*)zv + o) = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
+        if (d.io16 & HAMT_LN_Z_F16) *(uint2*)((bf16_t*)zv + o) = make_uint2(pack_h2(v[i].x, v[i].y), pack_h2(v[i].z, v[i].w));
+        else if (d.io16 & HAMT_LN_Z_BF16) *(uint2*)((bf16_t*)zv + o) = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
         else *(float4*)((float*)zv + o) = v[i];
       }
       const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
@@ -131,7 +135,10 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(hamt_ln_desc d, const 
           a.x *= f_[0]; a.y *= f_[1]; a.z *= f_[2]; a.w *= f_[3];
         }
         float4 zz;
-        if (d.io16 & HAMT_LN_Z_BF16) {
+        if (d.io16 & HAMT_LN_Z_F16) {
+          const uint2 u = *(const uint2*)((const bf16_t*)zv + o);
+          unpack_h2(u.x, zz.x, zz.y); unpack_h2(u.y, zz.z, zz.w);
+        } else if (d.io16 & HAMT_LN_Z_BF16) {
           const uint2 u = *(const uint2*)((const bf16_t*)zv + o);
           zz = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
         } else zz = *(const float4*)((const float*)zv + o);
@@ -313,6 +320,8 @@ extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* re
   HAMT_CHECK_ARG(d && x && gamma && beta && (y || y16) && mean && rstd, "hamt_ln_fwd: null pointer");
   HAMT_CHECK_ARG(d->H % 4 == 0 && d->H >= 4 && d->H <= 1024, "hamt_ln_fwd: H=%d unsupported (need H%%4==0, H<=1024)", d->H);
   HAMT_CHECK_ARG(d->p_pre >= 0.f && d->p_pre < 1.f && d->p_post >= 0.f && d->p_post < 1.f, "hamt_ln_fwd: bad dropout p");
+  HAMT_CHECK_ARG((d->io16 & (HAMT_LN_X_BF16 | HAMT_LN_X_F16)) != (HAMT_LN_X_BF16 | HAMT_LN_X_F16) && (d->io16 & (HAMT_LN_Z_BF16 | HAMT_LN_Z_F16)) != (HAMT_LN_Z_BF16 | HAMT_LN_Z_F16),
+                 "hamt_ln_fwd: io16 = %d names two formats for one tensor", d->io16);
   if (d->M == 0) return HAMT_OK;
   const int nv = (d->H + 255) / 256;
   const int rows = (y16 && d->Mpad16 > d->M) ? d->Mpad16 : d->M;

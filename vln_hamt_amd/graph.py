@@ -184,9 +184,20 @@ class GraphedTrainStep:
                     if not n_:
                         plan.graphs.append(None)
                         continue
+                    # the group's launch table is a function of the plan alone (device pointers into the captured step's static
+                    # buffers and the arenas): written ONCE, here; the replayed graph is the grouped kernels only.  (With the
+                    # table-write kernel inside the graph, the second lane's one-workgroup write sat ~275 us behind the first
+                    # lane's chip-filling tiles before it was dispatched: DESIGN 6c)
+                    # The table is re-homed first: `plan.tables` were allocated DURING the capture, i.e. in the graph's private pool, where
+                    # a block may have been the temporary of an earlier node -- every replay of the step graph scribbles over it (harmless
+                    # while each group graph rewrote its table, an aperture violation in the grouped kernel once it did not)
+                    with torch.cuda.stream(side):
+                        plan.tables[gi] = torch.empty_like(plan.tables[gi])
+                        wgrad.launch_group(plan, gi, phase=1)
+                    side.synchronize()
                     gg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gg, pool=self.pool, stream=side, capture_error_mode=self.capture_mode):
-                        wgrad.launch_group(plan, gi)
+                        wgrad.launch_group(plan, gi, phase=2)
                     plan.graphs.append(gg)
             if getattr(self.grad_sync, "sharded", False) and os.environ.get("HAMT_NO_GROUP_GRAPHS") is None:
                 self.grad_sync.capture_update(self.max_norm, self.pool, side, self.capture_mode)

@@ -71,6 +71,8 @@ def _dt(t: torch.Tensor) -> int:
         return L.HAMT_F32
     if t.dtype == torch.bfloat16:
         return L.HAMT_BF16
+    if t.dtype == torch.float16:     # IEEE half: `C` of a dense layer in front of a LayerNorm (hamt.h: HAMT_F16) -- hamt_gemm refuses it elsewhere
+        return L.HAMT_F16
     if t.dtype == torch.uint8:       # the one-byte gelu' image (hamt.h: HAMT_U8G) -- `aux` of EPI_GELU_GRAD / EPI_MUL_AUX only
         return L.HAMT_U8G
     raise L.HamtError(f"unsupported dtype {t.dtype}")
@@ -550,21 +552,26 @@ def shadow16(x: torch.Tensor):
 LN_Z16 = os.environ.get("HAMT_LN_Z32") is None       # ablation: keep the saved pre-LN sum in fp32 behind a bf16 dense output as well
 
 
+def _ln_io(t, flag_bf16, flag_f16):
+    return flag_bf16 if t.dtype == torch.bfloat16 else (flag_f16 if t.dtype == torch.float16 else 0)
+
+
 def _ln_fwd(x2, r2, gamma, beta, eps, p_pre, p_post, want16):
     """`x2` may be bf16 (the fused blocks' dense outputs in bf16 mode: what a linear returns under autocast); the pre-LN sum
     saved for backward is then kept in bf16 too (backward re-normalises it with the exact fp32 mean / rstd): 14 instead of
     18 bytes per element through this kernel, 14 instead of 16 through its backward."""
     M, H = x2.shape
     dev = x2.device
-    x16_in = x2.dtype == torch.bfloat16
-    z = torch.empty(M, H, dtype=torch.bfloat16 if (x16_in and LN_Z16) else torch.float32, device=dev)
+    x16_in = x2.dtype in (torch.bfloat16, torch.float16)
+    # (the saved pre-LN sum takes the dense output's 2-byte format: half behind a half output -- |z| is O(1 .. 100) --, bf16 behind bf16)
+    z = torch.empty(M, H, dtype=x2.dtype if (x16_in and LN_Z16) else torch.float32, device=dev)
     y = torch.empty(M, H, dtype=torch.float32, device=dev)
     mean = torch.empty(M, dtype=torch.float32, device=dev)
     rstd = torch.empty(M, dtype=torch.float32, device=dev)
     Mp = _rup(M) if want16 else 0
     y16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want16 else None
     cid = next_call_id() if (p_pre > 0 or p_post > 0) else 0
-    d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp, (L.LN_X_BF16 if x16_in else 0) | (L.LN_Z_BF16 if z.dtype == torch.bfloat16 else 0))
+    d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp, _ln_io(x2, L.LN_X_BF16, L.LN_X_F16) | _ln_io(z, L.LN_Z_BF16, L.LN_Z_F16))
     L.check(L.load().hamt_ln_fwd(C.byref(d), _p(x2), _p(r2), _p(gamma), _p(beta), _p(z), _p(y), _p(y16),
                                  _p(mean), _p(rstd), _p(rng_state(dev)), _stream()), "hamt_ln_fwd")
     return y, y16, z, mean, rstd, cid
@@ -605,7 +612,7 @@ def _ln_bwd(dy2, z, mean, rstd, gamma, eps, p_pre, p_post, cid, want_dx32, want_
         dx16 = torch.empty(Mp, H, dtype=torch.bfloat16, device=dev) if want_dx16 else None
     red = torch.empty(3, H, dtype=torch.float32, device=dev)      # stored (not accumulated) by the reduce kernel
     ws = torch.empty(L.workspace_bytes(L.WS_LN_BWD, M, H) // 4, dtype=torch.float32, device=dev)
-    d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp, L.LN_Z_BF16 if z.dtype == torch.bfloat16 else 0)
+    d = L.LnDesc(M, H, float(eps), float(p_pre), float(p_post), cid, Mp, _ln_io(z, L.LN_Z_BF16, L.LN_Z_F16))
     defer = _can_defer_ln(params, dev, H)
     L.check(L.load().hamt_ln_bwd(C.byref(d), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dx16),
                                  None if defer else _p(red[0]), None if defer else _p(red[1]),

@@ -47,30 +47,34 @@ def shadow_only(p) -> bool:
 class _Overlap:
     """State of AdamW.attach(): the update stream, the chunk list with one event per chunk, the module hooks."""
 
-    def __init__(self, opt, model, chunk_elems):
+    def __init__(self, opt, model, chunk_elems, chunks=None, stream=None):
         self.opt, self.model = opt, model
         from .. import streams
-        self.stream = streams.role_stream(opt._flat_p.device, "update")      # (one stream per role and process: streams.role_stream)
+        self.stream = stream if stream is not None else streams.role_stream(opt._flat_p.device, "update")      # (one stream per role and process: streams.role_stream)
         # chunk 0: the fp32-read region (biases, LayerNorm, embedding tables: the first kernels of a forward pass read those);
         # then the GEMM-weight region in arena (= registration = use) order, cut at parameter boundaries
+        # (`chunks` given -- parallel.ShardedGradSync.attach_gather: the static exchange ranges in the order their all-gathers are
+        # issued on `stream`; they cut THROUGH parameters, so a parameter belongs to the last chunk that holds any of it)
         n_a, n = opt._n_shadow_only, opt._n
-        ends = [int(e) for e in opt._ends.tolist()]
-        chunks = [(n_a, n - n_a)] if n > n_a else []
-        lo = 0
-        for e in ends:
-            if e > n_a:
-                break
-            if e - lo >= chunk_elems:
-                chunks.append((lo, e - lo))
-                lo = e
-        if lo < n_a:
-            chunks.append((lo, n_a - lo))
+        if chunks is None:
+            ends = [int(e) for e in opt._ends.tolist()]
+            chunks = [(n_a, n - n_a)] if n > n_a else []
+            lo = 0
+            for e in ends:
+                if e > n_a:
+                    break
+                if e - lo >= chunk_elems:
+                    chunks.append((lo, e - lo))
+                    lo = e
+            if lo < n_a:
+                chunks.append((lo, n_a - lo))
         self.chunks = chunks
         self.events = [torch.cuda.Event() for _ in chunks]
         self.chunk_of = {}
         for p, o in zip(opt._params, opt._offs):
+            last = o + max(p.numel(), 1) - 1
             for i, (f, c) in enumerate(chunks):
-                if f <= o < f + c:
+                if f <= last < f + c:
                     self.chunk_of[id(p)] = i
                     break
         self.pending = False
@@ -139,6 +143,13 @@ class _Overlap:
     def _post(self, mod, args, out):
         self.opt.wait_update()
 
+    def mark_pending(self):
+        """the chunks' events have just been recorded on `stream` (in chunk order): gate every later parameter read behind them"""
+        from .. import streams
+        self.pending = True
+        self.waited.clear()
+        streams.pending_updates.add(self.opt)
+
 
 class AdamW(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
@@ -156,6 +167,7 @@ class AdamW(Optimizer):
         self._packed = False
         self._active: Optional[List[bool]] = None
         self._ov = None             # _Overlap: the update runs on its own stream next to the following forward pass (attach())
+        self._gather_ov = None      # _Overlap over the sharded exchange's ranges: the next forward is gated range by range behind the all-gathers
         self._table_ready = False   # the device table already describes the step whose gradients are packed now
         self._dp_wrappers = weakref.WeakSet()   # parallel.ArenaDataParallel wrappers whose backward passes fill this optimizer's arena
         self._counted = None        # flags of the step host_table() COUNTED and no update launch has consumed yet (zero_grad() takes it back)
@@ -446,13 +458,19 @@ class AdamW(Optimizer):
             self._ov.remove()
             self._ov = None
 
+    def _gates(self):
+        """the overlap objects whose events gate parameter reads: the update on its own stream (attach) and / or the parameters'
+        all-gathers of the sharded exchange on the communication stream (parallel.ShardedGradSync.attach_gather)"""
+        return [g for g in (self._ov, self._gather_ov) if g is not None]
+
     def wait_update(self):
-        """Order the current stream behind an update still running on the update stream (no-op otherwise)."""
-        ov = self._ov
-        if ov is not None and ov.pending:
-            torch.cuda.current_stream().wait_event(ov.events[-1])
-            ov.pending = False
-            streams.pending_updates.discard(self)
+        """Order the current stream behind an update still running on the update stream -- and behind the parameter all-gathers of the
+        sharded exchange still running on the communication stream (no-op otherwise)."""
+        for ov in self._gates():
+            if ov.pending:
+                torch.cuda.current_stream().wait_event(ov.events[-1])
+                ov.pending = False
+        streams.pending_updates.discard(self)
 
     def launch_step_overlapped(self, gnorm_sq=None, max_norm: float = 0.0):
         """launch_step on the update stream, one launch + one event per chunk (capturable: a fork of the capturing stream that

@@ -415,6 +415,28 @@ class ShardedGradSync(OverlappedGradSync):
         super().close()
         if getattr(self.opt, "_sharded_sync", None) is self:
             self.opt._sharded_sync = None
+        self.detach_gather()
+
+    def attach_gather(self, model: torch.nn.Module):
+        """Gate `model`'s next forward pass range by range behind the parameters' all-gathers of update() instead of making the
+        stream wait for all of them: forward pre-hooks on every module (optim.adamw._Overlap: the machinery of AdamW.attach, with
+        the static exchange ranges as its chunks and the communication stream as its stream).  Eager loops only; under graph replay
+        the all-gathers sit between the replays on the launching stream, as before."""
+        from .optim.adamw import _Overlap
+        o = self.opt
+        self.detach_gather()
+        n_a = o._n_shadow_only
+        tail = [(lo, hi - lo) for lo, hi in self._ranges if hi > n_a]
+        chunks = tail + [(lo, hi - lo) for lo, hi in self._ranges if hi <= n_a]
+        o._gather_ov = _Overlap(o, model, 0, chunks=chunks, stream=self.comm)
+        return self
+
+    def detach_gather(self):
+        gov = getattr(self.opt, "_gather_ov", None)
+        if gov is not None:
+            self.opt.wait_update()
+            gov.remove()
+            self.opt._gather_ov = None
 
     def _wire_spec(self):
         if not self.direct_wire:
@@ -605,6 +627,7 @@ class ShardedGradSync(OverlappedGradSync):
         from . import _lib as L
         from .ops import _p, _stream
         o, lib = self.opt, L.load()
+        o.wait_update()                    # (all-gathers of the previous update still on the communication stream: attach_gather)
         graphs = self._upd if (self._upd is not None and self._upd[2] == float(max_norm)) else None
         if have_sumsq or norm_reduced:
             pass
@@ -620,13 +643,32 @@ class ShardedGradSync(OverlappedGradSync):
         else:
             self._launch_adamw(max_norm)
         n_a = o._n_shadow_only
-        for lo, hi in self._ranges:
-            if hi <= n_a:
-                self._all_gather_inplace(o._flat_p16[lo:hi])         # GEMM weights: only their bf16 image is ever read
-            else:
-                self._all_gather_inplace(o._flat_p[lo:hi])
-        if o._n > n_a:                                                # bf16 images of the >= 2-D fp32-read parameters (tied MLM decoder ...)
-            L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
+        gov = o._gather_ov
+        if gov is not None and not torch.cuda.is_current_stream_capturing() and os.environ.get("HAMT_NO_GATHER_OVERLAP") is None:
+            # eager loop (parallel.ArenaDataParallel): the parameters' all-gathers run on the communication stream in the order a forward
+            # pass reads them -- the fp32-read region (embedding tables, biases, LayerNorm: the first kernels), then the GEMM-weight
+            # ranges in arena (= registration = use) order -- one event per range; the NEXT forward starts right away and every module
+            # waits for the range(s) that hold its parameters (attach_gather: optim.AdamW's pre-hook gates), instead of the whole
+            # forward waiting for ~350 MB of all-gather at world 8 (DDP overlaps the same way: utils/misc.py:57-58 + main_r2r.py:246)
+            cur = torch.cuda.current_stream()
+            self.comm.wait_stream(cur)
+            with torch.cuda.stream(self.comm):
+                for i, (f, c) in enumerate(gov.chunks):
+                    if f + c <= n_a:
+                        self._all_gather_inplace(o._flat_p16[f:f + c])
+                    else:
+                        self._all_gather_inplace(o._flat_p[f:f + c])
+                        L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
+                    gov.events[i].record(self.comm)
+            gov.mark_pending()
+        else:
+            for lo, hi in self._ranges:
+                if hi <= n_a:
+                    self._all_gather_inplace(o._flat_p16[lo:hi])         # GEMM weights: only their bf16 image is ever read
+                else:
+                    self._all_gather_inplace(o._flat_p[lo:hi])
+            if o._n > n_a:                                                # bf16 images of the >= 2-D fp32-read parameters (tied MLM decoder ...)
+                L.check(lib.hamt_cast_f32_bf16(o._n - n_a, _p(o._flat_p[n_a:]), _p(o._flat_p16[n_a:]), _stream()), "hamt_cast_f32_bf16")
         o._counted = None                                             # the counted step is applied (optim.AdamW.zero_grad)
         o.mark_updated()
         self._unconsumed = False
@@ -638,6 +680,7 @@ class ShardedGradSync(OverlappedGradSync):
         optimizer.state_dict() from one rank): make the fp32 masters of the GEMM-weight region and exp_avg / exp_avg_sq of the
         whole arena current on every rank."""
         o = self.opt
+        o.wait_update()
         for lo, hi in self._ranges:
             if hi <= o._n_shadow_only:
                 self._all_gather_inplace(o._flat_p[lo:hi])
@@ -721,6 +764,8 @@ class ArenaDataParallel(torch.nn.Module):
             prec = precision_of(cfg) if cfg is not None else "bf16"
             n_groups, wire, sharded = self._cfg
             self.grad_sync = make_grad_sync(opt, prec, n_groups=n_groups, wire=wire, sharded=sharded)
+            if getattr(self.grad_sync, "sharded", False) and os.environ.get("HAMT_NO_GATHER_OVERLAP") is None:
+                self.grad_sync.attach_gather(self.module)       # the next forward runs under the parameters' all-gathers
         return self.grad_sync
 
     def forward(self, *args, **kwargs):

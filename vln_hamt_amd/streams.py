@@ -93,14 +93,16 @@ def fork(main: torch.cuda.Stream, side: torch.cuda.Stream):
     update, `side` now waits for as well."""
     side.wait_stream(main)
     for o in pending_updates:
-        o._ov.inherit(side, main)
+        for g in o._gates():
+            g.inherit(side, main)
 
 
 def join(main: torch.cuda.Stream, side: torch.cuda.Stream):
     """`main` continues behind everything enqueued on `side` (main.wait_stream(side))."""
     main.wait_stream(side)
     for o in pending_updates:
-        o._ov.inherit(main, side)
+        for g in o._gates():
+            g.inherit(main, side)
 
 
 def gate(*what):
@@ -110,4 +112,5 @@ def gate(*what):
     if not pending_updates:
         return
     for o in list(pending_updates):
-        o._ov.gate(what)
+        for g in o._gates():
+            g.gate(what)

@@ -200,15 +200,17 @@ def table_entries(descs, n: int) -> int:
     return L.workspace_bytes(L.WS_WGRAD_TABLE, *[descs[i].M for i in range(n)]) // L.WGRAD_TABLE_ENTRY
 
 
-def launch(descs, n: int, table: Optional[torch.Tensor] = None):
+def launch(descs, n: int, table: Optional[torch.Tensor] = None, phase: int = 3):
     """hamt_wgrad_grouped on the current stream; `table` = device scratch for the launch table (allocated here when
-    None: from the caching allocator, i.e. from the graph's private pool during a capture)."""
+    None: from the caching allocator, i.e. from the graph's private pool during a capture).  phase 1 / 2: only write the table /
+    only launch from a table written before (hamt_wgrad_grouped_ex)."""
     from .ops import _stream
     if n == 0:
         return
     if table is None:
+        assert phase == 3
         table = torch.empty(table_entries(descs, n) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device="cuda")
-    L.check(L.load().hamt_wgrad_grouped(n, descs, table.data_ptr(), table.numel(), _stream()), "hamt_wgrad_grouped")
+    L.check(L.load().hamt_wgrad_grouped_ex(n, descs, table.data_ptr(), table.numel(), phase, _stream()), "hamt_wgrad_grouped")
 
 
 def pending(device=None) -> int:
@@ -577,7 +579,7 @@ def _build_plan(items, optimizer, n_groups, wire):
     return plan
 
 
-def launch_group(plan: Plan, g: int):
+def launch_group(plan: Plan, g: int, phase: int = 3):
     descs, n = plan.groups[g]
     if n:
-        launch(descs, n, table=plan.tables[g])
+        launch(descs, n, table=plan.tables[g], phase=phase)
