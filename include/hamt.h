@@ -333,7 +333,7 @@ int hamt_scatter_add_rows(int R, int W, const float* src, int ld_src, int col0, 
                           float* dst, int ld_dst, void* stream);
 /* scatter_add in a FIXED summation order (colliding rows are added in row order by one writer per table row: bit-reproducible, unlike the
  * atomic form); idx must be given; T = rows of the table (< 2^31): source rows whose index is outside [0, T) are skipped.  ws: 34 R ints of device
- * scratch.  Beyond 32 768 source rows it falls back to the atomic kernel. */
+ * scratch.  Beyond 262 144 source rows (the ranking is quadratic) it falls back to the atomic kernel and says so on stderr, once. */
 int hamt_scatter_add_rows_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx,
                                   float* dst, int ld_dst, int T, int* ws, void* stream);
 /* the same for a CONTIGUOUS table dst[T][W] of T <= 8 rows (idx must be given): fixed-order sums instead of atomics -- the table's
@@ -347,7 +347,7 @@ int hamt_embed_sum_fwd(int B, int L, int H, const int64_t* ids, const float* wor
 /* backward: dword[ids] += dz, dpos[l] += sum_b dz, dtype_row += sum dz (any of the three may be NULL);
  * V = rows of the word table (ids outside [0, V) are skipped).  ws / ws_bytes: device scratch and ITS SIZE; needed when dtype_row is given
  * (>= HAMT_WS_COLSUM {B * L, H}, checked).  With ws_bytes >= HAMT_WS_EMBED_BWD {B * L, H} the word rows are summed in a fixed order
- * (hamt_scatter_add_rows_ordered); with less (or beyond 32 768 rows) by atomic adds -- never written past ws_bytes */
+ * (hamt_scatter_add_rows_ordered); with less (or beyond 262 144 rows) by atomic adds -- never written past ws_bytes */
 int hamt_embed_sum_bwd(int B, int L, int H, int V, const int64_t* ids, const float* dz, float* dword,
                        float* dpos, float* dtype_row, float* ws, size_t ws_bytes, void* stream);
 

@@ -489,7 +489,8 @@ def test_wgrad_grouped_matches_per_problem_reference(tile, monkeypatch):
         d.ss = ss.data_ptr() if ss is not None else None
         d.K_valid = kv
         kr = kv if kv else K
-        rw = dy[:kr].double().cpu().t() @ x[:kr].double().cpu() + (dw0.double() if aw else 0)
+        # (the fp64 reference products on the GPU -- torch / rocBLAS dgemm as the CHECKER: 60 of them on the host cores took 20 s of this test)
+        rw = (dy[:kr].double().t() @ x[:kr].double()).cpu() + (dw0.double() if aw else 0)
         rb = (dy[:kr].double().cpu().sum(0) + (db0.double() if ab else 0)) if wdb else db0.double()
         if not aw and i % 5 == 4:      # wire output (hamt_wgrad_desc.wire_scale): bf16(0.5 dW) into a bf16 array, no fp32 store, no ss
             dw = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -560,13 +561,13 @@ def test_wgrad_grouped_second_operand_pair(tile, monkeypatch):
         d.dy, d.x, d.dw, d.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if wdb else None)
         d.M, d.N, d.K, d.ldy, d.ldx, d.ldw, d.accum_dw, d.accum_db = M, N, K, dy.stride(0), x.stride(0), N, aw, aw
         d.ss = ss.data_ptr()
-        rw = dy.double().cpu().t() @ x.double().cpu() + (dw0.double() if aw else 0)
+        rw = (dy.double().t() @ x.double()).cpu() + (dw0.double() if aw else 0)
         rb = dy.double().cpu().sum(0) + (db0.double() if aw else 0)
         if K2:
             dy2, x2 = operand(K2, M, 7 * i + 4, kv2), operand(K2, N, 7 * i + 5, kv2)
             d.dy2, d.x2, d.K2, d.ldy2, d.ldx2, d.K2_valid = dy2.data_ptr(), x2.data_ptr(), K2, dy2.stride(0), x2.stride(0), kv2
             kr = kv2 if kv2 else K2
-            rw = rw + dy2[:kr].double().cpu().t() @ x2[:kr].double().cpu()
+            rw = rw + (dy2[:kr].double().t() @ x2[:kr].double()).cpu()
             rb = rb + dy2[:kr].double().cpu().sum(0)
         refs.append((dw, db, rw, rb if wdb else db0.double(), ss))
     tab = torch.empty(sum((sp[3] + 63) // 64 for sp in specs) * L.WGRAD_TABLE_ENTRY, dtype=torch.uint8, device=DEV)
@@ -1037,8 +1038,8 @@ def test_embed_sum_and_gather_scatter_exact():
 def test_scatter_add_ordered_is_bit_reproducible(R, T, W):
     """dst[idx[r]] += src[r] with colliding rows summed in ROW order by one writer per table row (hamt_scatter_add_rows_ordered, the word
     embeddings' gradient in hamt_embed_sum_bwd): equal to a sequential fp32 sum in row order -- hence bit-identical from run to run,
-    which the atomic scatter was not (tools/grad_bitwise_repeat.py) -- on top of what the table held.  33 000 rows: the atomic fallback
-    beyond 32 768 (correct, not ordered)."""
+    which the atomic scatter was not (tools/grad_bitwise_repeat.py) -- on top of what the table held.  33 000 rows: ordered as well since
+    round 6 (the fallback to atomics starts at 262 144 rows, and is announced on stderr)."""
     import ctypes as C
     from vln_hamt_amd import _lib as L
     from vln_hamt_amd.ops import _p, _stream
@@ -1060,7 +1061,7 @@ def test_scatter_add_ordered_is_bit_reproducible(R, T, W):
         del junk
     ref = base.double().index_add(0, idx, src.double())
     close(outs[0], ref, 2e-5, "ordered scatter")
-    if R <= 32768:
+    if R <= 262144:
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "ordered scatter is not bit-reproducible"
         # (the defined order: up to 8 source rows of a table row are summed in row order; more: members j = 0 .. 7 (mod 8) in row order,
         # the eight sums added in that order; the total is added to the table row)
@@ -1106,7 +1107,8 @@ def test_scatter_add_ordered_skips_rows_outside_the_table():
     dst = buf[guard:guard + T]
     dst.zero_()
     ws = torch.empty(34 * R, dtype=torch.int32, device=DEV)
-    L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(src.to(DEV)), W, 0, _p(idx.to(DEV)), _p(dst), W, T, _p(ws), _stream()), "scatter")
+    src_d, idx_d = src.to(DEV), idx.to(DEV)                      # (held: a temporary's block would be handed to the next allocation)
+    L.check(L.load().hamt_scatter_add_rows_ordered(R, W, _p(src_d), W, 0, _p(idx_d), _p(dst), W, T, _p(ws), _stream()), "scatter")
     torch.cuda.synchronize()
     ok = torch.ones(R, dtype=torch.bool); ok[bad] = False
     ref = torch.zeros(T, W, dtype=torch.float64).index_add(0, idx[ok], src[ok].double())
@@ -1117,13 +1119,14 @@ def test_scatter_add_ordered_skips_rows_outside_the_table():
     ids = torch.randint(0, V, (B, Lq), generator=g)
     ids[1, 2], ids[3, 4] = -1, V
     dz = rnd(B * Lq, H, seed=2)
+    ids_d, dz_d = ids.to(DEV), dz.to(DEV)
     for ws_bytes in (L.workspace_bytes(L.WS_EMBED_BWD, B * Lq, H), L.workspace_bytes(L.WS_COLSUM, B * Lq, H)):
         wsb = torch.full((ws_bytes // 4 + 4096,), 5.0, device=DEV)
         tab = torch.full((guard + V + guard, H), 7.0, device=DEV)
         dword = tab[guard:guard + V]
         dword.zero_()
         dtyp = torch.zeros(H, device=DEV)
-        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, V, _p(ids.to(DEV)), _p(dz.to(DEV)), _p(dword), None, _p(dtyp), _p(wsb), ws_bytes, _stream()), "embed bwd")
+        L.check(L.load().hamt_embed_sum_bwd(B, Lq, H, V, _p(ids_d), _p(dz_d), _p(dword), None, _p(dtyp), _p(wsb), ws_bytes, _stream()), "embed bwd")
         torch.cuda.synchronize()
         okm = ((ids >= 0) & (ids < V)).flatten()
         ref = torch.zeros(V, H, dtype=torch.float64).index_add(0, ids.flatten()[okm], dz[okm].double())
@@ -1131,7 +1134,7 @@ def test_scatter_add_ordered_skips_rows_outside_the_table():
         close(dtyp.cpu(), dz.double().sum(0), 2e-5, "dtype row")
         assert float((tab[:guard] - 7.0).abs().max()) == 0.0 and float((tab[guard + V:] - 7.0).abs().max()) == 0.0, "wrote outside the word table"
         assert float((wsb[ws_bytes // 4:] - 5.0).abs().max()) == 0.0, "wrote past ws_bytes"
-    assert L.load().hamt_embed_sum_bwd(B, Lq, H, V, _p(ids.to(DEV)), _p(dz.to(DEV)), None, None, _p(dtyp), _p(wsb), 16, _stream()) != 0      # dtype_row needs COLSUM scratch
+    assert L.load().hamt_embed_sum_bwd(B, Lq, H, V, _p(ids_d), _p(dz_d), None, None, _p(dtyp), _p(wsb), 16, _stream()) != 0      # dtype_row needs COLSUM scratch
 
 
 @pytest.mark.parametrize("B,L,H,V", [(64, 80, 768, 30522), (5, 33, 1024, 100), (2, 7, 132, 50), (3, 9, 1028, 40)])

@@ -236,7 +236,11 @@ def test_update_overlapped_with_the_next_forward_matches_in_stream_update(tiny):
             assert torch.equal(e_gated, e_after)
     o2.wait_update()
     torch.cuda.synchronize()
-    assert max(abs(a - b) for a, b in zip(l1, l2)) < 1e-4, (l1, l2)
+    # (the two runs take the gradient norm from different sums -- the attached optimizer reduces the whole arena, the plain one adds the
+    # weight-gradient tiles' own sums of squares -- so the clip coefficient differs in the last bit and the losses (1.2 .. 6.9 here) drift
+    # apart by 1e-5 .. 2e-4 over the eight steps, run after run the same: 1.86e-4 with the half-precision dense outputs of round 6, < 1e-4
+    # with the bf16 ones.  A parameter read that overtook its chunk's update shows as 1e-3 and more, and in `w` below.)
+    assert max(abs(a - b) for a, b in zip(l1, l2)) < 5e-4, (l1, l2)
     w = _worst(m1, m2)
     assert w < 2e-5, w
     o2.detach()

@@ -439,7 +439,15 @@ __global__ __launch_bounds__(64 * SCAT_WAVES) void scatter_segment_add_kernel(in
 // ws: (SCAT_SLICES + 2) R ints.  false: no index / no scratch / R too large for the quadratic ranking (the caller falls back to atomics)
 static bool scatter_add_ordered(int R, int W, const float* src, int ld_src, int col0, const int64_t* idx, float* dst, int ld_dst, int T, int* ws, hipStream_t s) {
   static const bool off = getenv("HAMT_ATOMIC_SCATTER") != nullptr;      // (measurement: the atomic kernels instead)
-  if (R > 32768 || !idx || !ws || off) return false;
+  // The ranking compares every pair of source rows: 26 M compares (11 us) at the step's 5 120 rows, 1 G (~0.4 ms) at 32 768, 69 G at
+  // SCAT_MAX_ROWS -- a pass of tens of milliseconds that no batch of this path comes near (RxR: 32 x 250 = 8 000 rows); beyond that
+  // the atomic kernels, LOUDLY (once): the sums are then correct but not bit-reproducible
+  constexpr int SCAT_MAX_ROWS = 262144;
+  if (R > SCAT_MAX_ROWS && idx && ws && !off) {
+    static bool told = false;
+    if (!told) { told = true; fprintf(stderr, "[hamt] scatter_add over %d rows (> %d): atomic adds instead of the ordered sums -- results are not bit-reproducible\n", R, SCAT_MAX_ROWS); }
+  }
+  if (R > SCAT_MAX_ROWS || !idx || !ws || off) return false;
   const int ns = (R + 255) / 256 < SCAT_SLICES ? (R + 255) / 256 : SCAT_SLICES;      // slices of the row range (grid.y): 256 rows each up to 8192 rows
   const int per = ((R + ns - 1) / ns + 255) / 256 * 256;
   int* cnt = ws;
@@ -505,7 +513,7 @@ extern "C" int hamt_embed_sum_bwd(int B, int L, int H, int V, const int64_t* ids
   if (B * L == 0) return HAMT_OK;
   hipStream_t s = as_stream(stream);
   // (the word rows: in a fixed order when ws is given AND large enough for the ranking's (SCAT_SLICES + 2) R ints -- scatter_add_ordered
-  // above -- else, or beyond 32 768 rows, by atomic adds.  ws_bytes: ABI 1 took the size on trust; a caller that sized ws by the older
+  // above -- else, or beyond 262 144 rows, by atomic adds.  ws_bytes: ABI 1 took the size on trust; a caller that sized ws by the older
   // HAMT_WS_COLSUM rule would have been overrun by the ranking arrays)
   const bool ws_ok = ws && ws_bytes >= (size_t)(SCAT_SLICES + 2) * (size_t)(B * L) * sizeof(int);
   if (dtype_row) {

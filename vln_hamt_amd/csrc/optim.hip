@@ -397,9 +397,6 @@ extern "C" int hamt_adamw_table_range(size_t first, size_t n, float* p, float* g
   if (n == 0) return HAMT_OK;
   size_t b = (n / 4 + 1023) / 1024;              // 16-KiB chunks of 256 x 4 float4; the grid sweeps them together (see the kernel)
   int nb = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
-  // (measurement: a THROTTLED update -- few workgroups, a fraction of the HBM rate -- next to the following forward pass,
-  // GraphedTrainStep(overlap_update=True); read per call)
-  if (const char* cap = getenv("HAMT_ADAMW_MAX_BLOCKS")) { const int c = atoi(cap); if (c > 0 && nb > c) nb = c; }
   hipLaunchKernelGGL((adamw_table_kernel<4>), dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v, (bf16_t*)p16, ends,
                      (const float4*)hyp, nparams, gnorm_sq, max_norm, beta1, beta2, eps, zero_grad, first / 4);
   HAMT_CHECK_LAUNCH("hamt_adamw_table");

@@ -463,14 +463,15 @@ class AdamW(Optimizer):
         all-gathers of the sharded exchange on the communication stream (parallel.ShardedGradSync.attach_gather)"""
         return [g for g in (self._ov, self._gather_ov) if g is not None]
 
-    def wait_update(self):
-        """Order the current stream behind an update still running on the update stream -- and behind the parameter all-gathers of the
-        sharded exchange still running on the communication stream (no-op otherwise)."""
-        for ov in self._gates():
-            if ov.pending:
+    def wait_update(self, gathers: bool = True):
+        """Order the current stream behind an update still running on the update stream -- and (`gathers`) behind the parameter
+        all-gathers of the sharded exchange still running on the communication stream (no-op otherwise)."""
+        for ov in ((self._ov, self._gather_ov) if gathers else (self._ov,)):
+            if ov is not None and ov.pending:
                 torch.cuda.current_stream().wait_event(ov.events[-1])
                 ov.pending = False
-        streams.pending_updates.discard(self)
+        if not any(g.pending for g in self._gates()):
+            streams.pending_updates.discard(self)
 
     def launch_step_overlapped(self, gnorm_sq=None, max_norm: float = 0.0):
         """launch_step on the update stream, one launch + one event per chunk (capturable: a fork of the capturing stream that
@@ -556,7 +557,7 @@ class AdamW(Optimizer):
             if self._built:
                 self._flat_g._hamt_dirty = True
         if self._built and getattr(self._flat_g, "_hamt_dirty", False):
-            self.wait_update()
+            self.wait_update(gathers=False)      # (an update on its own stream reads the gradient arena; the parameters' all-gathers do not)
             # something accumulated into arena slots it assumed zero and no update (which zeroes the arena) has run since
             self._flat_g.zero_()
             self._flat_g._hamt_dirty = False
