@@ -292,7 +292,8 @@ int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* residual, con
                 const uint64_t* rng, void* stream);
 /* dz = d(pre-LN sum) (also the residual gradient); dx = dropout_pre-masked dz (may be NULL); dx16 (optional) = the same
  * as bf16 [Mpad16, H] -- the operand of the dgrad/wgrad GEMMs of the dense layer that produced x; dxsum (optional) +=
- * column sums of dx = that layer's bias gradient; dgamma/dbeta/dxsum are STORED (overwritten).  ws: >= 3*256*H floats. */
+ * column sums of dx = that layer's bias gradient; dgamma/dbeta/dxsum are STORED (overwritten).  ws: HAMT_WS_LN_BWD {M, H} bytes
+ * (3 H floats per block of the kernel, at most 256 blocks). */
 int hamt_ln_bwd(const hamt_ln_desc* d, const float* dy, const void* z, const float* mean,
                 const float* rstd, const float* gamma, float* dz, float* dx, void* dx16, float* dgamma,
                 float* dbeta, float* dxsum, float* ws, const uint64_t* rng, void* stream);

@@ -174,6 +174,36 @@ def test_wgrad_plan_invariants_cpu():
             assert g_prev in plan.deps[g_next]
     first = [min(o for o, ws in writes.items() if any(g == gg for g, _ in ws)) for gg in range(len(plan.groups))]
     assert len(plan.groups) >= 4 and first[:4] == sorted(first[:4])                     # (4)
+    # (5) round 6: groups cut at the exchange's STATIC range boundaries (`cuts`): the weights written once whose slot starts in static
+    # range k form one group, in arena order, and static range k is final (parallel.range_finality) once that group -- or, for a
+    # weight that straddles the boundary, its predecessor -- has run; it never waits for a LATER range's group
+    from vln_hamt_amd.parallel import range_finality
+    for w, b in params:
+        w.grad = b.grad = None
+    once = [i for i in range(len(params)) if order.count(i) == 1]
+    items1 = []
+    for i in once:
+        w, b = params[i]
+        dy, x = mk(w)
+        items1.append((w, b, dy, x))
+    cuts = [n // 4 // 8 * 8, n // 2 // 8 * 8, 3 * n // 4 // 8 * 8]
+    plan = wgrad.build_plan(items1, SimpleNamespace(_flat_g=flat_g), n_groups=2, cuts=cuts)
+    static = list(zip([0] + cuts, cuts + [n]))
+    import bisect
+    g_of = {}
+    for g, (descs, cnt) in enumerate(plan.groups):
+        for i in range(cnt):
+            g_of[(descs[i].dw - base) // 4] = g
+    by_range = {}
+    for o, g in g_of.items():
+        by_range.setdefault(bisect.bisect_right(cuts, o), set()).add(g)
+    assert all(len(v) == 1 for v in by_range.values()), by_range                         # one group per static range
+    ks = sorted(by_range)
+    assert [next(iter(by_range[k])) for k in ks] == list(range(len(ks))), by_range        # numbered in arena order, none empty
+    fin = range_finality(static, plan.ranges)
+    for k, (lo, hi, after, touched) in enumerate(fin):
+        own = next(iter(by_range[k])) if k in by_range else -1
+        assert after <= max(own, max((next(iter(by_range[j])) for j in by_range if j < k), default=-1)), (k, after, own)
 
 
 def test_shard_cuts_invariants():

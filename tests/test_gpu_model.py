@@ -4,6 +4,7 @@ Tolerances (north_star): activations/logits/losses <= 1e-3 in fp32 mode, <= 1e-2
 relative to max(1, |ref|_max)); integer/index work (compaction order, -inf positions) bit exact.
 """
 import math
+import functools
 import os
 
 import numpy as np
@@ -625,6 +626,15 @@ def test_canon_gradients_vs_reference_goldens(prec):
                 assert cos >= 0.99 and pcos >= 0.99 and abs((n1 / n2) ** 0.5 - 1) <= 0.03, (task, cos, pcos, (n1 / n2) ** 0.5)
 
 
+@functools.lru_cache(maxsize=1)
+def _b64_model():
+    """the R2R-canon weights (174.8 M elements from the numpy recipe) and the model built on them, shared by the two modes below"""
+    from oracle.hamt_oracle import OracleConfig, make_state_dict, pretrain_param_shapes
+    cfg = OracleConfig()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=5)
+    return cfg, sd, build(cfg, sd, "bf16")
+
+
 @pytest.mark.parametrize("mode", ["padded", "packed"])
 def test_canon_b64_vs_oracle(mode):
     """The BENCHMARKED batch itself (the goldens stop at B = 16): R2R-canon model, B = 64, L = 80, T = 5 (padded, the
@@ -635,11 +645,9 @@ def test_canon_b64_vs_oracle(mode):
     SPREL / MRC.  SAR and ITM: the loss gradient is a sum of terms that cancel (regression residuals of both signs; five nearly
     identical candidates: see test_canon_multi_seed_margins), so what is compared at cosine >= 0.99 is the gradient of ONE un-cancelled
     output, mean_b prediction[b, 0] -- and the outputs themselves (predictions / logits) at 1e-2 (head outputs: `head_tol`)."""
-    from oracle.hamt_oracle import HamtOracle, OracleConfig, make_state_dict, pretrain_param_shapes
+    from oracle.hamt_oracle import HamtOracle
     from vln_hamt_amd.synth import make_batch, make_itm_rng
-    cfg = OracleConfig()
-    sd = make_state_dict(pretrain_param_shapes(cfg), seed=5)
-    model = build(cfg, sd, "bf16")
+    cfg, sd, model = _b64_model()
     named = dict(model.named_parameters())
     packed = mode == "packed"
 
@@ -676,7 +684,7 @@ def test_canon_b64_vs_oracle(mode):
     # a few worker threads, the GPU passes and the comparisons follow as the results arrive.
     from concurrent.futures import ThreadPoolExecutor
     tasks = ("mlm", "sap", "sar", "sprel", "mrc", "itm")
-    pool = ThreadPoolExecutor(max_workers=4)
+    pool = ThreadPoolExecutor(max_workers=8)
     work = {}
     for i, task in enumerate(tasks):
         batch = make_batch(task, 64 if task != "itm" else 32, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)

@@ -44,7 +44,7 @@ def _ln_bwd_add(dln, x2, mean, rstd, gamma, eps, dy2, params=None):
     dev = x2.device
     dx = torch.empty(M, D, dtype=torch.float32, device=dev)
     red = torch.empty(3, D, dtype=torch.float32, device=dev)
-    ws = torch.empty(3 * 256 * D, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.workspace_bytes(L.WS_LN_BWD, M, D) // 4, dtype=torch.float32, device=dev)
     d = L.LnDesc(M, D, float(eps), 0.0, 0.0, 0, 0)
     defer = params is not None and _can_defer_ln((params[0], params[1], None), dev, D)
     L.check(L.load().hamt_ln_bwd_add(C.byref(d), _p(dln), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dy2), _p(dx),

@@ -336,6 +336,9 @@ extern "C" int hamt_ln_fwd(const hamt_ln_desc* d, const void* x, const float* re
 
 // waves per block and number of blocks (= partials) of the backward kernel for M rows (measured, H = 768, incl. the reduce
 // pass: M = 11520 42 -> 31 us, 5120 24 -> 22, 2368 17.6 -> 14.1 with 16 waves; 384 rows are fastest with 4)
+// (round 6: the cap at 256 blocks leaves a quarter of the waves of a 5 120-row call with a second row; 320 / 720 blocks -- one row per wave --
+// measured SLOWER, tools/ln_bench.py: 17.1 -> 20.0 us at 5 120 rows, 24.5 -> 34.2 at 11 520, the B = 64 step 9.17 -> 9.28 ms: every block
+// ends with a 16-wave LDS tree and 3 H floats of partials, and that tail grows with the block count faster than the row loop shrinks)
 static void ln_bwd_geometry(int M, int* nwv_out, int* nb_out) {
   static const int force_w = getenv("HAMT_LN_BWD_WAVES") ? atoi(getenv("HAMT_LN_BWD_WAVES")) : 0;
   const int nwv = force_w ? force_w : (M >= 2048 ? 16 : (M >= 1024 ? 8 : 4));

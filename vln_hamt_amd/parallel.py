@@ -202,7 +202,7 @@ class OverlappedGradSync:
 
     def _on_flush(self, items):
         from . import wgrad
-        plan = wgrad.build_plan(items, self.opt, self.n_groups, wire=self._wire_spec())
+        plan = wgrad.build_plan(items, self.opt, self.n_groups, wire=self._wire_spec(), cuts=self._group_cuts())
         if plan is None:                   # some parameter lives outside the arena: plain semantics
             ps = wgrad._Pass()
             ps.items = list(items)
@@ -218,6 +218,15 @@ class OverlappedGradSync:
     def take_plan(self):
         p, self.plan = self.plan, None
         return p
+
+    def _group_cuts(self):
+        """interior boundaries of the static exchange ranges inside the GEMM-weight region: the weight-gradient launch groups are cut
+        THERE (wgrad.build_plan `cuts`), so that range k is final -- and its collective under way -- when group k has run.
+        HAMT_GROUPS_EQUAL_WORK=1: `n_groups` equal-work groups as before round 6 (measurements)."""
+        if os.environ.get("HAMT_GROUPS_EQUAL_WORK"):
+            return None
+        n_a = self.opt._n_shadow_only
+        return [hi for (lo, hi) in self._static_ranges() if hi < n_a]
 
     def _wire_spec(self):
         """None, or (bf16 staging arena, scale, first element NOT covered) for weight-gradient launches that write the wire value

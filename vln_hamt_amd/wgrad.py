@@ -434,7 +434,7 @@ class Plan:
         self.graphs: Optional[list] = None      # per group: a captured hipGraph of its launches (graph.GraphedTrainStep)
 
 
-def build_plan(items, optimizer, n_groups: int = 4, wire=None) -> Optional[Plan]:
+def build_plan(items, optimizer, n_groups: int = 4, wire=None, cuts=None) -> Optional[Plan]:
     """Resolve `items` to arena slots (every parameter must own one) and publish `.grad` views.  A parameter that
     already has an autograd-produced `.grad` gets accum = 1: the caller packs that gradient into the slot BEFORE the
     groups run.  Returns None when some parameter has no arena slot (caller falls back to flush semantics).
@@ -444,8 +444,14 @@ def build_plan(items, optimizer, n_groups: int = 4, wire=None) -> Optional[Plan]
     launch as bf16(scale * dW) straight into `stage16` (the exchange's staging arena, same element offsets) -- what the pack pass
     over the fp32 arena would have produced -- and the fp32 slot is not written at all.  `plan.pack_segs` lists what is left for
     the pack kernel in that region: weights written twice in the pass (shared cross-attention weights: fp32 accumulation first),
-    and gradients that came through autograd."""
-    return _build_plan(items, optimizer, n_groups, wire)
+    and gradients that came through autograd.
+
+    `cuts` (sorted arena offsets, the interior boundaries of the exchange's STATIC ranges in the GEMM-weight region): launch group g =
+    the queued weights whose slot starts in static range g, instead of `n_groups` equal-work groups.  A static range is then final
+    as soon as ITS group has run -- its collective (and the widening of the owned chunk) starts under the next group -- where
+    equal-work cuts, which fall anywhere, left three of four ranges waiting for the last group (round 6: 350 us of serial
+    unpack / norm kernels behind the last weight-gradient launch of a one-rank exchange)."""
+    return _build_plan(items, optimizer, n_groups, wire, cuts)
 
 
 def _merge_segs(segs):
@@ -458,7 +464,7 @@ def _merge_segs(segs):
     return out
 
 
-def _build_plan(items, optimizer, n_groups, wire):
+def _build_plan(items, optimizer, n_groups, wire, cuts=None):
     flat_g = optimizer._flat_g
     base, n_total = flat_g.data_ptr(), flat_g.numel()
 
@@ -492,13 +498,22 @@ def _build_plan(items, optimizer, n_groups, wire):
     # (per-batch padding to the local longest instruction, the packed text's row bucket), and the launch groups decide when an
     # arena range may be exchanged: the cuts must be the same on every rank that queued the same parameters
     flops = [float(t[2].numel()) for t in probs]
-    total, acc, cuts, gi = sum(flops), 0.0, [], 0
+    total, acc, gi = sum(flops), 0.0, 0
     group_of = []
-    for f in flops:                         # equal-work cuts in arena order
-        if gi < n_groups - 1 and acc >= (gi + 1) * total / n_groups:
-            gi += 1
-        group_of.append(gi)
-        acc += f
+    if cuts:                                # one group per static exchange range (arena layout and world size only: rank-invariant too)
+        import bisect
+        first = bisect.bisect_right(cuts, probs[0][0]) if probs else 0
+        for t in probs:                     # (groups without a queued weight are dropped: numbering starts at the first one used)
+            group_of.append(bisect.bisect_right(cuts, t[0]))
+        used = sorted(set(group_of))
+        renum = {g: i for i, g in enumerate(used)}
+        group_of = [renum[g] for g in group_of]
+    else:
+        for f in flops:                     # equal-work cuts in arena order
+            if gi < n_groups - 1 and acc >= (gi + 1) * total / n_groups:
+                gi += 1
+            group_of.append(gi)
+            acc += f
     # a buffer written twice in the pass: the second write must land in a LATER launch than the first
     last_group: dict = {}
     dep_pairs = set()
