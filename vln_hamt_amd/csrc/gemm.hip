@@ -79,7 +79,10 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int row, int col, f
 // LDS tiles are kept k-major ([k][r], r contiguous, row stride R+16 floats => the two 16-lane halves
 // of a 32-lane ds_read_b32 group hit disjoint banks).
 // =================================================================================================
-constexpr int F_BM = 64, F_BN = 64, F_BK = 16, F_LD = 64 + 16;
+// F_BK = 32 since round 6 (two 16-row stage pieces per thread and operand): a tile's life is its chain of k-stages -- global load one
+// stage ahead, LDS write, barrier, 0.8 us each -- and the callers of this path are few-tile problems (the fp32 prediction heads: 96
+// tiles at the rollout's 456 x 768 x 768, 40 us for 48 stages of 16)
+constexpr int F_BM = 64, F_BN = 64, F_BK = 32, F_LD = 64 + 16, F_NP = F_BK / 16;
 
 template <bool KMAJOR>
 __device__ __forceinline__ void f32_stage_load(const float* __restrict__ P, int ld, int r0, int rlim, int k0,
@@ -132,18 +135,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[4], rb[4];
+  float ra[F_NP][4], rb[F_NP][4];        // a stage = F_NP pieces of 16 k-rows (the 256 threads cover 64 x 16 per piece)
   const int nk = (g.K + F_BK - 1) / F_BK;
-  f32_stage_load<A_KM>(A, g.lda, m0, g.M, 0, g.ka_lim, t, ra);
-  f32_stage_load<B_KM>(B, g.ldb, n0, g.N, 0, g.kb_lim, t, rb);
-  f32_stage_write<A_KM>(lds[0][0], t, ra);
-  f32_stage_write<B_KM>(lds[0][1], t, rb);
+#pragma unroll
+  for (int h = 0; h < F_NP; ++h) {
+    f32_stage_load<A_KM>(A, g.lda, m0, g.M, 16 * h, g.ka_lim, t, ra[h]);
+    f32_stage_load<B_KM>(B, g.ldb, n0, g.N, 16 * h, g.kb_lim, t, rb[h]);
+  }
+#pragma unroll
+  for (int h = 0; h < F_NP; ++h) {
+    f32_stage_write<A_KM>(lds[0][0] + 16 * h * F_LD, t, ra[h]);
+    f32_stage_write<B_KM>(lds[0][1] + 16 * h * F_LD, t, rb[h]);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      f32_stage_load<A_KM>(A, g.lda, m0, g.M, (kt + 1) * F_BK, g.ka_lim, t, ra);
-      f32_stage_load<B_KM>(B, g.ldb, n0, g.N, (kt + 1) * F_BK, g.kb_lim, t, rb);
+#pragma unroll
+      for (int h = 0; h < F_NP; ++h) {
+        f32_stage_load<A_KM>(A, g.lda, m0, g.M, (kt + 1) * F_BK + 16 * h, g.ka_lim, t, ra[h]);
+        f32_stage_load<B_KM>(B, g.ldb, n0, g.N, (kt + 1) * F_BK + 16 * h, g.kb_lim, t, rb[h]);
+      }
     }
     const float* As = lds[cur][0];
     const float* Bs = lds[cur][1];
@@ -161,8 +173,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      f32_stage_write<A_KM>(lds[cur ^ 1][0], t, ra);
-      f32_stage_write<B_KM>(lds[cur ^ 1][1], t, rb);
+#pragma unroll
+      for (int h = 0; h < F_NP; ++h) {
+        f32_stage_write<A_KM>(lds[cur ^ 1][0] + 16 * h * F_LD, t, ra[h]);
+        f32_stage_write<B_KM>(lds[cur ^ 1][1] + 16 * h * F_LD, t, rb[h]);
+      }
     }
     __syncthreads();
   }

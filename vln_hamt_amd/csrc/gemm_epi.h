@@ -179,12 +179,16 @@ __device__ __forceinline__ void epi_store(const GemmArgsF& g, int row, int col, 
 // whose columns all exist (rows may be ragged), with 16-byte aligned rows, takes this path instead: the tile-level test is made once (workgroup
 // uniform), the dtype of C is a template argument, the bias of a lane's 8 columns is loaded once per tile, and a piece is two LDS reads,
 // the arithmetic and one or two 16-byte stores.
-constexpr int EPI_FAST_MASK = HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_ACCUM | HAMT_EPI_MUL_AUX;
+// (round 6: + dropout and the residual add -- the epilogues of the ViT blocks' proj / fc1 / fc2, vision_transformer.py:148-150, 176-177,
+// 196-197, which ran the general path: 35 % of the image-input step's kernel time in three GEMM instantiations)
+constexpr int EPI_FAST_MASK = HAMT_EPI_BIAS | HAMT_EPI_GELU | HAMT_EPI_GELU_GRAD | HAMT_EPI_ACCUM | HAMT_EPI_MUL_AUX | HAMT_EPI_DROPOUT | HAMT_EPI_ADD_AUX;
 __device__ __forceinline__ bool epi_fast_ok(const GemmArgsF& g, int epi, int m0, int n0, int bm, int bn) {
   (void)m0; (void)bm;     // (rows may be ragged: epi_fast8 skips rows >= M, one compare per piece)
   bool ok = (epi & ~EPI_FAST_MASK) == 0 && g.ksplit <= 1 && n0 + bn <= g.N && (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0;
   if (epi & HAMT_EPI_BIAS) ok = ok && ((uintptr_t)g.bias & 15) == 0;
   if (epi & (HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) ok = ok && g.dtype_aux == HAMT_BF16 && (g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0;
+  if (epi & HAMT_EPI_ADD_AUX)      // the residual: fp32 or bf16 rows, 16-byte aligned; `aux` cannot also be the gelu' image
+    ok = ok && !(epi & (HAMT_EPI_GELU_GRAD | HAMT_EPI_MUL_AUX)) && (g.dtype_aux == HAMT_BF16 || g.dtype_aux == HAMT_F32) && (g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0;
   return ok;
 }
 // EPI: compile-time flag set (subset of EPI_FAST_MASK); b8: the bias of columns col .. col + 7 (BIAS); pre_aux: the piece's 8 bf16 of aux
@@ -199,10 +203,25 @@ __device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
   }
+  float keep[8];
+  if constexpr ((EPI & HAMT_EPI_DROPOUT) != 0) {      // the row's mask stream, two groups of four columns (as epi_store draws them)
+    const RngKey key = rng_key(g.rng, g.call_id);     // (kernel-argument address: scalar loads)
+    const uint32_t rowh = hamt_mix32((uint32_t)row ^ key.k0);
+    const float inv_keep = 1.0f / (1.0f - g.p_drop);
+    float f0[4], f1[4];
+    drop_scale4(key, rowh, (uint32_t)(col >> 2), g.p_drop, inv_keep, f0);
+    drop_scale4(key, rowh, (uint32_t)(col >> 2) + 1u, g.p_drop, inv_keep, f1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { keep[j] = f0[j]; keep[4 + j] = f1[j]; }
+  }
   if constexpr ((EPI & HAMT_EPI_GELU_GRAD) != 0) {
     float dg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) gelu_and_grad(v[j], v[j], dg[j]);
+    if constexpr ((EPI & HAMT_EPI_DROPOUT) != 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dg[j] *= keep[j];
+    }
     st_bf<8>((bf16_t*)g.aux + (size_t)row * g.ldaux + col, dg);
   }
   if constexpr ((EPI & HAMT_EPI_MUL_AUX) != 0) {
@@ -210,6 +229,17 @@ __device__ __forceinline__ void epi_fast8(const GemmArgsF& g, int row, int col, 
     const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) { v[2 * q] *= __uint_as_float(w4[q] << 16); v[2 * q + 1] *= __uint_as_float(w4[q] & 0xffff0000u); }
+  }
+  if constexpr ((EPI & HAMT_EPI_DROPOUT) != 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= keep[j];
+  }
+  if constexpr ((EPI & HAMT_EPI_ADD_AUX) != 0) {      // the residual add behind the dropout
+    float h[8];
+    const size_t ia = (size_t)row * g.ldaux + col;
+    if (g.dtype_aux == HAMT_BF16) ld_bf<8>((const bf16_t*)g.aux + ia, h); else ld_f<8>((const float*)g.aux + ia, h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += h[j];
   }
   const size_t ic = (size_t)row * g.ldc + col;
   if constexpr (C16) {
