@@ -635,6 +635,50 @@ def _b64_model():
     return cfg, sd, build(cfg, sd, "bf16")
 
 
+_B64_TASKS = ("mlm", "sap", "sar", "sprel", "mrc", "itm")
+
+
+@functools.lru_cache(maxsize=1)
+def _b64_oracle_jobs():
+    """The pinned oracle's forward + backward passes of BOTH modes of test_canon_b64_vs_oracle (16 at B = 64: 150 of each mode's 160 seconds
+    when they ran one after the other on the host while the GPU idled -- VERDICT r5 weak 3: the suite at 850 of the driver's 1 200 s),
+    started up front on worker threads (torch's CPU ops release the GIL); the GPU passes and the comparisons follow as the results arrive,
+    the second mode finds its results waiting.  -> {mode: {task: (batch, future of the loss pass, future of the outputs pass or None)}}"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.hamt_oracle import HamtOracle
+    from vln_hamt_amd.synth import make_batch, make_itm_rng
+    cfg, sd, _ = _b64_model()
+
+    def oracle_job(task, cpu_batch, itm, outputs):
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
+        with torch.enable_grad():
+            if not outputs:
+                ref = HamtOracle(osd, cfg).forward(cpu_batch, task, True, itm)
+                ref.mean().backward()
+            else:
+                ref = HamtOracle(osd, cfg).forward(cpu_batch, task, False, itm)
+                ref = ref[0] if isinstance(ref, tuple) else ref
+                ref[:, 0].mean().backward()
+        return ref.detach(), {k: v.grad for k, v in osd.items()}
+
+    pool = ThreadPoolExecutor(max_workers=8)
+    work = {}
+    for mode in ("padded", "packed"):
+        packed = mode == "packed"
+        work[mode] = {}
+        for i, task in enumerate(_B64_TASKS):
+            batch = make_batch(task, 64 if task != "itm" else 32, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)
+            itm = None
+            if task == "itm":
+                itm = make_itm_rng(batch, seed=11)
+                batch["itm_neg_idxs"], batch["itm_shuffled_pos_ids"] = itm["neg_idxs"], itm["shuffled_pos_ids"]
+            cpu_batch = {k: v for k, v in batch.items() if not k.startswith("txt_pack") and k not in ("txt_cu", "txt_unpack_idx")}
+            work[mode][task] = (batch, pool.submit(oracle_job, task, cpu_batch, itm, False),
+                                pool.submit(oracle_job, task, cpu_batch, itm, True) if task in ("sar", "itm") else None)
+    pool.shutdown(wait=False)
+    return work
+
+
 @pytest.mark.parametrize("mode", ["padded", "packed"])
 def test_canon_b64_vs_oracle(mode):
     """The BENCHMARKED batch itself (the goldens stop at B = 16): R2R-canon model, B = 64, L = 80, T = 5 (padded, the
@@ -665,36 +709,8 @@ def test_canon_b64_vs_oracle(mode):
         for p in named.values():
             p.grad = None
 
-    def oracle_job(task, cpu_batch, itm, outputs):
-        """the pinned oracle's forward + backward of one task on the host (a worker thread: torch's CPU ops release the GIL) ->
-        (loss or outputs, {parameter name: gradient or None})"""
-        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
-        with torch.enable_grad():
-            if not outputs:
-                ref = HamtOracle(osd, cfg).forward(cpu_batch, task, True, itm)
-                ref.mean().backward()
-            else:
-                ref = HamtOracle(osd, cfg).forward(cpu_batch, task, False, itm)
-                ref = ref[0] if isinstance(ref, tuple) else ref
-                ref[:, 0].mean().backward()
-        return ref.detach(), {k: v.grad for k, v in osd.items()}
-
-    # The oracle's 16 forward + backward passes at B = 64 were 150 of this test's 160 seconds, one after the other on the host while the GPU
-    # idled (VERDICT r5 weak 3: the suite at 850 of the driver's 1 200 seconds).  They are independent: all of them are started up front on
-    # a few worker threads, the GPU passes and the comparisons follow as the results arrive.
-    from concurrent.futures import ThreadPoolExecutor
-    tasks = ("mlm", "sap", "sar", "sprel", "mrc", "itm")
-    pool = ThreadPoolExecutor(max_workers=8)
-    work = {}
-    for i, task in enumerate(tasks):
-        batch = make_batch(task, 64 if task != "itm" else 32, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)
-        itm = None
-        if task == "itm":
-            itm = make_itm_rng(batch, seed=11)
-            batch["itm_neg_idxs"], batch["itm_shuffled_pos_ids"] = itm["neg_idxs"], itm["shuffled_pos_ids"]
-        cpu_batch = {k: v for k, v in batch.items() if not k.startswith("txt_pack") and k not in ("txt_cu", "txt_unpack_idx")}
-        work[task] = (batch, pool.submit(oracle_job, task, cpu_batch, itm, False),
-                      pool.submit(oracle_job, task, cpu_batch, itm, True) if task in ("sar", "itm") else None)
+    tasks = _B64_TASKS
+    work = _b64_oracle_jobs()[mode]
     try:
         with _CountCalls("hamt_attn_varlen_fwd", "hamt_attn_varlen_bwd") as cnt:
             for task in tasks:
@@ -724,7 +740,8 @@ def test_canon_b64_vs_oracle(mode):
                 print(f"    [{task} outputs] err {oerr:.2e}; gradient of mean_b output[b, 0]: cosine {cos1:.5f}, norm ratio {ratio1:.4f}")
                 assert oerr <= HEAD_CAP and cos1 >= 0.99 and abs(ratio1 - 1) <= 0.03, (task, oerr, cos1, ratio1)
     finally:
-        pool.shutdown(wait=True, cancel_futures=True)
+        for t_ in tasks:                       # (results are 0.7 GB each: let go of this mode's)
+            work[t_] = (None, None, None)
     assert (cnt.n["hamt_attn_varlen_fwd"] > 0) == packed and (cnt.n["hamt_attn_varlen_bwd"] > 0) == packed, cnt.n
 
 
