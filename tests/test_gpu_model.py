@@ -638,16 +638,20 @@ def _b64_model():
 _B64_TASKS = ("mlm", "sap", "sar", "sprel", "mrc", "itm")
 
 
-@functools.lru_cache(maxsize=1)
-def _b64_oracle_jobs():
-    """The pinned oracle's forward + backward passes of BOTH modes of test_canon_b64_vs_oracle (16 at B = 64: 150 of each mode's 160 seconds
-    when they ran one after the other on the host while the GPU idled -- VERDICT r5 weak 3: the suite at 850 of the driver's 1 200 s),
-    started up front on worker threads (torch's CPU ops release the GIL); the GPU passes and the comparisons follow as the results arrive,
-    the second mode finds its results waiting.  -> {mode: {task: (batch, future of the loss pass, future of the outputs pass or None)}}"""
+def _b64_oracle_jobs(mode):
+    """The pinned oracle's forward + backward passes of one mode of test_canon_b64_vs_oracle (8 at B = 64: 150 of the test's 160 seconds when
+    they ran one after the other on the host while the GPU idled -- VERDICT r5 weak 3: the suite at 850 of the driver's 1 200 s), started up
+    front on worker threads (torch's CPU ops release the GIL); the GPU passes and the comparisons follow as the results arrive.  Every
+    worker thread brings its OWN OpenMP team: with torch's default of one thread per core, eight concurrent passes put 8 x (cores) threads
+    on the cores and finish no sooner than eight passes in a row (round 6, first attempt) -- the team size is cut to cores / 8 for the
+    duration.  -> (pool, {task: (batch, future of the loss pass, future of the outputs pass or None)}, restore())"""
     from concurrent.futures import ThreadPoolExecutor
     from oracle.hamt_oracle import HamtOracle
     from vln_hamt_amd.synth import make_batch, make_itm_rng
     cfg, sd, _ = _b64_model()
+    n_workers = 8
+    n_before = torch.get_num_threads()
+    torch.set_num_threads(max(4, (os.cpu_count() or 8) // n_workers))
 
     def oracle_job(task, cpu_batch, itm, outputs):
         osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
@@ -661,22 +665,19 @@ def _b64_oracle_jobs():
                 ref[:, 0].mean().backward()
         return ref.detach(), {k: v.grad for k, v in osd.items()}
 
-    pool = ThreadPoolExecutor(max_workers=8)
+    pool = ThreadPoolExecutor(max_workers=n_workers)
+    packed = mode == "packed"
     work = {}
-    for mode in ("padded", "packed"):
-        packed = mode == "packed"
-        work[mode] = {}
-        for i, task in enumerate(_B64_TASKS):
-            batch = make_batch(task, 64 if task != "itm" else 32, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)
-            itm = None
-            if task == "itm":
-                itm = make_itm_rng(batch, seed=11)
-                batch["itm_neg_idxs"], batch["itm_shuffled_pos_ids"] = itm["neg_idxs"], itm["shuffled_pos_ids"]
-            cpu_batch = {k: v for k, v in batch.items() if not k.startswith("txt_pack") and k not in ("txt_cu", "txt_unpack_idx")}
-            work[mode][task] = (batch, pool.submit(oracle_job, task, cpu_batch, itm, False),
-                                pool.submit(oracle_job, task, cpu_batch, itm, True) if task in ("sar", "itm") else None)
-    pool.shutdown(wait=False)
-    return work
+    for i, task in enumerate(_B64_TASKS):
+        batch = make_batch(task, 64 if task != "itm" else 32, cfg, seed=640 + i, txt_len=80, hist_len=7 if packed else 5, ragged=packed, txt_pack=packed)
+        itm = None
+        if task == "itm":
+            itm = make_itm_rng(batch, seed=11)
+            batch["itm_neg_idxs"], batch["itm_shuffled_pos_ids"] = itm["neg_idxs"], itm["shuffled_pos_ids"]
+        cpu_batch = {k: v for k, v in batch.items() if not k.startswith("txt_pack") and k not in ("txt_cu", "txt_unpack_idx")}
+        work[task] = (batch, pool.submit(oracle_job, task, cpu_batch, itm, False),
+                      pool.submit(oracle_job, task, cpu_batch, itm, True) if task in ("sar", "itm") else None)
+    return pool, work, (lambda: torch.set_num_threads(n_before))
 
 
 @pytest.mark.parametrize("mode", ["padded", "packed"])
@@ -710,7 +711,7 @@ def test_canon_b64_vs_oracle(mode):
             p.grad = None
 
     tasks = _B64_TASKS
-    work = _b64_oracle_jobs()[mode]
+    pool, work, restore_threads = _b64_oracle_jobs(mode)
     try:
         with _CountCalls("hamt_attn_varlen_fwd", "hamt_attn_varlen_bwd") as cnt:
             for task in tasks:
@@ -740,8 +741,8 @@ def test_canon_b64_vs_oracle(mode):
                 print(f"    [{task} outputs] err {oerr:.2e}; gradient of mean_b output[b, 0]: cosine {cos1:.5f}, norm ratio {ratio1:.4f}")
                 assert oerr <= HEAD_CAP and cos1 >= 0.99 and abs(ratio1 - 1) <= 0.03, (task, oerr, cos1, ratio1)
     finally:
-        for t_ in tasks:                       # (results are 0.7 GB each: let go of this mode's)
-            work[t_] = (None, None, None)
+        pool.shutdown(wait=True, cancel_futures=True)
+        restore_threads()
     assert (cnt.n["hamt_attn_varlen_fwd"] > 0) == packed and (cnt.n["hamt_attn_varlen_bwd"] > 0) == packed, cnt.n
 
 

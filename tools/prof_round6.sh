@@ -36,4 +36,8 @@ python -m pytest tests/test_gpu_model.py -q -s -k "canon_b64 or dead_code or can
 ( echo "# round 6 (final tree): lines printed by the gated parity tests -- test_canon_b64_vs_oracle, test_unread_outputs_of_the_last_cross_layer_are_dead_code,"
   echo "# test_canon_multi_seed_margins, test_canon_ragged_vs_reference_goldens (pytest -s).  Head outputs gated at 1e-2 flat."
   grep -E "^\.?\[|^    \[|passed|failed" $O/par.log ) > $O/r06_parity_margins.txt
+# 5) soak: 960 steps, B = 64, full-length and ragged batches (training sanity of the final build)
+( echo "# tools/soak.py 960 steps, B = 64, bf16, hipGraph replay, 12 fixed synthetic batches per task (final build of round 6: IEEE-half dense outputs in front of the LayerNorms)"
+  echo "# full-length batches (L = 80, T = 5):"; SOAK_B=64 python3 tools/soak.py 960 2>/dev/null | grep "steps:"
+  echo "# ragged batches (SOAK_RAGGED=1: L ~ U[20, 80], T ~ U[0, 7]; text packed through the text-only and the cross-modal layers):"; SOAK_B=64 SOAK_RAGGED=1 python3 tools/soak.py 960 2>/dev/null | grep "steps:" ) > $O/r06_soak_b64_960steps.txt
 ls -la $O; head -n 30 $O/r06_hbm_rates_b64.txt; tail -c 1500 $O/r06_bench_b64.json
