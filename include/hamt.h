@@ -31,8 +31,8 @@
 extern "C" {
 #endif
 
-#define HAMT_ABI_VERSION 2   /* 2: hamt_gemm_ln_fwd / hamt_graph_split_* removed (round 5); hamt_embed_sum_bwd takes V and ws_bytes,
-                              * hamt_scatter_add_rows_ordered takes T; hamt_ln_fwd_grouped / hamt_ln_bwd_grouped added (round 6) */
+#define HAMT_ABI_VERSION 2   /* 2 (round 6): hamt_gemm_ln_fwd / hamt_graph_split_* removed (round 5); hamt_embed_sum_bwd takes V and ws_bytes,
+                              * hamt_scatter_add_rows_ordered takes T; hamt_wgrad_grouped_ex and the dtype HAMT_F16 added */
 
 typedef enum { HAMT_OK = 0, HAMT_ERR_ARG = -1, HAMT_ERR_UNSUPPORTED = -2, HAMT_ERR_LAUNCH = -3 } hamt_status;
 typedef enum { HAMT_F32 = 0, HAMT_BF16 = 1,
