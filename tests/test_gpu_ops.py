@@ -879,6 +879,49 @@ def test_ln_bf16_dense_input_and_bf16_saved_sum(M, H):
     assert cos > 0.9999, cos
 
 
+@pytest.mark.parametrize("M,N,K", [(5120, 768, 768), (2752, 768, 3072), (130, 96, 128), (33, 136, 64)])
+def test_half_dense_output_interface(M, N, K):
+    """HAMT_F16 (round 6): the dense layer in front of a LayerNorm stores IEEE half -- `C` of a plain / bias / accumulate hamt_gemm
+    (interior tiles through epi_fast8, ragged ones through epi_store), read back by hamt_ln_fwd as `x` and saved as `z` in the same
+    format.  Half's rounding (2^-11) instead of bf16's (2^-8); values beyond +-65504 saturate (never inf); any other epilogue is refused."""
+    ops = _ops()
+    from vln_hamt_amd import _lib as L
+    a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    a16, w16, b = a.to(DEV).to(torch.bfloat16), w.to(DEV).to(torch.bfloat16), bias.to(DEV)
+    ref = bf16_round(a).double() @ bf16_round(w).double().t() + bias.double()
+    oh = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ob = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a16, w16, oh, bias=b)
+    ops.gemm(a16, w16, ob, bias=b)
+    scale = float(ref.abs().max())
+    eh, eb = float((oh.double().cpu() - ref).abs().max()) / scale, float((ob.double().cpu() - ref).abs().max()) / scale
+    assert eh <= 2.0 ** -11 * 1.05 + 3e-6 * math.sqrt(K) and eb > 4 * eh, (eh, eb)        # one rounding of the fp32 accumulator, 8 x finer than bf16's
+    base = rnd(M, N, seed=4)
+    acc = base.to(DEV).to(torch.float16)
+    ops.gemm(a16, w16, acc, epilogue=L.EPI_ACCUM)
+    close(acc.float(), base.to(torch.float16).double() + (ref - bias.double()), 2e-3, "half C +=")
+    big = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a16, w16, big, bias=b, alpha=1e6)
+    assert bool(torch.isfinite(big).all()) and float(big.abs().max()) == 65504.0, "half C must saturate, not overflow"
+    with pytest.raises(L.HamtError):
+        ops.gemm(a16, w16, oh, bias=b, epilogue=L.EPI_GELU)
+    # the LayerNorm side: x as half == the same values given in fp32; z saved as half
+    if N % 4 == 0:
+        r = rnd(M, N, seed=5).to(DEV)
+        g, be = (1.0 + 0.1 * rnd(N, seed=6)).to(DEV), (0.1 * rnd(N, seed=7)).to(DEV)
+        ya, ya16, za, mean_a, rstd_a, _ = ops._ln_fwd(oh, r, g, be, 1e-12, 0.0, 0.0, True)
+        yb, yb16, zb, mean_b, rstd_b, _ = ops._ln_fwd(oh.float(), r, g, be, 1e-12, 0.0, 0.0, True)
+        assert za.dtype == torch.float16 and zb.dtype == torch.float32
+        assert torch.equal(ya, yb) and torch.equal(ya16[:M], yb16[:M]) and torch.equal(mean_a, mean_b) and torch.equal(rstd_a, rstd_b)
+        assert torch.equal(za, zb.to(torch.float16))
+        dy = rnd(M, N, seed=8).to(DEV)
+        dza, _, _, dga, dba, _ = ops._ln_bwd(dy, za, mean_a, rstd_a, g, 1e-12, 0.0, 0.0, 0, False, True, False)
+        dzb, _, _, dgb, dbb, _ = ops._ln_bwd(dy, zb, mean_b, rstd_b, g, 1e-12, 0.0, 0.0, 0, False, True, False)
+        assert torch.equal(dba, dbb)
+        assert float((dza - dzb).abs().max()) < 3e-3 * float(dzb.abs().max())          # (the bf16-saved sum: 2e-2, test above)
+        assert float((dga - dgb).abs().max()) < 3e-3 * float(dgb.abs().max())
+
+
 def test_ln_dropout_pre_post():
     ops = _ops()
     M, H, p = 512, 768, 0.1

@@ -47,7 +47,11 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint3
 // ---- IEEE half <-> f32 (HAMT_F16: the 2-byte format of a dense layer's output in front of a LayerNorm -- 10 mantissa bits, a
 // rounding 8 x finer than bf16's at the same bytes; round to nearest even, v_cvt_f16_f32)
 typedef __attribute__((ext_vector_type(2))) _Float16 hamt_h2;
+// Values beyond half's range SATURATE at +-65504 (one v_med3_f32 each) instead of becoming inf: the consumer is a LayerNorm, which an
+// inf turns into a row of NaN and a saturated outlier does not.  (HAMT's dense outputs are O(1 .. 100); the clamp is insurance.)
 __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  lo = __builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f);
+  hi = __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f);
   const hamt_h2 b = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(uint32_t, b);
 }
