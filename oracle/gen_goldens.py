@@ -13,6 +13,7 @@ Outputs (all small .npz; inputs + expected outputs, no reference source):
   canon_multi.npz     R2R-canon over two more weight seeds and at per-GPU batch 16: losses, trunk probes, gradient norms / probes,
                       single-candidate-logit gradients for ITM
   canon_multi_sar.npz the SAR gradient of the canon_multi draws term by term (single regression outputs)
+  canon_b64.npz / canon_b64_sar.npz   the same two for ONE draw at the BENCHMARKED per-GPU batch 64 (`canon_b64`, `canon_b64_sar`; ~25 min of CPU, ~25 GB)
   canon_ragged.npz    R2R-canon on RAGGED batches (L ~ U[20, 80], T ~ U[0, 7], B = 16): what the packed text path is compared with
   optim_tiny.npz      3 steps of clip(5.0) + reference AdamW + warmup schedule on the tiny model
   tiny_finetune.npz   NavCMT language / history / visual modes (incl. no_lang_ca)
@@ -592,6 +593,10 @@ def gen_collate():
 # per-GPU batch (16, pretrain_r2r.json) on two of them -- bf16 margins measured on ONE seed at B = 2 say little
 CANON_MULTI = [(7, 300, 2), (99, 500, 2), (2024, 700, 16), (7, 900, 16)]
 MULTI_PROBE = 65
+# (round 6) the BENCHMARKED per-GPU batch from the reference itself: the reference's goldens stopped at its own batch 16, the B = 64 model-level
+# comparison ran against the pinned oracle only.  Same content as canon_multi / canon_multi_sar, one draw, files canon_b64*.npz
+# (the history embeddings as a 64-column probe: the full tensor would be 1.2 MB per task).
+CANON_B64 = [(5, 6400, 64)]
 
 
 def grads_packed_n(named_params, prefix, n):
@@ -605,16 +610,17 @@ def grads_packed_n(named_params, prefix, n):
     return {f"{prefix}grad_names": np.array(names), f"{prefix}grad_norms": np.array(norms, dtype=np.float64), f"{prefix}grad_probes": np.stack(probes)}
 
 
-def gen_canon_multi():
-    """R2R-canon again over CANON_MULTI: per task the loss, trunk probes, per-parameter gradient norms and 65-point gradient
+def gen_canon_multi(cases=None, out="canon_multi.npz", hist_probe=False):
+    """R2R-canon again over CANON_MULTI (or `cases`): per task the loss, trunk probes, per-parameter gradient norms and 65-point gradient
     probes from the REFERENCE; for ITM additionally the gradients of single candidate logits (sum_b logits[b, k], k = 0 positive and
     k = 3 a shuffled negative): the loss gradient is a difference of five nearly equal such terms, so its cosine measures
     cancellation noise -- the terms themselves are gated like every other task."""
     torch.set_num_threads(8)
-    store = {"meta/cases": np.asarray(CANON_MULTI)}
+    cases = CANON_MULTI if cases is None else cases
+    store = {"meta/cases": np.asarray(cases)}
     cfg = OracleConfig()
     models = {}
-    for ci, (wseed, bseed, B) in enumerate(CANON_MULTI):
+    for ci, (wseed, bseed, B) in enumerate(cases):
         if wseed not in models:
             sd = make_state_dict(pretrain_param_shapes(cfg), seed=wseed)
             models[wseed] = build_ref_pretrain(cfg, sd)
@@ -637,7 +643,10 @@ def gen_canon_multi():
                     t, h, o = model.bert(g("txt_ids"), g("txt_masks"), g("hist_img_fts"), g("hist_ang_fts"), g("hist_pano_img_fts"),
                                          g("hist_pano_ang_fts"), g("hist_masks"), g("ob_img_fts"), g("ob_ang_fts"), g("ob_nav_types"), g("ob_masks"))
                     store[pre + "txt_probe"] = t[:, :4, :32].numpy().copy()
-                    store[pre + "hist_embeds"] = h.numpy()
+                    if hist_probe:
+                        store[pre + "hist_probe"] = h[:, :, :64].numpy().copy()
+                    else:
+                        store[pre + "hist_embeds"] = h.numpy()
                     if o is not None:
                         store[pre + "ob_probe"] = o[:, :, :16].numpy().copy()
             store[pre + "loss"] = loss.numpy()
@@ -659,20 +668,21 @@ def gen_canon_multi():
                     store.update(grads_packed_n(model.named_parameters(), pre + f"logit{k}/", MULTI_PROBE))
             model.zero_grad(set_to_none=True)
             print(f"  [canon multi c{ci} w{wseed} B{B} {task}] loss {loss.mean().item():.4f}", flush=True)
-    np.savez_compressed(os.path.join(OUT, "canon_multi.npz"), **store)
-    print("canon_multi.npz:", len(store), "arrays")
+    np.savez_compressed(os.path.join(OUT, out), **store)
+    print(out + ":", len(store), "arrays")
 
 
-def gen_canon_multi_sar():
-    """SAR on the CANON_MULTI draws, term by term: the loss gradient is sum_{b,k} (2 r_bk / 3B) d pred_bk, a sum over samples and the
+def gen_canon_multi_sar(cases=None, out="canon_multi_sar.npz"):
+    """SAR on the CANON_MULTI draws (or `cases`), term by term: the loss gradient is sum_{b,k} (2 r_bk / 3B) d pred_bk, a sum over samples and the
     three regression outputs whose residuals r have both signs -- on one B = 16 draw it cancels far enough that bf16 rounding of the
     TERMS shows in the cosine of the SUM.  Stored: the reference's predictions, targets and the gradients of the three single-output
     means d(mean_b pred[b, k]) (65-point probes + norms), which tests/ gate like every other gradient."""
     torch.set_num_threads(8)
-    store = {"meta/cases": np.asarray(CANON_MULTI)}
+    cases = CANON_MULTI if cases is None else cases
+    store = {"meta/cases": np.asarray(cases)}
     cfg = OracleConfig()
     models = {}
-    for ci, (wseed, bseed, B) in enumerate(CANON_MULTI):
+    for ci, (wseed, bseed, B) in enumerate(cases):
         if wseed not in models:
             models[wseed] = build_ref_pretrain(cfg, make_state_dict(pretrain_param_shapes(cfg), seed=wseed))
         model, vil = models[wseed]
@@ -687,8 +697,8 @@ def gen_canon_multi_sar():
         store[pre + "targets"] = torch.cat([batch["ob_action_angles"], batch["ob_progress"].unsqueeze(1)], 1).numpy()
         model.zero_grad(set_to_none=True)
         print(f"  [canon multi sar terms c{ci} w{wseed} B{B}]", flush=True)
-    np.savez_compressed(os.path.join(OUT, "canon_multi_sar.npz"), **store)
-    print("canon_multi_sar.npz:", len(store), "arrays")
+    np.savez_compressed(os.path.join(OUT, out), **store)
+    print(out + ":", len(store), "arrays")
 
 
 # ------------------------------------------------------------------------------------------------ ragged batches (the packed text path)
@@ -1008,4 +1018,6 @@ if __name__ == "__main__":
     for w in which:
         {"tiny": gen_tiny, "canon": gen_canon, "optim": gen_optim, "finetune": gen_finetune, "vit": gen_vit, "collate": gen_collate,
          "r2r_data": gen_r2r_data, "r2r_tasks": gen_r2r_tasks, "loader": gen_loader, "canon_multi": gen_canon_multi, "canon_ragged": gen_canon_ragged, "canon_multi_sar": gen_canon_multi_sar, "a2c": gen_a2c,
-         "canon_autocast": gen_canon_autocast}[w]()
+         "canon_autocast": gen_canon_autocast,
+         "canon_b64": lambda: gen_canon_multi(CANON_B64, "canon_b64.npz", hist_probe=True),
+         "canon_b64_sar": lambda: gen_canon_multi_sar(CANON_B64, "canon_b64_sar.npz")}[w]()

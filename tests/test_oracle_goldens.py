@@ -141,6 +141,40 @@ def test_canon_backward_matches_reference(task):
         np.testing.assert_allclose(grad_probe(g), probes[i], rtol=0, atol=2e-5 * max(1.0, float(np.abs(probes[i]).max())), err_msg=k)
 
 
+def test_oracle_matches_reference_at_the_benchmarked_batch():
+    """canon_b64.npz (round 6): the REFERENCE's losses at per-GPU batch 64 -- the batch bench.py times and tests/test_gpu_model.py compares the
+    HIP path with the oracle at -- reproduced by the oracle (forward of all six tasks), and its SAP backward against the reference's
+    per-parameter gradient norms / 65-point probes: the oracle is pinned at B = 64 too, not only at the reference's own B = 2 / 16."""
+    from _util import grad_probe
+    store = load_npz("canon_b64.npz")
+    wseed, bseed, B = (int(v) for v in store["meta/cases"][0])
+    cfg = OracleConfig()
+    sd = make_state_dict(pretrain_param_shapes(cfg), seed=wseed)
+    orc = HamtOracle(sd, cfg)
+    for i, task in enumerate(("mlm", "sap", "sar", "sprel", "mrc", "itm")):
+        pre = f"c0/{task}/"
+        batch = make_batch(task, B if task != "itm" else 2 * B, cfg, seed=bseed + i, txt_len=80, hist_len=5)
+        rng = sub(store, pre + "rng/")
+        itm = None
+        if rng:
+            itm = {"neg_idxs": torch.from_numpy(rng["neg_idxs"]),
+                   "shuffled_pos_ids": [torch.from_numpy(rng[k]) for k in sorted(rng) if k.startswith("shuffled")]}
+        with torch.no_grad():
+            loss = orc.forward(batch, task, True, itm)
+        np.testing.assert_allclose(loss.numpy(), store[pre + "loss"], rtol=2e-5, atol=2e-5, err_msg=task)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "mlm_head.predictions.decoder.weight"}
+    batch = make_batch("sap", B, cfg, seed=bseed + 1, txt_len=80, hist_len=5)
+    HamtOracle(osd, cfg).forward(batch, "sap", True, None).mean().backward()
+    names = [str(n) for n in store["c0/sap/grad_names"]]
+    norms, probes = store["c0/sap/grad_norms"], store["c0/sap/grad_probes"]
+    gmax = float(norms.max())
+    for i, k in enumerate(names):
+        g = osd[k].grad
+        assert g is not None, k
+        assert abs(float(g.double().norm()) - norms[i]) <= 1e-4 * max(norms[i], 1e-3 * gmax), (k, float(g.double().norm()), norms[i])
+        np.testing.assert_allclose(grad_probe(g, probes.shape[1]), probes[i], rtol=0, atol=2e-5 * max(1.0, float(np.abs(probes[i]).max())), err_msg=k)
+
+
 @pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
 def test_committed_tiny_goldens_match_their_generator(tmp_path, monkeypatch):
     """Generator <-> fixture drift guard: re-running oracle/gen_goldens.py's tiny set against the real reference
