@@ -218,6 +218,7 @@ def self_launch(n, argv, launcher=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes needs it)
     env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")          # (one node: no host-name lookups in a gloo rendezvous)
     cmd = launcher or [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
                        "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
     cmd = cmd + [os.path.abspath(__file__)] + list(argv)

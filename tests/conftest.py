@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The multi-process tests rendezvous on 127.0.0.1.  gloo otherwise starts by resolving the machine's hostname -- the container's may not
+# resolve -- and on some boxes of the pool the first few such tests of a run took 55-93 s instead of 5 (two of four full-suite runs of
+# round 6: +300 s); with the interface named no lookup is made, and a resolver that does get asked gives up after one second.
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+os.environ.setdefault("RES_OPTIONS", "timeout:1 attempts:1")
 
 
 def pytest_configure(config):

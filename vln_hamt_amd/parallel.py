@@ -35,6 +35,8 @@ def init_distributed(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):      # one node: gloo must not try to resolve the host name (it may not resolve)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend is None:
             # HAMT_DIST_BACKEND=gloo: functional testing of the multi-rank path with several ranks on ONE GPU (gloo stages
             # CUDA tensors through the host; RCCL refuses two ranks per device)
